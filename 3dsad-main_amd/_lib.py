@@ -1,0 +1,96 @@
+"""ctypes binding of ``csrc/libsad_amd.so`` (C-ABI declared in ``include/sad_amd.h``).
+
+No reference FFI exists to mirror (``/root/reference/README.md:1-2`` is the whole upstream
+repository); the entry points are the ones BASELINE.json ``north_star`` names.  Loading fails loudly
+when the library is missing — there is no CPU fallback anywhere in this package.
+"""
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+SO_PATH = os.path.join(CSRC, "libsad_amd.so")
+
+MAX_LAYERS = 4
+MAX_RADII = 4
+
+c_f32p = ctypes.POINTER(ctypes.c_float)
+c_i32p = ctypes.POINTER(ctypes.c_int32)
+vp = ctypes.c_void_p
+
+
+class MlpArgs(ctypes.Structure):
+    """``struct sad_mlp_args`` (include/sad_amd.h)."""
+    _fields_ = [
+        ("xyz", vp), ("new_xyz", vp), ("idx", vp), ("feat", vp),
+        ("ld_feat", ctypes.c_int),
+        ("B", ctypes.c_int), ("N", ctypes.c_int), ("M", ctypes.c_int), ("S", ctypes.c_int),
+        ("C", ctypes.c_int),
+        ("L", ctypes.c_int), ("dims", ctypes.c_int * (MAX_LAYERS + 1)),
+        ("packed", vp), ("relu_mask", ctypes.c_int),
+        ("out", vp), ("ld_out", ctypes.c_int), ("col_off", ctypes.c_int),
+    ]
+
+
+# name -> (restype, argtypes); every symbol include/sad_amd.h declares
+SIGNATURES = {
+    "sad_version": (ctypes.c_int, []),
+    "sad_last_error": (ctypes.c_char_p, []),
+    "sad_set_option": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_int]),
+    "sad_fps_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int]),
+    "sad_fps_f32": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp, vp]),
+    "sad_gather_xyz_f32": (ctypes.c_int, [vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp]),
+    "sad_gather_points": (ctypes.c_int, [vp, vp] + [ctypes.c_int] * 5 + [vp, vp]),
+    "sad_group_points": (ctypes.c_int, [vp, vp] + [ctypes.c_int] * 6 + [vp, vp]),
+    "sad_ball_query_f32": (ctypes.c_int, [vp, vp, ctypes.c_float, vp] + [ctypes.c_int] * 4 + [vp, vp]),
+    "sad_ball_query_multi_f32": (ctypes.c_int, [vp, vp, ctypes.c_int, c_f32p, vp,
+                                               ctypes.POINTER(ctypes.c_int), ctypes.POINTER(vp),
+                                               ctypes.c_int, ctypes.c_int, ctypes.c_int, vp]),
+    "sad_knn_f32": (ctypes.c_int, [vp, vp] + [ctypes.c_int] * 4 + [vp, vp]),
+    "sad_mlp_packed_floats": (ctypes.c_size_t, [ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.c_int]),
+    "sad_mlp_pack_f32": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.c_int,
+                                       ctypes.POINTER(vp), ctypes.POINTER(vp), vp, vp]),
+    "sad_mlp_chain_f32": (ctypes.c_int, [ctypes.POINTER(MlpArgs), vp]),
+    "sad_candidates_f32": (ctypes.c_int, [vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                         ctypes.c_float, ctypes.c_float, ctypes.c_float, c_f32p,
+                                         vp, vp, vp]),
+    "sad_decode_boxes_f32": (ctypes.c_int, [vp, vp, ctypes.c_int, ctypes.c_int, c_f32p, vp, vp]),
+}
+
+_lib = None
+
+
+def build(force: bool = False) -> str:
+    """Compile every HIP source for gfx950 with hipcc (csrc/Makefile).  Works without a GPU."""
+    cmd = ["make", "-C", CSRC, "-j4"] + (["-B"] if force else [])
+    subprocess.check_call(cmd, stdout=subprocess.DEVNULL)
+    return SO_PATH
+
+
+def lib():
+    """The loaded library.  Raises if it has not been built — the HIP path is the only path."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SO_PATH):
+            raise RuntimeError(
+                f"{SO_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; "
+                "g.build()'` (hipcc, gfx950).  sad_amd has no CPU fallback.")
+        handle = ctypes.CDLL(SO_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)  # AttributeError here = header/library mismatch
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(code: int, what: str) -> None:
+    """Turn a negative SAD_E* return code into a RuntimeError carrying sad_last_error()."""
+    if code != 0:
+        msg = lib().sad_last_error()
+        raise RuntimeError(f"{what} failed ({code}): {msg.decode() if msg else ''}")
+
+
+def set_option(key: str, value: int) -> None:
+    check(lib().sad_set_option(key.encode(), int(value)), "sad_set_option")

@@ -1,0 +1,31 @@
+// Library-wide entry points: version, thread-local error string, tuning options.
+#include <string.h>
+
+#include "common.h"
+
+namespace sad {
+
+static thread_local char g_err[512] = "";
+static int g_opt[OPT_COUNT] = {0, 0};
+
+void set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+}
+
+int get_option(int which) { return (which >= 0 && which < OPT_COUNT) ? g_opt[which] : 0; }
+
+}  // namespace sad
+
+SAD_API int sad_version(void) { return 1; }
+
+SAD_API const char *sad_last_error(void) { return sad::g_err; }
+
+SAD_API int sad_set_option(const char *key, int value) {
+    SAD_REQUIRE(key, "sad_set_option: NULL key");
+    if (!strcmp(key, "fps_dpp")) { sad::g_opt[sad::OPT_FPS_DPP] = value; return SAD_OK; }
+    if (!strcmp(key, "mlp_rw")) { sad::g_opt[sad::OPT_MLP_RW] = value; return SAD_OK; }
+    return sad::fail(SAD_EINVAL, "sad_set_option: unknown key '%s'", key);
+}

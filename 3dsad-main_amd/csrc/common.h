@@ -1,0 +1,48 @@
+// Shared host-side helpers for the libsad_amd.so translation units (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/sad_amd.h"
+
+#define SAD_API extern "C" __attribute__((visibility("default")))
+
+namespace sad {
+
+void set_error(const char *fmt, ...);
+int get_option(int which);
+enum { OPT_FPS_DPP = 0, OPT_MLP_RW = 1, OPT_COUNT };
+
+inline int fail(int code, const char *fmt, ...) {
+    char buf[480];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    set_error("%s", buf);
+    return code;
+}
+
+inline int check_launch(const char *what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(SAD_ELAUNCH, "%s: %s", what, hipGetErrorString(e));
+    return SAD_OK;
+}
+
+// SPEC.md §1 — the one squared-distance expression every index decision uses.  The library is
+// built with -ffp-contract=off so none of these multiplies/adds is fused.
+__device__ __forceinline__ float d2f(float px, float py, float pz, float cx, float cy, float cz) {
+    float dx = px - cx, dy = py - cy, dz = pz - cz;
+    float xx = dx * dx, yy = dy * dy, zz = dz * dz;
+    float s = xx + yy;
+    return s + zz;
+}
+
+}  // namespace sad
+
+#define SAD_REQUIRE(cond, ...)                                \
+    do {                                                      \
+        if (!(cond)) return sad::fail(SAD_EINVAL, __VA_ARGS__); \
+    } while (0)

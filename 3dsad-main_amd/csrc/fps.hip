@@ -1,0 +1,217 @@
+// Farthest point sampling for gfx950 (SPEC.md §2).  No reference source exists
+// (/root/reference/README.md:1-2 is the whole upstream repository).
+//
+// One workgroup per scene.  The scene's points and their running min-distances live in VGPRs
+// (PPT points per thread), so a sampling step touches no memory except the one broadcast read of
+// the last pick's coordinates: the kernel is bound by the serial chain of M steps (per step: PPT
+// distance updates per lane, a wave64 arg-max, one barrier, a 16-entry cross-wave arg-max), not by
+// HBM — compulsory traffic is N*12 B in and M*4 B out per scene.
+#include "common.h"
+
+namespace {
+
+// (d, i) is better than (bd, bi): larger distance, ties -> lower index (SPEC.md §2).
+__device__ __forceinline__ bool better(float d, int i, float bd, int bi) {
+    return d > bd || (d == bd && i < bi);
+}
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
+}
+template <int CTRL>
+__device__ __forceinline__ int dpp_i(int v) {
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, false);
+}
+
+// All-lanes arg-max over `width` lanes (width = 64 or 16), every lane ends with the winner.
+template <bool DPP, int WIDTH>
+__device__ __forceinline__ void wave_argmax(float &bd, int &bi) {
+    if constexpr (DPP) {
+        // in-row butterfly on DPP (no LDS crossbar): quad xor 1, quad xor 2, half-row mirror,
+        // row mirror; rows are then combined with two bpermute steps.
+#define SAD_STEP(CTRL)                                             \
+    {                                                              \
+        float od = dpp_f<CTRL>(bd);                                \
+        int oi = dpp_i<CTRL>(bi);                                  \
+        bool t = better(od, oi, bd, bi);                           \
+        bd = t ? od : bd;                                          \
+        bi = t ? oi : bi;                                          \
+    }
+        SAD_STEP(0xB1)   // quad_perm [1,0,3,2]
+        SAD_STEP(0x4E)   // quad_perm [2,3,0,1]
+        SAD_STEP(0x141)  // row_half_mirror
+        SAD_STEP(0x140)  // row_mirror
+#undef SAD_STEP
+        if constexpr (WIDTH == 64) {
+#pragma unroll
+            for (int off = 16; off <= 32; off <<= 1) {
+                float od = __shfl_xor(bd, off, 64);
+                int oi = __shfl_xor(bi, off, 64);
+                bool t = better(od, oi, bd, bi);
+                bd = t ? od : bd;
+                bi = t ? oi : bi;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int off = WIDTH / 2; off >= 1; off >>= 1) {
+            float od = __shfl_xor(bd, off, 64);
+            int oi = __shfl_xor(bi, off, 64);
+            bool t = better(od, oi, bd, bi);
+            bd = t ? od : bd;
+            bi = t ? oi : bi;
+        }
+    }
+}
+
+template <int THREADS, int PPT, bool DPP>
+__global__ __launch_bounds__(THREADS) void fps_reg_kernel(const float *__restrict__ xyz, int N,
+                                                          int M, int *__restrict__ idx_out) {
+    constexpr int NW = THREADS / 64;
+    static_assert(NW == 16 || NW == 4, "cross-wave reduce assumes 4 or 16 waves");
+    __shared__ float s_d[2][16];
+    __shared__ int s_i[2][16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float *p = xyz + (size_t)blockIdx.x * N * 3;
+    int *out = idx_out + (size_t)blockIdx.x * M;
+
+    float px[PPT], py[PPT], pz[PPT], md[PPT];
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+        const int j = k * THREADS + tid;
+        if (j < N) {
+            px[k] = p[j * 3 + 0];
+            py[k] = p[j * 3 + 1];
+            pz[k] = p[j * 3 + 2];
+            md[k] = __builtin_inff();
+        } else {  // padding never wins: real min-distances are >= 0
+            px[k] = py[k] = pz[k] = 0.f;
+            md[k] = -1.f;
+        }
+    }
+    if (tid == 0) out[0] = 0;
+    int last = 0;
+    for (int i = 1; i < M; ++i) {
+        const float cx = p[last * 3 + 0], cy = p[last * 3 + 1], cz = p[last * 3 + 2];
+        float bd = -1.f;
+        int bi = 0;
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) {
+            const float d = sad::d2f(px[k], py[k], pz[k], cx, cy, cz);
+            const float m = md[k] < d ? md[k] : d;
+            md[k] = m;
+            if (m > bd) {  // strict: ascending j inside the thread keeps the lowest index
+                bd = m;
+                bi = k * THREADS + tid;
+            }
+        }
+        wave_argmax<DPP, 64>(bd, bi);
+        const int buf = i & 1;
+        if (lane == 0) {
+            s_d[buf][wave] = bd;
+            s_i[buf][wave] = bi;
+        }
+        __syncthreads();
+        bd = s_d[buf][lane & (NW - 1)];
+        bi = s_i[buf][lane & (NW - 1)];
+        if constexpr (NW == 16) {
+            wave_argmax<DPP, 16>(bd, bi);
+        } else {
+#pragma unroll
+            for (int off = 2; off >= 1; off >>= 1) {
+                float od = __shfl_xor(bd, off, 64);
+                int oi = __shfl_xor(bi, off, 64);
+                bool t = better(od, oi, bd, bi);
+                bd = t ? od : bd;
+                bi = t ? oi : bi;
+            }
+        }
+        last = __builtin_amdgcn_readfirstlane(bi);
+        if (tid == 0) out[i] = last;
+    }
+}
+
+// Any N: min-distances in a global workspace (L2-resident), coordinates re-read every step.
+__global__ __launch_bounds__(1024) void fps_big_kernel(const float *__restrict__ xyz, int N, int M,
+                                                       float *__restrict__ mind_ws,
+                                                       int *__restrict__ idx_out) {
+    __shared__ float s_d[2][16];
+    __shared__ int s_i[2][16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float *p = xyz + (size_t)blockIdx.x * N * 3;
+    float *md = mind_ws + (size_t)blockIdx.x * N;
+    int *out = idx_out + (size_t)blockIdx.x * M;
+    for (int j = tid; j < N; j += 1024) md[j] = __builtin_inff();
+    if (tid == 0) out[0] = 0;
+    int last = 0;
+    for (int i = 1; i < M; ++i) {
+        const float cx = p[last * 3 + 0], cy = p[last * 3 + 1], cz = p[last * 3 + 2];
+        float bd = -1.f;
+        int bi = 0;
+        for (int j = tid; j < N; j += 1024) {  // each thread owns the same j every step
+            const float d = sad::d2f(p[j * 3 + 0], p[j * 3 + 1], p[j * 3 + 2], cx, cy, cz);
+            const float o = md[j];
+            const float m = o < d ? o : d;
+            md[j] = m;
+            if (m > bd) {
+                bd = m;
+                bi = j;
+            }
+        }
+        wave_argmax<false, 64>(bd, bi);
+        const int buf = i & 1;
+        if (lane == 0) {
+            s_d[buf][wave] = bd;
+            s_i[buf][wave] = bi;
+        }
+        __syncthreads();
+        bd = s_d[buf][lane & 15];
+        bi = s_i[buf][lane & 15];
+        wave_argmax<false, 16>(bd, bi);
+        last = __builtin_amdgcn_readfirstlane(bi);
+        if (tid == 0) out[i] = last;
+    }
+}
+
+template <int THREADS, int PPT>
+void launch_reg(const float *xyz, int B, int N, int M, int *idx, hipStream_t st, bool dpp) {
+    if (dpp)
+        hipLaunchKernelGGL((fps_reg_kernel<THREADS, PPT, true>), dim3(B), dim3(THREADS), 0, st, xyz, N, M, idx);
+    else
+        hipLaunchKernelGGL((fps_reg_kernel<THREADS, PPT, false>), dim3(B), dim3(THREADS), 0, st, xyz, N, M, idx);
+}
+
+}  // namespace
+
+SAD_API size_t sad_fps_workspace_bytes(int B, int N) {
+    if (B <= 0 || N <= 16384) return 0;
+    return (size_t)B * (size_t)N * sizeof(float);
+}
+
+SAD_API int sad_fps_f32(const float *xyz, int B, int N, int M, int32_t *idx, void *workspace,
+                        sad_stream_t stream) {
+    SAD_REQUIRE(xyz && idx, "sad_fps_f32: NULL pointer");
+    SAD_REQUIRE(B >= 1 && N >= 1 && M >= 1 && M <= N, "sad_fps_f32: need B>=1, 1<=M<=N (B=%d N=%d M=%d)", B, N, M);
+    SAD_REQUIRE((size_t)N * 3 < (1u << 31), "sad_fps_f32: N too large");
+    hipStream_t st = (hipStream_t)stream;
+    const bool dpp = sad::get_option(sad::OPT_FPS_DPP) != 0;
+    if (N > 16384) {
+        SAD_REQUIRE(workspace, "sad_fps_f32: N=%d > 16384 needs sad_fps_workspace_bytes() of workspace", N);
+        hipLaunchKernelGGL(fps_big_kernel, dim3(B), dim3(1024), 0, st, xyz, N, M, (float *)workspace, idx);
+        return sad::check_launch("sad_fps_f32");
+    }
+    if (N <= 2048) {
+        const int ppt = (N + 255) / 256;
+        if (ppt <= 1) launch_reg<256, 1>(xyz, B, N, M, idx, st, dpp);
+        else if (ppt <= 2) launch_reg<256, 2>(xyz, B, N, M, idx, st, dpp);
+        else if (ppt <= 4) launch_reg<256, 4>(xyz, B, N, M, idx, st, dpp);
+        else launch_reg<256, 8>(xyz, B, N, M, idx, st, dpp);
+    } else {
+        const int ppt = (N + 1023) / 1024;
+        if (ppt <= 4) launch_reg<1024, 4>(xyz, B, N, M, idx, st, dpp);
+        else if (ppt <= 8) launch_reg<1024, 8>(xyz, B, N, M, idx, st, dpp);
+        else launch_reg<1024, 16>(xyz, B, N, M, idx, st, dpp);
+    }
+    return sad::check_launch("sad_fps_f32");
+}

@@ -1,0 +1,98 @@
+// Candidate centres + adaptive radius (SPEC.md §8 steps 2-4) and box decode (SPEC.md §9).
+// No reference source exists (/root/reference/README.md:1-2).  Tiny element-wise kernels.
+#include "common.h"
+
+namespace {
+
+struct F3 { float v[3]; };
+struct F9 { float v[9]; };
+
+__global__ __launch_bounds__(256) void candidates_kernel(const float *__restrict__ xyz3,
+                                                         const float *__restrict__ c, int M3, int K,
+                                                         float shift_max, float r_min, float r_max,
+                                                         F3 anchor, float *__restrict__ cand,
+                                                         float *__restrict__ radius) {
+    const int b = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= K) return;
+    const float *ci = c + ((size_t)b * K + i) * 6;
+    const float *p = xyz3 + ((size_t)b * M3 + i) * 3;
+    float *o = cand + ((size_t)b * K + i) * 3;
+    float sz[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        float sh = ci[d];
+        sh = sh < -shift_max ? -shift_max : sh;
+        sh = sh > shift_max ? shift_max : sh;
+        o[d] = p[d] + sh;
+        float s = ci[3 + d];
+        s = s < -1.0f ? -1.0f : s;
+        s = s > 1.0f ? 1.0f : s;
+        const float t1 = s * s;
+        const float t2 = 0.5f * t1;
+        const float t3 = 1.0f + s;
+        const float q = t3 + t2;
+        sz[d] = anchor.v[d] * q;
+    }
+    const float ll = sz[0] * sz[0], ww = sz[1] * sz[1], hh = sz[2] * sz[2];
+    float sum = ll + ww;
+    sum = sum + hh;
+    float r = 0.5f * __fsqrt_rn(sum);  // correctly rounded, as sqrtf on the host
+    r = r < r_min ? r_min : r;
+    r = r > r_max ? r_max : r;
+    radius[(size_t)b * K + i] = r;
+}
+
+__global__ __launch_bounds__(256) void decode_kernel(const float *__restrict__ cand,
+                                                     const float *__restrict__ o, int total, F9 anchors,
+                                                     float *__restrict__ boxes) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= total) return;
+    const float *oi = o + (size_t)t * 10;
+    const float *p = cand + (size_t)t * 3;
+    float *bx = boxes + (size_t)t * 9;
+    int label = 0;
+    float best = oi[0];
+#pragma unroll
+    for (int k = 1; k < 3; ++k)
+        if (oi[k] > best) { best = oi[k]; label = k; }
+    const float score = 1.0f / (1.0f + expf(-best));
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        bx[d] = p[d] + oi[3 + d];
+        float e = oi[6 + d];
+        e = e < -2.0f ? -2.0f : e;
+        e = e > 2.0f ? 2.0f : e;
+        const float a = label == 0 ? anchors.v[d] : (label == 1 ? anchors.v[3 + d] : anchors.v[6 + d]);
+        bx[3 + d] = a * expf(e);
+    }
+    bx[6] = oi[9];
+    bx[7] = score;
+    bx[8] = (float)label;
+}
+
+}  // namespace
+
+SAD_API int sad_candidates_f32(const float *xyz3, const float *c, int B, int M3, int K,
+                               float shift_max, float r_min, float r_max, const float *anchor,
+                               float *cand, float *radius, sad_stream_t stream) {
+    SAD_REQUIRE(xyz3 && c && anchor && cand && radius, "sad_candidates_f32: NULL pointer");
+    SAD_REQUIRE(B >= 1 && B <= 65535 && K >= 1 && K <= M3, "sad_candidates_f32: need 1 <= K <= M3 (K=%d M3=%d)", K, M3);
+    F3 a{{anchor[0], anchor[1], anchor[2]}};
+    dim3 grid((K + 255) / 256, B);
+    hipLaunchKernelGGL(candidates_kernel, grid, dim3(256), 0, (hipStream_t)stream, xyz3, c, M3, K,
+                       shift_max, r_min, r_max, a, cand, radius);
+    return sad::check_launch("sad_candidates_f32");
+}
+
+SAD_API int sad_decode_boxes_f32(const float *cand, const float *o, int B, int K, const float *anchors,
+                                 float *boxes, sad_stream_t stream) {
+    SAD_REQUIRE(cand && o && anchors && boxes, "sad_decode_boxes_f32: NULL pointer");
+    SAD_REQUIRE(B >= 1 && K >= 1 && (long long)B * K < (1LL << 31), "sad_decode_boxes_f32: bad sizes");
+    F9 a;
+    for (int i = 0; i < 9; ++i) a.v[i] = anchors[i];
+    const int total = B * K;
+    hipLaunchKernelGGL(decode_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                       cand, o, total, a, boxes);
+    return sad::check_launch("sad_decode_boxes_f32");
+}

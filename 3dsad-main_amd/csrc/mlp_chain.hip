@@ -1,0 +1,480 @@
+// Fused group -> shared-MLP (1x1 conv + bias + ReLU chain) -> max-pool for gfx950 (SPEC.md §6).
+// No reference source exists (/root/reference/README.md:1-2 is the whole upstream repository).
+//
+// Formulation.  Every layer is computed TRANSPOSED on v_mfma_f32_32x32x2_f32:
+//     Y^T[oc, row] = W[oc, k] * X^T[k, row]        A = weights, B = activations, D = Y^T tile
+// so the MFMA output has the sample row on the lane (col = lane&31) and the output channels in the
+// 16 accumulator registers — exactly the [k][row] image the next layer reads as its B operand.
+// Activations of a tile of R = 32*RW*WM rows therefore stay in LDS as a [channel][row] image for the
+// whole chain (never in HBM); weights are pre-packed in A-fragment order (one coalesced 16-B load
+// per lane feeds four MFMAs) and stream from L2 straight into VGPRs through a 4-deep register ring.
+// The accumulator starts at the bias and the k-loop ascends, so each output is the fmaf chain of
+// SPEC.md §6 bit for bit (the MFMA is an exact k-ordered f32 fma chain on gfx950).
+//
+// Work split inside a workgroup of W waves: WN waves along the 32-channel output tiles, WM = W/WN
+// along the row tiles (RW row tiles of 32 rows per wave).  Narrow layers (SA1: one output tile) use
+// WN = 1 so every wave owns its own rows; wide layers use WN = W so all waves share one row tile
+// and the LDS image stays small.
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int MAXL = SAD_MAX_LAYERS;
+
+struct MlpParams {
+    const float *xyz;
+    const float *new_xyz;
+    const int32_t *idx;
+    const float *feat;
+    const float *packed;
+    float *out;
+    long long total_rows;  // B*M*Sp
+    int ld_feat, N, M, S, C;
+    int sp_shift;          // Sp = 1 << sp_shift rows per pooling group (Sp >= S)
+    int grouped;           // idx != NULL
+    int L;
+    int kp[MAXL];          // padded input channels of layer l (multiple of 8)
+    int np[MAXL];          // padded output channels of layer l (multiple of 32)
+    int cout_last;
+    long long off[MAXL];   // float offset of layer l inside `packed`
+    int relu_mask;
+    int ld_out, col_off;
+    int wn_shift;          // WN = 1 << wn_shift
+    int kc;                // layer-0 k-chunk (multiple of 8); == kp[0] when the whole input fits
+    int bufA_rows, bufB_rows;
+    int cpr, cshift;       // float4 chunks per feature row (0 = scalar path), log2 of lanes per row
+    int vec_out;           // 16-B output stores allowed
+};
+
+__device__ __forceinline__ float xor_max(float v, int off) {
+    const float o = __shfl_xor(v, off, 64);
+    return o > v ? o : v;
+}
+
+// One 8-deep k-step (four MFMA k-pairs) for all RW row tiles of this wave.
+template <int RW>
+__device__ __forceinline__ void kstep(f32x16 (&acc)[RW], const float4 a, const float *__restrict__ in,
+                                      int RP) {
+    const float av[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+#pragma unroll
+        for (int rt = 0; rt < RW; ++rt) {
+            const float bv = in[(2 * e) * RP + rt * 32];
+            acc[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], bv, acc[rt], 0, 0, 0);
+        }
+    }
+}
+
+template <int W, int RW>
+__global__ __launch_bounds__(W * 64) void mlp_chain_kernel(const MlpParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int j = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int WN = 1 << p.wn_shift;
+    const int WM = W >> p.wn_shift;
+    const int wn = wave & (WN - 1);
+    const int wm = wave >> p.wn_shift;
+    const int R = 32 * RW * WM;
+    const int RP = R + 1;
+    float *bufA = smem;
+    float *bufB = smem + (size_t)p.bufA_rows * RP;
+    int *sm_idx = reinterpret_cast<int *>(bufB + (size_t)p.bufB_rows * RP);
+    const long long r0 = (long long)blockIdx.x * R;
+    const int koff = p.grouped ? 4 : 0;
+    const int Sp = 1 << p.sp_shift;
+
+    // ---- per-row source index: grouped -> global point index b*N + idx, plain -> row -----------
+    for (int r = tid; r < R; r += W * 64) {
+        long long gr = r0 + r;
+        if (gr >= p.total_rows) gr = p.total_rows - 1;
+        if (p.grouped) {
+            const long long bm = gr >> p.sp_shift;
+            int s = (int)(gr & (Sp - 1));
+            if (s >= p.S) s = 0;  // padded sample repeats sample 0: the max-pool ignores duplicates
+            const int b = (int)(bm / p.M);
+            sm_idx[r] = (int)((long long)b * p.N + p.idx[bm * p.S + s]);
+        } else {
+            sm_idx[r] = (int)gr;
+        }
+    }
+    __syncthreads();
+
+    const int nchunks = (p.kp[0] + p.kc - 1) / p.kc;
+
+    for (int l = 0; l < p.L; ++l) {
+        const float *in = (l & 1) ? bufB : bufA;
+        float *outb = (l & 1) ? bufA : bufB;
+        const int n_oc = p.np[l] >> 5;
+        const int nrounds = (n_oc + WN - 1) >> p.wn_shift;
+        const float *wl = p.packed + p.off[l];
+        const float *bias = wl;
+        const float4 *frags = reinterpret_cast<const float4 *>(wl + p.np[l]);
+        const int nT4 = p.kp[l] >> 3;
+        const bool last = (l == p.L - 1);
+        const bool relu = (p.relu_mask >> l) & 1;
+        const int lchunks = (l == 0) ? nchunks : 1;
+
+        for (int round = 0; round < nrounds; ++round) {
+            const int oc = wn + (round << p.wn_shift);
+            const bool have = oc < n_oc;
+            f32x16 acc[RW];
+            if (have) {
+#pragma unroll
+                for (int g = 0; g < 16; ++g) {
+                    const float bv = bias[oc * 32 + 8 * (g >> 2) + (g & 3) + 4 * h];
+#pragma unroll
+                    for (int rt = 0; rt < RW; ++rt) acc[rt][g] = bv;
+                }
+            }
+            for (int ck = 0; ck < lchunks; ++ck) {
+                const int k0 = (l == 0) ? ck * p.kc : 0;
+                int k1 = (l == 0) ? k0 + p.kc : p.kp[l];
+                if (k1 > p.kp[l]) k1 = p.kp[l];
+                if (l == 0 && (round == 0 || lchunks > 1)) {
+                    // ---- stage input channels [k0,k1) of the tile into bufA (rows k - k0) -------
+                    if (!(round == 0 && ck == 0)) __syncthreads();  // previous readers are done
+                    if (p.grouped && k0 == 0) {  // rows 0..3 = point - centroid, 0 (SPEC.md §6)
+                        for (int r = tid; r < R; r += W * 64) {
+                            long long gr = r0 + r;
+                            if (gr >= p.total_rows) gr = p.total_rows - 1;
+                            const float *q = p.xyz + (long long)sm_idx[r] * 3;
+                            const float *c = p.new_xyz + (gr >> p.sp_shift) * 3;
+                            bufA[0 * RP + r] = q[0] - c[0];
+                            bufA[1 * RP + r] = q[1] - c[1];
+                            bufA[2 * RP + r] = q[2] - c[2];
+                            bufA[3 * RP + r] = 0.f;
+                        }
+                    }
+                    const int f0 = (k0 > koff ? k0 : koff) - koff;         // first feature channel
+                    int f1 = k1 - koff;                                    // one past the last
+                    const int fl = f1 < p.C ? f1 : p.C;
+                    if (p.cpr > 0) {
+                        const int cprp = 1 << p.cshift;
+                        const int rpp = 64 >> p.cshift;
+                        for (int r = wave * rpp + (lane >> p.cshift); r < R; r += W * rpp) {
+                            const float *src = p.feat + (long long)sm_idx[r] * p.ld_feat;
+                            for (int ch = (f0 >> 2) + (lane & (cprp - 1)); ch < (fl >> 2); ch += cprp) {
+                                const float4 v = *reinterpret_cast<const float4 *>(src + 4 * ch);
+                                float *d = bufA + (size_t)(koff + 4 * ch - k0) * RP + r;
+                                d[0] = v.x;
+                                d[RP] = v.y;
+                                d[2 * RP] = v.z;
+                                d[3 * RP] = v.w;
+                            }
+                        }
+                    } else {
+                        for (int r = tid; r < R; r += W * 64) {
+                            const float *src = p.feat + (long long)sm_idx[r] * p.ld_feat;
+                            for (int c = f0; c < fl; ++c) bufA[(size_t)(koff + c - k0) * RP + r] = src[c];
+                        }
+                    }
+                    // zero the channel padding [koff + C, kp) that falls inside this chunk
+                    const int z0 = (koff + p.C > k0 ? koff + p.C : k0);
+                    for (int k = z0 + wave; k < k1; k += W)
+                        for (int r = lane; r < R; r += 64) bufA[(size_t)(k - k0) * RP + r] = 0.f;
+                    __syncthreads();
+                }
+                if (have) {
+                    const float *inw = in + (size_t)h * RP + (wm * RW) * 32 + j;  // + k*RP per k-pair
+                    const float4 *af = frags + ((size_t)oc * nT4 + (k0 >> 3)) * 64 + lane;
+                    const int n4 = (k1 - k0) >> 3;
+                    float4 a0 = af[0];
+                    float4 a1 = af[(1 < n4 ? 1 : n4 - 1) * 64];
+                    float4 a2 = af[(2 < n4 ? 2 : n4 - 1) * 64];
+                    float4 a3 = af[(3 < n4 ? 3 : n4 - 1) * 64];
+                    for (int t = 0; t < n4; t += 4) {
+                        const float4 b0 = af[(t + 4 < n4 ? t + 4 : n4 - 1) * 64];
+                        const float4 b1 = af[(t + 5 < n4 ? t + 5 : n4 - 1) * 64];
+                        const float4 b2 = af[(t + 6 < n4 ? t + 6 : n4 - 1) * 64];
+                        const float4 b3 = af[(t + 7 < n4 ? t + 7 : n4 - 1) * 64];
+                        kstep<RW>(acc, a0, inw + (size_t)(8 * t) * RP, RP);
+                        if (t + 1 < n4) kstep<RW>(acc, a1, inw + (size_t)(8 * t + 8) * RP, RP);
+                        if (t + 2 < n4) kstep<RW>(acc, a2, inw + (size_t)(8 * t + 16) * RP, RP);
+                        if (t + 3 < n4) kstep<RW>(acc, a3, inw + (size_t)(8 * t + 24) * RP, RP);
+                        a0 = b0; a1 = b1; a2 = b2; a3 = b3;
+                    }
+                }
+            }
+            if (!have) continue;
+            // ---- epilogue ---------------------------------------------------------------------
+            if (relu) {
+#pragma unroll
+                for (int rt = 0; rt < RW; ++rt)
+#pragma unroll
+                    for (int g = 0; g < 16; ++g) acc[rt][g] = acc[rt][g] > 0.f ? acc[rt][g] : 0.f;
+            }
+            if (!last) {
+#pragma unroll
+                for (int rt = 0; rt < RW; ++rt)
+#pragma unroll
+                    for (int g = 0; g < 16; ++g)
+                        outb[(size_t)(oc * 32 + 8 * (g >> 2) + (g & 3) + 4 * h) * RP + (wm * RW + rt) * 32 + j] = acc[rt][g];
+            } else if (!p.grouped) {
+                // plain rows: lane (j,h) holds row j, channels oc*32 + 8a + 4h + (0..3)
+#pragma unroll
+                for (int rt = 0; rt < RW; ++rt) {
+                    const long long gr = r0 + (wm * RW + rt) * 32 + j;
+                    if (gr >= p.total_rows) continue;
+                    float *o = p.out + gr * p.ld_out + p.col_off;
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) {
+                        const int ch = oc * 32 + 8 * a + 4 * h;
+                        if (p.vec_out && ch + 3 < p.cout_last) {
+                            *reinterpret_cast<float4 *>(o + ch) = make_float4(acc[rt][4 * a], acc[rt][4 * a + 1], acc[rt][4 * a + 2], acc[rt][4 * a + 3]);
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                if (ch + e < p.cout_last) o[ch + e] = acc[rt][4 * a + e];
+                        }
+                    }
+                }
+            } else {
+                // max-pool over the Sp rows of each group, then the group leader writes 16 channels
+                if (p.sp_shift == 6) {
+#pragma unroll
+                    for (int rt = 0; rt + 1 < RW; rt += 2)
+#pragma unroll
+                        for (int g = 0; g < 16; ++g) acc[rt][g] = acc[rt + 1][g] > acc[rt][g] ? acc[rt + 1][g] : acc[rt][g];
+                }
+                const int lsteps = p.sp_shift < 5 ? p.sp_shift : 5;  // butterfly steps inside a half
+                const int rstep = (p.sp_shift == 6) ? 2 : 1;
+#pragma unroll
+                for (int rt = 0; rt < RW; rt += 1) {
+                    if (rstep == 2 && (rt & 1)) continue;
+#pragma unroll
+                    for (int g = 0; g < 16; ++g) {
+                        float v = acc[rt][g];
+                        for (int s = 0; s < lsteps; ++s) v = xor_max(v, 1 << s);
+                        acc[rt][g] = v;
+                    }
+                    const int gl = (p.sp_shift < 5) ? Sp : 32;      // lanes per group inside a half
+                    if ((j & (gl - 1)) != 0) continue;
+                    const long long row = r0 + (wm * RW + rt) * 32 + j;
+                    const long long grp = row >> p.sp_shift;
+                    if (row >= p.total_rows) continue;
+                    float *o = p.out + grp * p.ld_out + p.col_off;
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) {
+                        const int ch = oc * 32 + 8 * a + 4 * h;
+                        if (p.vec_out && ch + 3 < p.cout_last) {
+                            *reinterpret_cast<float4 *>(o + ch) = make_float4(acc[rt][4 * a], acc[rt][4 * a + 1], acc[rt][4 * a + 2], acc[rt][4 * a + 3]);
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                if (ch + e < p.cout_last) o[ch + e] = acc[rt][4 * a + e];
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ---- weight packing --------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pack_kernel(const float *__restrict__ Wm,
+                                                   const float *__restrict__ bias, int Cin, int Cout,
+                                                   int KP, int NP, int has_xyz,
+                                                   float *__restrict__ dst) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long nfrag = (long long)NP * KP;
+    if (t < NP) {
+        dst[t] = t < Cout ? bias[t] : 0.f;
+        return;
+    }
+    const long long q = t - NP;
+    if (q >= nfrag) return;
+    const int e = (int)(q & 3);
+    const int lane = (int)((q >> 2) & 63);
+    const long long blk = q >> 8;  // oc_tile * nT4 + t4
+    const int nT4 = KP >> 3;
+    const int t4 = (int)(blk % nT4);
+    const int oct = (int)(blk / nT4);
+    const int oc = oct * 32 + (lane & 31);
+    const int kpad = 8 * t4 + 2 * e + (lane >> 5);
+    int k = kpad;
+    bool ok = true;
+    if (has_xyz) {
+        if (kpad == 3) ok = false;       // the zero lane after x,y,z
+        else if (kpad > 3) k = kpad - 1;
+    }
+    ok = ok && (k < Cin) && (oc < Cout);
+    dst[t] = ok ? Wm[(size_t)oc * Cin + k] : 0.f;
+}
+
+inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+struct Geometry {
+    int kp[MAXL], np[MAXL];
+    long long off[MAXL];
+    long long total;
+};
+
+inline Geometry geometry(int L, const int *dims, int first_has_xyz) {
+    Geometry g{};
+    long long off = 0;
+    for (int l = 0; l < L; ++l) {
+        const int cin = dims[l] + ((l == 0 && first_has_xyz) ? 1 : 0);
+        g.kp[l] = round_up(cin, 8);
+        g.np[l] = round_up(dims[l + 1], 32);
+        g.off[l] = off;
+        off += (long long)g.np[l] + (long long)g.np[l] * g.kp[l];
+    }
+    g.total = off;
+    return g;
+}
+
+int check_dims(const char *fn, int L, const int *dims) {
+    if (L < 1 || L > MAXL || !dims) return sad::fail(SAD_EINVAL, "%s: L=%d not in 1..%d", fn, L, MAXL);
+    for (int l = 0; l <= L; ++l)
+        if (dims[l] < 1 || dims[l] > 4096) return sad::fail(SAD_EUNSUPPORTED, "%s: dims[%d]=%d not in 1..4096", fn, l, dims[l]);
+    return SAD_OK;
+}
+
+template <int W, int RW>
+int launch_mlp(const MlpParams &p, size_t lds, long long nblocks, hipStream_t st) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&mlp_chain_kernel<W, RW>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((mlp_chain_kernel<W, RW>), dim3((unsigned)nblocks), dim3(W * 64), lds, st, p);
+    return sad::check_launch("sad_mlp_chain_f32");
+}
+
+}  // namespace
+
+SAD_API size_t sad_mlp_packed_floats(int L, const int *dims, int first_has_xyz) {
+    if (L < 1 || L > MAXL || !dims) return 0;
+    return (size_t)geometry(L, dims, first_has_xyz).total;
+}
+
+SAD_API int sad_mlp_pack_f32(int L, const int *dims, int first_has_xyz, const float *const *Wm,
+                             const float *const *bias, float *packed, sad_stream_t stream) {
+    if (int e = check_dims("sad_mlp_pack_f32", L, dims)) return e;
+    SAD_REQUIRE(Wm && bias && packed, "sad_mlp_pack_f32: NULL pointer");
+    SAD_REQUIRE(!first_has_xyz || dims[0] >= 3, "sad_mlp_pack_f32: first_has_xyz needs dims[0] >= 3");
+    const Geometry g = geometry(L, dims, first_has_xyz);
+    for (int l = 0; l < L; ++l) {
+        SAD_REQUIRE(Wm[l] && bias[l], "sad_mlp_pack_f32: NULL weight pointer for layer %d", l);
+        const long long n = (long long)g.np[l] + (long long)g.np[l] * g.kp[l];
+        hipLaunchKernelGGL(pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                           (hipStream_t)stream, Wm[l], bias[l], dims[l], dims[l + 1], g.kp[l], g.np[l],
+                           (l == 0 && first_has_xyz) ? 1 : 0, packed + g.off[l]);
+    }
+    return sad::check_launch("sad_mlp_pack_f32");
+}
+
+SAD_API int sad_mlp_chain_f32(const sad_mlp_args *a, sad_stream_t stream) {
+    SAD_REQUIRE(a, "sad_mlp_chain_f32: NULL args");
+    if (int e = check_dims("sad_mlp_chain_f32", a->L, a->dims)) return e;
+    const bool grouped = a->idx != nullptr;
+    SAD_REQUIRE(a->packed && a->out, "sad_mlp_chain_f32: NULL packed/out");
+    SAD_REQUIRE(a->B >= 1 && a->M >= 1 && a->C >= 0, "sad_mlp_chain_f32: bad B/M/C");
+    SAD_REQUIRE(a->C == 0 || a->feat, "sad_mlp_chain_f32: C=%d but feat is NULL", a->C);
+    SAD_REQUIRE(a->C == 0 || a->ld_feat >= a->C, "sad_mlp_chain_f32: ld_feat=%d < C=%d", a->ld_feat, a->C);
+    if (grouped) {
+        SAD_REQUIRE(a->xyz && a->new_xyz, "sad_mlp_chain_f32: grouped mode needs xyz and new_xyz");
+        SAD_REQUIRE(a->N >= 1 && a->S >= 1 && a->S <= 64, "sad_mlp_chain_f32: need N>=1, 1<=S<=64 (S=%d)", a->S);
+        SAD_REQUIRE(a->dims[0] == a->C + 3, "sad_mlp_chain_f32: dims[0]=%d != C+3=%d", a->dims[0], a->C + 3);
+        SAD_REQUIRE((long long)a->B * a->N < (1LL << 31), "sad_mlp_chain_f32: B*N too large");
+    } else {
+        SAD_REQUIRE(a->S == 1, "sad_mlp_chain_f32: plain mode needs S == 1");
+        SAD_REQUIRE(a->C >= 1 && a->dims[0] == a->C, "sad_mlp_chain_f32: dims[0]=%d != C=%d", a->dims[0], a->C);
+        SAD_REQUIRE((long long)a->B * a->M < (1LL << 31), "sad_mlp_chain_f32: too many rows");
+    }
+    const int cout = a->dims[a->L];
+    SAD_REQUIRE(a->ld_out >= a->col_off + cout && a->col_off >= 0, "sad_mlp_chain_f32: ld_out=%d too small for col_off=%d + C_out=%d", a->ld_out, a->col_off, cout);
+
+    MlpParams p{};
+    const Geometry g = geometry(a->L, a->dims, grouped);
+    p.xyz = a->xyz; p.new_xyz = a->new_xyz; p.idx = a->idx; p.feat = a->feat; p.packed = a->packed;
+    p.out = a->out; p.ld_feat = a->ld_feat; p.N = a->N; p.M = a->M; p.S = a->S; p.C = a->C;
+    p.grouped = grouped; p.L = a->L; p.relu_mask = a->relu_mask; p.ld_out = a->ld_out;
+    p.col_off = a->col_off; p.cout_last = cout;
+    int sp_shift = 0;
+    while ((1 << sp_shift) < a->S) ++sp_shift;
+    p.sp_shift = sp_shift;
+    p.total_rows = (long long)a->B * a->M << sp_shift;
+    int max_noc = 1, min_noc = 1 << 30;
+    for (int l = 0; l < a->L; ++l) {
+        p.kp[l] = g.kp[l]; p.np[l] = g.np[l]; p.off[l] = g.off[l];
+        max_noc = g.np[l] / 32 > max_noc ? g.np[l] / 32 : max_noc;
+        min_noc = g.np[l] / 32 < min_noc ? g.np[l] / 32 : min_noc;
+    }
+    p.vec_out = (a->ld_out % 4 == 0 && a->col_off % 4 == 0 && ((uintptr_t)a->out % 16 == 0)) ? 1 : 0;
+    // feature staging: 16-B chunks when rows are 16-B aligned
+    if (a->C >= 4 && a->C % 4 == 0 && a->ld_feat % 4 == 0 && ((uintptr_t)a->feat % 16 == 0)) {
+        p.cpr = a->C / 4;
+        int cs = 0;
+        while ((1 << cs) < p.cpr && cs < 6) ++cs;
+        p.cshift = cs;
+    } else {
+        p.cpr = 0; p.cshift = 0;
+    }
+    // LDS rows: bufA holds inputs of even layers / outputs of odd layers, bufB the others
+    auto lds_rows = [&](int kc, int &ra, int &rb) {
+        ra = kc; rb = 1;
+        for (int l = 0; l < a->L; ++l) {
+            if (l == a->L - 1) break;  // the last layer's output never touches LDS
+            int &dst = (l & 1) ? ra : rb;
+            dst = g.np[l] > dst ? g.np[l] : dst;
+        }
+    };
+    // ---- choose the workgroup geometry -----------------------------------------------------
+    // W waves, WN along output tiles; R = 32*RW*(W/WN) rows per workgroup.
+    const size_t BUDGET2 = 78 * 1024, BUDGET1 = 156 * 1024;
+    int W = 4, wn_shift = 0, RW = 1, kc = g.kp[0];
+    auto lds_bytes = [&](int w, int wns, int rw, int kcc) {
+        int ra, rb;
+        lds_rows(kcc, ra, rb);
+        const size_t R = 32 * (size_t)rw * (w >> wns);
+        return ((size_t)(ra + rb) * (R + 1) + R) * 4 + 16;
+    };
+    {
+        if (max_noc >= 16 && min_noc >= 8) W = 8;
+        int wmax = 0;
+        while ((1 << (wmax + 1)) <= W) ++wmax;                 // log2(W)
+        int wns0 = 0;                                          // WN <= narrowest layer's tile count
+        while (wns0 < wmax && (1 << (wns0 + 1)) <= min_noc) ++wns0;
+        const int rw_min = (grouped && sp_shift == 6) ? 2 : 1; // 64-row pooling groups span 2 tiles
+        const int rw_opt = sad::get_option(sad::OPT_MLP_RW);
+        bool found = false;
+        // preference: fewest idle waves (small WN), then most rows per wave, two workgroups per CU
+        // before one, whole-input staging before k-chunked staging.
+        for (int pass = 0; pass < 3 && !found; ++pass) {
+            const size_t budget = pass == 0 ? BUDGET2 : BUDGET1;
+            const int kcc = pass < 2 ? g.kp[0] : (g.kp[0] < 256 ? g.kp[0] : 256);
+            for (int wns = wns0; wns <= wmax && !found; ++wns)
+                for (int rw = 4; rw >= rw_min && !found; rw >>= 1) {
+                    if ((rw_opt == 1 || rw_opt == 2 || rw_opt == 4) && rw != rw_opt && rw_opt >= rw_min) continue;
+                    if (lds_bytes(W, wns, rw, kcc) <= budget) {
+                        wn_shift = wns; RW = rw; kc = kcc; found = true;
+                    }
+                }
+        }
+        if (!found) return sad::fail(SAD_EUNSUPPORTED, "sad_mlp_chain_f32: layer widths do not fit LDS");
+    }
+    p.wn_shift = wn_shift;
+    p.kc = kc;
+    lds_rows(kc, p.bufA_rows, p.bufB_rows);
+    const size_t lds = lds_bytes(W, wn_shift, RW, kc);
+    const long long R = 32LL * RW * (W >> wn_shift);
+    const long long nblocks = (p.total_rows + R - 1) / R;
+    SAD_REQUIRE(nblocks < (1LL << 31), "sad_mlp_chain_f32: too many workgroups");
+    hipStream_t st = (hipStream_t)stream;
+    if (W == 8) {
+        if (RW == 1) return launch_mlp<8, 1>(p, lds, nblocks, st);
+        if (RW == 2) return launch_mlp<8, 2>(p, lds, nblocks, st);
+        return launch_mlp<8, 4>(p, lds, nblocks, st);
+    }
+    if (RW == 1) return launch_mlp<4, 1>(p, lds, nblocks, st);
+    if (RW == 2) return launch_mlp<4, 2>(p, lds, nblocks, st);
+    return launch_mlp<4, 4>(p, lds, nblocks, st);
+}

@@ -1,0 +1,121 @@
+"""The measured path end to end: 3-stage SA backbone -> size-adaptive cluster layer -> box/cls head
+(SPEC.md §7-§9, topology §11).  The upstream reference (``/root/reference/README.md:1-2``) names the
+idea ("size adaptive clustering") and ships no code; the mechanism is this repository's SPEC.md §8.
+
+Stream plan.  Sampling (fps -> gather) depends on coordinates only, so the serial FPS chain of all
+three stages runs on its own HIP stream, one 1024-thread workgroup per scene, while the grouping /
+MFMA-MLP kernels of the earlier stages fill the rest of the chip on the main stream; events hand
+each stage's centroids over.
+"""
+import ctypes
+from typing import Optional
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import ops
+from ._lib import check, lib
+from .config import DetectorConfig
+from .sa_module import SAModuleMSG
+
+
+class SADDetector(nn.Module):
+    def __init__(self, cfg: DetectorConfig, weights: dict, device, overlap_fps: bool = True):
+        super().__init__()
+        self.cfg = cfg
+        self.device = torch.device(device)
+        c = cfg.in_feat
+        self.stages = []
+        for si, st in enumerate(cfg.stages):
+            w = {f"b{i}": weights[f"sa{si + 1}.b{i}"] for i in range(len(st.mlps))}
+            if st.agg:
+                w["agg"] = weights[f"sa{si + 1}.agg"]
+            m = SAModuleMSG(c, st, self.device, w)
+            self.stages.append(m)
+            c = m.out_channels
+        self.cand_mlp = ops.PackedMLP(weights["cand"], False, self.device,
+                                      relu_mask=(1 << (len(weights["cand"]) - 1)) - 1)
+        self.cluster_branches = [ops.PackedMLP(weights[f"cluster.b{i}"], True, self.device)
+                                 for i in range(len(cfg.cluster_mlps))]
+        self.cluster_cat = sum(m[-1] for m in cfg.cluster_mlps)
+        self.cluster_agg = ops.PackedMLP(weights["cluster.agg"], False, self.device)
+        self.head = ops.PackedMLP(weights["head"], False, self.device,
+                                  relu_mask=(1 << (len(weights["head"]) - 1)) - 1)
+        self._anchor = (ctypes.c_float * 3)(*cfg.anchor_car)
+        self._anchors = (ctypes.c_float * 9)(*[v for a in cfg.anchors for v in a])
+        self.overlap_fps = overlap_fps
+        self._side = torch.cuda.Stream(device=self.device) if overlap_fps else None
+
+    def _sample_chain(self, xyz):
+        """All three stages' (new_xyz) — coordinates only."""
+        out = []
+        cur = xyz
+        for m in self.stages:
+            _, cur = m.sample(cur)
+            out.append(cur)
+        return out
+
+    def forward(self, points: torch.Tensor, trace: Optional[dict] = None) -> torch.Tensor:
+        """points [B,N,3+in_feat] f32 on the GPU -> boxes [B,K,9]."""
+        cfg = self.cfg
+        if not points.is_cuda:
+            raise RuntimeError("points: expected a GPU tensor (sad_amd has no CPU path)")
+        points = points.contiguous()
+        B, N, D = points.shape
+        xyz = points[:, :, :3].contiguous()
+        feat = points[:, :, 3:] if D > 3 else None   # strided view [B,N,in_feat], no copy
+        main = torch.cuda.current_stream()
+        if self.overlap_fps:
+            side = self._side
+            side.wait_stream(main)
+            evs = []
+            with torch.cuda.stream(side):
+                cur = xyz
+                centroids = []
+                for m in self.stages:
+                    _, cur = m.sample(cur)
+                    centroids.append(cur)
+                    ev = torch.cuda.Event()
+                    ev.record(side)
+                    evs.append(ev)
+            for t in centroids:
+                t.record_stream(main)
+            xyz.record_stream(side)
+        else:
+            centroids = self._sample_chain(xyz)
+            evs = [None] * len(centroids)
+        cur_xyz, cur_feat = xyz, feat
+        for si, m in enumerate(self.stages):
+            if evs[si] is not None:
+                main.wait_event(evs[si])
+            new_xyz = centroids[si]
+            cur_feat = m.group_and_pool(cur_xyz, cur_feat, new_xyz)
+            if trace is not None:
+                trace[f"sa{si + 1}"] = dict(new_xyz=new_xyz, out=cur_feat)
+            cur_xyz = new_xyz
+        # ---- size-adaptive cluster layer (SPEC.md §8) ----------------------------------------
+        K = cfg.n_cand
+        M3 = cur_xyz.shape[1]
+        c = self.cand_mlp.rows(cur_feat[:, :K, :])                      # [B,K,6]
+        cand = torch.empty((B, K, 3), dtype=torch.float32, device=points.device)
+        rad = torch.empty((B, K), dtype=torch.float32, device=points.device)
+        check(lib().sad_candidates_f32(cur_xyz.data_ptr(), c.data_ptr(), B, M3, K, cfg.shift_max,
+                                       cfg.r_min, cfg.r_max, self._anchor, cand.data_ptr(),
+                                       rad.data_ptr(), main.cuda_stream), "sad_candidates_f32")
+        idxs = ops.ball_query_multi(cfg.cluster_scales, cfg.cluster_nsamples, cur_xyz, cand, rad)
+        cat = torch.empty((B, K, self.cluster_cat), dtype=torch.float32, device=points.device)
+        off = 0
+        for mlp, idx in zip(self.cluster_branches, idxs):
+            mlp.grouped(cur_xyz, cur_feat, cand, idx, out=cat, col_off=off)
+            off += mlp.out_channels
+        cfeat = self.cluster_agg.rows(cat)
+        # ---- head + decode (SPEC.md §9) -------------------------------------------------------
+        o = self.head.rows(cfeat)                                        # [B,K,10]
+        boxes = torch.empty((B, K, 9), dtype=torch.float32, device=points.device)
+        check(lib().sad_decode_boxes_f32(cand.data_ptr(), o.data_ptr(), B, K, self._anchors,
+                                         boxes.data_ptr(), main.cuda_stream), "sad_decode_boxes_f32")
+        if trace is not None:
+            trace["cluster"] = dict(c=c, cand=cand, radius=rad, ball_idx=idxs, cat=cat, cfeat=cfeat,
+                                    head=o)
+        return boxes

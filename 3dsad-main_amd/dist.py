@@ -1,0 +1,45 @@
+"""Batch sharding across the GPUs of one node (SPEC.md §10).
+
+Scenes are independent, so the path shards with no data-path collective: rank r processes a
+contiguous slice of the batch, and ONE ``all_gather`` of the fixed-shape ``boxes [B_loc,K,9]``
+(9 216 B per scene — latency-bound, not link-bound) reassembles the result in rank order.  On
+ROCm the ``nccl`` backend is RCCL over xGMI; the same code runs on ``gloo`` for CPU tests.
+The upstream reference (``/root/reference/README.md:1-2``) has no distributed code to mirror.
+"""
+from typing import Callable, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def shard_range(total: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous [lo, hi) slice of ``total`` scenes for ``rank``; requires total % world == 0 so
+    every rank contributes the same fixed-shape tensor to the all_gather."""
+    if total % world != 0:
+        raise ValueError(f"batch {total} is not divisible by world size {world}")
+    per = total // world
+    return rank * per, (rank + 1) * per
+
+
+def all_gather_boxes(local_boxes: torch.Tensor, group=None) -> torch.Tensor:
+    """local [B_loc,K,9] on every rank -> [world*B_loc,K,9] in rank order (one collective)."""
+    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return local_boxes
+    world = dist.get_world_size(group)
+    local_boxes = local_boxes.contiguous()
+    out = torch.empty((world * local_boxes.shape[0],) + tuple(local_boxes.shape[1:]),
+                      dtype=local_boxes.dtype, device=local_boxes.device)
+    dist.all_gather_into_tensor(out, local_boxes, group=group)
+    return out
+
+
+def run_sharded(forward: Callable[[torch.Tensor], torch.Tensor], points: torch.Tensor,
+                group=None) -> torch.Tensor:
+    """``points`` [B,N,D] is the GLOBAL batch (same on every rank, or at least this rank's slice
+    valid); each rank runs ``forward`` on its slice and the boxes are all-gathered."""
+    if dist.is_available() and dist.is_initialized():
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+    else:
+        rank, world = 0, 1
+    lo, hi = shard_range(points.shape[0], rank, world)
+    return all_gather_boxes(forward(points[lo:hi]), group)

@@ -1,0 +1,274 @@
+"""Python operator surface: ``fps / ball_query / knn_query / group_points / gather_points`` plus
+the fused grouped-MLP (``PackedMLP`` / ``mlp_chain``).
+
+Names and argument order are the ones BASELINE.json ``north_star`` fixes ("keeps the reference's
+Python operator surface (fps / ball_query / group_points / sa_module)"); the upstream reference
+itself (``/root/reference/README.md:1-2``) defines none, so semantics are SPEC.md §2-§6.
+
+Every function takes CUDA(=HIP) tensors, enqueues hand-written gfx950 kernels on the current torch
+stream through the C-ABI (``include/sad_amd.h``) and returns without synchronising.  There is no CPU
+path: a CPU tensor raises ``RuntimeError``.  torch is used for device memory and streams only.
+"""
+import ctypes
+from typing import List, Optional, Sequence, Tuple, Union
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import MlpArgs, check, lib, vp
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _need(t: torch.Tensor, name: str, dtype, ndim: int) -> torch.Tensor:
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name}: expected a torch.Tensor")
+    if not t.is_cuda:
+        raise RuntimeError(f"{name}: expected a GPU tensor (sad_amd has no CPU path)")
+    if dtype is not None and t.dtype != dtype:
+        raise TypeError(f"{name}: expected dtype {dtype}, got {t.dtype}")
+    if t.dim() != ndim:
+        raise ValueError(f"{name}: expected {ndim} dims, got shape {tuple(t.shape)}")
+    return t.contiguous()
+
+
+def fps(xyz: torch.Tensor, npoint: int) -> torch.Tensor:
+    """Farthest point sampling (SPEC.md §2).  xyz [B,N,3] f32 -> idx [B,npoint] int32."""
+    xyz = _need(xyz, "xyz", torch.float32, 3)
+    B, N, three = xyz.shape
+    if three != 3:
+        raise ValueError("xyz: last dim must be 3")
+    if not 1 <= npoint <= N:
+        raise ValueError(f"npoint={npoint} must be in 1..N={N}")
+    idx = torch.empty((B, npoint), dtype=torch.int32, device=xyz.device)
+    ws_bytes = lib().sad_fps_workspace_bytes(B, N)
+    ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=xyz.device) if ws_bytes else None
+    check(lib().sad_fps_f32(xyz.data_ptr(), B, N, npoint, idx.data_ptr(),
+                            ws.data_ptr() if ws is not None else None, _stream()), "sad_fps_f32")
+    return idx
+
+
+def gather_xyz(xyz: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
+    """xyz [B,N,3], idx [B,M] -> [B,M,3] (SPEC.md §5)."""
+    xyz = _need(xyz, "xyz", torch.float32, 3)
+    idx = _need(idx, "idx", torch.int32, 2)
+    B, N, _ = xyz.shape
+    M = idx.shape[1]
+    out = torch.empty((B, M, 3), dtype=torch.float32, device=xyz.device)
+    check(lib().sad_gather_xyz_f32(xyz.data_ptr(), idx.data_ptr(), B, N, M, out.data_ptr(), _stream()),
+          "sad_gather_xyz_f32")
+    return out
+
+
+def gather_points(features: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
+    """features [B,C,N] (f32/bf16/f16), idx [B,M] -> [B,C,M] (SPEC.md §5)."""
+    features = _need(features, "features", None, 3)
+    idx = _need(idx, "idx", torch.int32, 2)
+    esz = features.element_size()
+    if esz not in (2, 4):
+        raise TypeError("features: element size must be 2 or 4 bytes")
+    B, C, N = features.shape
+    M = idx.shape[1]
+    out = torch.empty((B, C, M), dtype=features.dtype, device=features.device)
+    check(lib().sad_gather_points(features.data_ptr(), idx.data_ptr(), B, C, N, M, esz,
+                                  out.data_ptr(), _stream()), "sad_gather_points")
+    return out
+
+
+def group_points(features: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
+    """features [B,C,N] (f32/bf16/f16), idx [B,M,S] -> [B,C,M,S] (SPEC.md §5)."""
+    features = _need(features, "features", None, 3)
+    idx = _need(idx, "idx", torch.int32, 3)
+    esz = features.element_size()
+    if esz not in (2, 4):
+        raise TypeError("features: element size must be 2 or 4 bytes")
+    B, C, N = features.shape
+    _, M, S = idx.shape
+    out = torch.empty((B, C, M, S), dtype=features.dtype, device=features.device)
+    check(lib().sad_group_points(features.data_ptr(), idx.data_ptr(), B, C, N, M, S, esz,
+                                 out.data_ptr(), _stream()), "sad_group_points")
+    return out
+
+
+def ball_query(radius: Union[float, torch.Tensor], nsample: int, xyz: torch.Tensor,
+               new_xyz: torch.Tensor) -> torch.Tensor:
+    """Ball query (SPEC.md §3).  ``radius``: Python float (fixed) or [B,M] f32 tensor (adaptive,
+    per centroid).  xyz [B,N,3], new_xyz [B,M,3] -> idx [B,M,nsample] int32."""
+    xyz = _need(xyz, "xyz", torch.float32, 3)
+    new_xyz = _need(new_xyz, "new_xyz", torch.float32, 3)
+    B, N, _ = xyz.shape
+    M = new_xyz.shape[1]
+    if new_xyz.shape[0] != B:
+        raise ValueError("xyz / new_xyz batch mismatch")
+    idx = torch.empty((B, M, nsample), dtype=torch.int32, device=xyz.device)
+    if isinstance(radius, torch.Tensor):
+        rad = _need(radius, "radius", torch.float32, 2)
+        if tuple(rad.shape) != (B, M):
+            raise ValueError(f"radius tensor must be [B,M]=({B},{M})")
+        check(lib().sad_ball_query_f32(xyz.data_ptr(), new_xyz.data_ptr(), 0.0, rad.data_ptr(), B, N, M,
+                                       nsample, idx.data_ptr(), _stream()), "sad_ball_query_f32")
+    else:
+        check(lib().sad_ball_query_f32(xyz.data_ptr(), new_xyz.data_ptr(), float(np.float32(radius)),
+                                       None, B, N, M, nsample, idx.data_ptr(), _stream()),
+              "sad_ball_query_f32")
+    return idx
+
+
+def ball_query_multi(radii: Sequence[float], nsamples: Sequence[int], xyz: torch.Tensor,
+                     new_xyz: torch.Tensor, radius_pc: Optional[torch.Tensor] = None
+                     ) -> List[torch.Tensor]:
+    """Several radii over the same (xyz, new_xyz): d2 is evaluated once per pair.  With
+    ``radius_pc`` [B,M] the radius of branch r for centroid (b,m) is radii[r]*radius_pc[b,m]
+    (SPEC.md §8 step 5).  Returns one idx [B,M,nsamples[r]] per radius."""
+    xyz = _need(xyz, "xyz", torch.float32, 3)
+    new_xyz = _need(new_xyz, "new_xyz", torch.float32, 3)
+    B, N, _ = xyz.shape
+    M = new_xyz.shape[1]
+    n = len(radii)
+    if n != len(nsamples) or not 1 <= n <= _lib.MAX_RADII:
+        raise ValueError(f"need 1..{_lib.MAX_RADII} radii with matching nsamples")
+    outs = [torch.empty((B, M, s), dtype=torch.int32, device=xyz.device) for s in nsamples]
+    r_arr = (ctypes.c_float * n)(*[float(np.float32(r)) for r in radii])
+    s_arr = (ctypes.c_int * n)(*[int(s) for s in nsamples])
+    p_arr = (vp * n)(*[o.data_ptr() for o in outs])
+    pc = None
+    if radius_pc is not None:
+        radius_pc = _need(radius_pc, "radius_pc", torch.float32, 2)
+        if tuple(radius_pc.shape) != (B, M):
+            raise ValueError(f"radius_pc must be [B,M]=({B},{M})")
+        pc = radius_pc.data_ptr()
+    check(lib().sad_ball_query_multi_f32(xyz.data_ptr(), new_xyz.data_ptr(), n, r_arr, pc, s_arr, p_arr,
+                                         B, N, M, _stream()), "sad_ball_query_multi_f32")
+    return outs
+
+
+def knn_query(k: int, xyz: torch.Tensor, new_xyz: torch.Tensor) -> torch.Tensor:
+    """k nearest neighbours sorted by (d2, index) (SPEC.md §4).  -> idx [B,M,k] int32."""
+    xyz = _need(xyz, "xyz", torch.float32, 3)
+    new_xyz = _need(new_xyz, "new_xyz", torch.float32, 3)
+    B, N, _ = xyz.shape
+    M = new_xyz.shape[1]
+    idx = torch.empty((B, M, k), dtype=torch.int32, device=xyz.device)
+    check(lib().sad_knn_f32(xyz.data_ptr(), new_xyz.data_ptr(), B, N, M, k, idx.data_ptr(), _stream()),
+          "sad_knn_f32")
+    return idx
+
+
+class PackedMLP:
+    """A shared-MLP chain (SPEC.md §6) with weights repacked once into MFMA A-fragment order.
+
+    ``layers`` = [(W [C_out,C_in], b [C_out]), ...] as numpy arrays or tensors (BatchNorm already
+    folded).  ``first_has_xyz``: the first layer's input is [rel_xyz(3) ‖ features(C_in-3)].
+    ``relu_mask`` bit l = ReLU after layer l (default: all layers).
+    """
+
+    def __init__(self, layers, first_has_xyz: bool, device, relu_mask: Optional[int] = None):
+        if not 1 <= len(layers) <= _lib.MAX_LAYERS:
+            raise ValueError(f"1..{_lib.MAX_LAYERS} layers supported")
+        self.device = torch.device(device)
+        ws, bs = [], []
+        for w, b in layers:
+            ws.append(torch.as_tensor(w, dtype=torch.float32).to(self.device).contiguous())
+            bs.append(torch.as_tensor(b, dtype=torch.float32).to(self.device).contiguous())
+        self.dims = [ws[0].shape[1]] + [w.shape[0] for w in ws]
+        for a, b in zip(ws[:-1], ws[1:]):
+            if b.shape[1] != a.shape[0]:
+                raise ValueError("layer shapes do not chain")
+        self.L = len(ws)
+        self.first_has_xyz = bool(first_has_xyz)
+        self.relu_mask = (1 << self.L) - 1 if relu_mask is None else int(relu_mask)
+        dims_c = (ctypes.c_int * (self.L + 1))(*self.dims)
+        n = lib().sad_mlp_packed_floats(self.L, dims_c, int(self.first_has_xyz))
+        self.packed = torch.empty((n,), dtype=torch.float32, device=self.device)
+        w_arr = (vp * self.L)(*[w.data_ptr() for w in ws])
+        b_arr = (vp * self.L)(*[b.data_ptr() for b in bs])
+        with torch.cuda.device(self.device):
+            check(lib().sad_mlp_pack_f32(self.L, dims_c, int(self.first_has_xyz), w_arr, b_arr,
+                                         self.packed.data_ptr(), _stream()), "sad_mlp_pack_f32")
+            torch.cuda.current_stream().synchronize()  # ws/bs may be freed after this returns
+        self.out_channels = self.dims[-1]
+
+    def _args(self) -> MlpArgs:
+        a = MlpArgs()
+        a.L = self.L
+        for i, d in enumerate(self.dims):
+            a.dims[i] = d
+        a.packed = self.packed.data_ptr()
+        a.relu_mask = self.relu_mask
+        return a
+
+    def grouped(self, xyz: torch.Tensor, feat_pm: Optional[torch.Tensor], new_xyz: torch.Tensor,
+                idx: torch.Tensor, out: Optional[torch.Tensor] = None, col_off: int = 0
+                ) -> torch.Tensor:
+        """Fused group -> MLP -> max over nsample.  xyz [B,N,3]; feat_pm point-major [B,N,C] (or
+        None); new_xyz [B,M,3]; idx [B,M,S].  Writes out[:, :, col_off:col_off+C_out] of a
+        point-major [B,M,ld_out] buffer (allocated [B,M,C_out] when ``out`` is None)."""
+        if not self.first_has_xyz:
+            raise RuntimeError("this PackedMLP was packed without the xyz prefix")
+        xyz = _need(xyz, "xyz", torch.float32, 3)
+        new_xyz = _need(new_xyz, "new_xyz", torch.float32, 3)
+        idx = _need(idx, "idx", torch.int32, 3)
+        B, N, _ = xyz.shape
+        _, M, S = idx.shape
+        a = self._args()
+        if feat_pm is None:
+            C = 0
+        else:
+            if not feat_pm.is_cuda or feat_pm.dtype != torch.float32 or feat_pm.dim() != 3:
+                raise TypeError("feat_pm: expected a GPU float32 [B,N,C] tensor")
+            if feat_pm.stride(2) != 1 or feat_pm.stride(0) != N * feat_pm.stride(1):
+                feat_pm = feat_pm.contiguous()
+            C = feat_pm.shape[2]
+            a.feat = feat_pm.data_ptr()
+            a.ld_feat = feat_pm.stride(1)
+        if self.dims[0] != C + 3:
+            raise ValueError(f"MLP expects {self.dims[0] - 3} feature channels, got {C}")
+        if out is None:
+            out = torch.empty((B, M, self.out_channels), dtype=torch.float32, device=xyz.device)
+        self._check_out(out, B * M, col_off)
+        a.xyz, a.new_xyz, a.idx = xyz.data_ptr(), new_xyz.data_ptr(), idx.data_ptr()
+        a.B, a.N, a.M, a.S, a.C = B, N, M, S, C
+        a.out, a.ld_out, a.col_off = out.data_ptr(), out.stride(-2), col_off
+        check(lib().sad_mlp_chain_f32(ctypes.byref(a), _stream()), "sad_mlp_chain_f32")
+        return out
+
+    def rows(self, x: torch.Tensor, out: Optional[torch.Tensor] = None, col_off: int = 0
+             ) -> torch.Tensor:
+        """Plain rows.  x [..., C] point-major (last-dim stride 1) -> [..., C_out]."""
+        if self.first_has_xyz:
+            raise RuntimeError("this PackedMLP was packed with the xyz prefix")
+        if not x.is_cuda or x.dtype != torch.float32:
+            raise TypeError("x: expected a GPU float32 tensor")
+        C = x.shape[-1]
+        if C != self.dims[0]:
+            raise ValueError(f"MLP expects {self.dims[0]} channels, got {C}")
+        x2 = x.reshape(-1, C)
+        if x2.stride(1) != 1:
+            x2 = x2.contiguous()
+        R = x2.shape[0]
+        if out is None:
+            out = torch.empty(tuple(x.shape[:-1]) + (self.out_channels,), dtype=torch.float32,
+                              device=x.device)
+        self._check_out(out, R, col_off)
+        a = self._args()
+        a.feat, a.ld_feat = x2.data_ptr(), x2.stride(0)
+        a.B, a.N, a.M, a.S, a.C = 1, 0, R, 1, C
+        a.out, a.ld_out, a.col_off = out.data_ptr(), out.stride(-2), col_off
+        check(lib().sad_mlp_chain_f32(ctypes.byref(a), _stream()), "sad_mlp_chain_f32")
+        return out
+
+    def _check_out(self, out: torch.Tensor, rows: int, col_off: int) -> None:
+        if not out.is_cuda or out.dtype != torch.float32 or out.stride(-1) != 1:
+            raise TypeError("out: expected a GPU float32 tensor with unit last-dim stride")
+        if out.numel() // out.shape[-1] != rows or not out.is_contiguous():
+            raise ValueError("out: expected a contiguous [rows, ld_out] buffer")
+        if col_off < 0 or col_off + self.out_channels > out.shape[-1]:
+            raise ValueError("out: col_off + C_out exceeds the buffer width")
+
+
+def mlp_chain(x: torch.Tensor, layers, relu_mask: Optional[int] = None) -> torch.Tensor:
+    """One-shot convenience: pack ``layers`` and apply them to rows x [..., C]."""
+    return PackedMLP(layers, False, x.device, relu_mask).rows(x)

@@ -1,0 +1,96 @@
+"""``sa_module``: multi-radius set abstraction (SPEC.md §7) on the fused HIP path.
+
+Drop-in surface named by BASELINE.json ``north_star`` (the upstream reference,
+``/root/reference/README.md:1-2``, defines none): ``forward(xyz [B,N,3], features [B,C,N]) ->
+(new_xyz [B,M,3], new_features [B,C',M])``.  Internally features are kept point-major ([B,N,C]) so a
+neighbour's feature row is one contiguous gather; ``forward_pm`` exposes that layout to callers that
+chain stages (the detector), skipping the two transposes of the channel-major surface.
+
+Pipeline per call: fps -> gather_xyz -> one multi-radius ball query (d2 evaluated once for all
+radii) -> per branch one fused gather+MLP+max kernel writing straight into its slice of the
+concatenated [B,M,sum C_b] buffer -> optional aggregation layer.  The grouped tensor
+[B,C+3,M,S] is never materialised.
+"""
+from typing import Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import ops
+from .config import SAStage
+from .synth import make_mlp_weights
+
+
+class SAModuleMSG(nn.Module):
+    """Multi-scale-grouping set abstraction.  ``weights`` = {"b<i>": [(W,b),...], "agg": [(W,b)]}
+    as numpy arrays (BatchNorm folded); seeded Kaiming-uniform weights are drawn when omitted."""
+
+    def __init__(self, in_channels: int, stage: SAStage, device, weights: Optional[dict] = None,
+                 seed: int = 0):
+        super().__init__()
+        self.stage = stage
+        self.in_channels = in_channels
+        self.device = torch.device(device)
+        if weights is None:
+            rng = np.random.default_rng(seed)
+            weights = {f"b{i}": make_mlp_weights([in_channels + 3] + list(m), rng)
+                       for i, m in enumerate(stage.mlps)}
+            if stage.agg:
+                weights["agg"] = make_mlp_weights([sum(m[-1] for m in stage.mlps), stage.agg], rng)
+        self.branches = [ops.PackedMLP(weights[f"b{i}"], True, self.device)
+                         for i in range(len(stage.mlps))]
+        self.cat_channels = sum(m[-1] for m in stage.mlps)
+        self.agg = ops.PackedMLP(weights["agg"], False, self.device) if stage.agg else None
+        self.out_channels = stage.agg if stage.agg else self.cat_channels
+
+    def sample(self, xyz: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        """fps + gather: (fps_idx [B,M], new_xyz [B,M,3]).  Depends on coordinates only."""
+        fidx = ops.fps(xyz, self.stage.npoint)
+        return fidx, ops.gather_xyz(xyz, fidx)
+
+    def group_and_pool(self, xyz: torch.Tensor, feat_pm: Optional[torch.Tensor],
+                       new_xyz: torch.Tensor, radius_pc: Optional[torch.Tensor] = None,
+                       radii: Optional[Sequence[float]] = None) -> torch.Tensor:
+        """ball query + fused MLP/max for every branch + aggregation -> [B,M,C'] point-major."""
+        st = self.stage
+        B, M = new_xyz.shape[0], new_xyz.shape[1]
+        idxs = ops.ball_query_multi(radii if radii is not None else st.radii, st.nsamples, xyz,
+                                    new_xyz, radius_pc)
+        cat = torch.empty((B, M, self.cat_channels), dtype=torch.float32, device=xyz.device)
+        off = 0
+        for mlp, idx in zip(self.branches, idxs):
+            mlp.grouped(xyz, feat_pm, new_xyz, idx, out=cat, col_off=off)
+            off += mlp.out_channels
+        return self.agg.rows(cat) if self.agg is not None else cat
+
+    def forward_pm(self, xyz: torch.Tensor, feat_pm: Optional[torch.Tensor]
+                   ) -> Tuple[torch.Tensor, torch.Tensor]:
+        """Point-major fast path: feat_pm [B,N,C] -> (new_xyz [B,M,3], new_feat_pm [B,M,C'])."""
+        _, new_xyz = self.sample(xyz)
+        return new_xyz, self.group_and_pool(xyz, feat_pm, new_xyz)
+
+    def forward(self, xyz: torch.Tensor, features: Optional[torch.Tensor]
+                ) -> Tuple[torch.Tensor, torch.Tensor]:
+        """Drop-in surface: features [B,C,N] channel-major -> (new_xyz, new_features [B,C',M])."""
+        feat_pm = features.transpose(1, 2).contiguous() if features is not None else None
+        new_xyz, out_pm = self.forward_pm(xyz, feat_pm)
+        return new_xyz, out_pm.transpose(1, 2).contiguous()
+
+
+class SAModule(SAModuleMSG):
+    """Single-radius set abstraction = the one-branch case (BASELINE.json configs[0])."""
+
+    def __init__(self, in_channels: int, npoint: int, radius: float, nsample: int,
+                 mlp: Sequence[int], device, weights: Optional[dict] = None, seed: int = 0):
+        super().__init__(in_channels, SAStage(npoint, (radius,), (nsample,), (tuple(mlp),), 0),
+                         device, weights, seed)
+
+
+def sa_module(xyz: torch.Tensor, features: Optional[torch.Tensor], npoint: int, radius: float,
+              nsample: int, layers) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Functional form: one single-radius SA layer with explicit ``layers`` [(W,b),...]."""
+    c = 0 if features is None else features.shape[1]
+    mod = SAModule(c, npoint, radius, nsample, [w.shape[0] for w, _ in layers], xyz.device,
+                   weights={"b0": layers})
+    return mod(xyz, features)

@@ -1,0 +1,124 @@
+/*
+ * sad_amd.h — C-ABI of libsad_amd.so: hand-written gfx950 (MI355X) HIP kernels for the
+ * set-abstraction + size-adaptive-clustering hot path.
+ *
+ * Reference interface replaced: none exists.  The upstream reference is a two-line README
+ * (/root/reference/README.md:1-2) and defines no operator/FFI surface; the entry points below are
+ * the ones BASELINE.json north_star names ("fps / ball_query / group_points / sa_module ... through
+ * a thin C-ABI extension"), with the semantics frozen in this repository's SPEC.md (section cited
+ * per function).  The Python binding a maintainer would add is in INTEGRATION.md.
+ *
+ * Contract (all functions):
+ *  - plain pointers and sizes only; no torch / C++ types cross the boundary;
+ *  - every data pointer is DEVICE memory owned by the caller (inputs, outputs and workspace); the
+ *    library never allocates, frees or retains device memory; pointer ARRAYS and small parameter
+ *    arrays (dims, radii, nsamples) are HOST memory read before the call returns;
+ *  - work is enqueued on `stream` (a hipStream_t passed as void*; NULL = default stream) of the
+ *    current device and the call returns without synchronising;
+ *  - returns 0 on success, a negative SAD_E* code otherwise; sad_last_error() gives a
+ *    thread-local message; nothing throws across the boundary; re-entrant, no global mutable
+ *    state other than the tuning options below.
+ */
+#ifndef SAD_AMD_H
+#define SAD_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SAD_OK 0
+#define SAD_EINVAL (-1)       /* bad argument (NULL pointer, size out of range, ...) */
+#define SAD_EUNSUPPORTED (-2) /* shape outside what the kernels implement */
+#define SAD_ELAUNCH (-3)      /* HIP reported a launch error */
+
+#define SAD_MAX_LAYERS 4
+#define SAD_MAX_RADII 4
+
+typedef void *sad_stream_t; /* hipStream_t */
+
+int sad_version(void);
+const char *sad_last_error(void);
+/* Tuning knobs for A/B measurements ("fps_dpp" 0/1, "mlp_rw" 0/1/2/4 (0 = auto)); returns SAD_EINVAL for an unknown key. */
+int sad_set_option(const char *key, int value);
+
+/* SPEC.md §2.  xyz[B,N,3] -> idx[B,M].  N <= 16384 runs register-resident and needs no workspace;
+ * larger N needs sad_fps_workspace_bytes(B,N) bytes of device workspace. */
+size_t sad_fps_workspace_bytes(int B, int N);
+int sad_fps_f32(const float *xyz, int B, int N, int M, int32_t *idx, void *workspace,
+                sad_stream_t stream);
+
+/* SPEC.md §5.  gather_xyz: xyz[B,N,3], idx[B,M] -> out[B,M,3].
+ * gather_points: src[B,C,N], idx[B,M] -> out[B,C,M]; elem_size 2 or 4 bytes.
+ * group_points:  feat[B,C,N], idx[B,M,S] -> out[B,C,M,S]; elem_size 2 or 4 bytes. */
+int sad_gather_xyz_f32(const float *xyz, const int32_t *idx, int B, int N, int M, float *out,
+                       sad_stream_t stream);
+int sad_gather_points(const void *src, const int32_t *idx, int B, int C, int N, int M,
+                      int elem_size, void *out, sad_stream_t stream);
+int sad_group_points(const void *feat, const int32_t *idx, int B, int C, int N, int M, int S,
+                     int elem_size, void *out, sad_stream_t stream);
+
+/* SPEC.md §3.  xyz[B,N,3], new_xyz[B,M,3] -> idx[B,M,S], 1 <= S <= 64.
+ * radius_pc == NULL: scalar `radius`; else per-centroid radius_pc[B,M] (adaptive) and `radius`
+ * is ignored. */
+int sad_ball_query_f32(const float *xyz, const float *new_xyz, float radius,
+                       const float *radius_pc, int B, int N, int M, int S, int32_t *idx,
+                       sad_stream_t stream);
+/* Multi-radius form: d2 evaluated once per pair, SPEC.md §3 applied per radius.  radii[n_radii] and
+ * nsamples[n_radii] are host arrays, idx[n_radii] a host array of device pointers (idx[r] is
+ * [B,M,nsamples[r]]).  With radius_pc != NULL the radius of branch r for centroid (b,m) is
+ * radii[r] * radius_pc[b,m] (one binary32 multiply; SPEC.md §8 step 5). */
+int sad_ball_query_multi_f32(const float *xyz, const float *new_xyz, int n_radii,
+                             const float *radii, const float *radius_pc, const int *nsamples,
+                             int32_t *const *idx, int B, int N, int M, sad_stream_t stream);
+
+/* SPEC.md §4.  -> idx[B,M,K] sorted by (d2, index); K <= 64, K <= N. */
+int sad_knn_f32(const float *xyz, const float *new_xyz, int B, int N, int M, int K, int32_t *idx,
+                sad_stream_t stream);
+
+/* ---- grouped point-feature MLP (SPEC.md §6) ------------------------------------------------
+ * Weights are repacked once into MFMA A-fragment order.  dims[L+1] = {C_in, C_1, ..., C_L} (host).
+ * first_has_xyz != 0: the first layer's input is [rel_xyz(3) || feat(C_in-3)].
+ * W[l] is [dims[l+1], dims[l]] row-major, bias[l] is [dims[l+1]] (host arrays of device pointers).
+ * `packed` needs sad_mlp_packed_floats() floats. */
+size_t sad_mlp_packed_floats(int L, const int *dims, int first_has_xyz);
+int sad_mlp_pack_f32(int L, const int *dims, int first_has_xyz, const float *const *W,
+                     const float *const *bias, float *packed, sad_stream_t stream);
+
+typedef struct sad_mlp_args {
+    /* grouped mode (idx != NULL): rows are (b, m, s); input row = [xyz[idx]-new_xyz || feat[idx]] */
+    const float *xyz;     /* [B,N,3]                                   (grouped mode) */
+    const float *new_xyz; /* [B,M,3]                                   (grouped mode) */
+    const int32_t *idx;   /* [B,M,S] or NULL                                          */
+    /* features: grouped mode: point-major [B,N,C] with row stride ld_feat (NULL iff C == 0);
+     * plain mode (idx == NULL): rows [B*M, C] with row stride ld_feat */
+    const float *feat;
+    int ld_feat;
+    int B, N, M, S, C; /* plain mode: N ignored, S must be 1 */
+    /* layers */
+    int L;                        /* 1..SAD_MAX_LAYERS */
+    int dims[SAD_MAX_LAYERS + 1]; /* dims[0] = C (+3 in grouped mode) */
+    const float *packed;          /* from sad_mlp_pack_f32 with the same L, dims, first_has_xyz */
+    int relu_mask;                /* bit l set = ReLU after layer l */
+    /* output: point-major rows.  grouped mode: max over the S samples of each (b,m) ->
+     * out[(b*M+m)*ld_out + col_off + o]; plain mode: out[row*ld_out + col_off + o] */
+    float *out;
+    int ld_out;
+    int col_off;
+} sad_mlp_args;
+int sad_mlp_chain_f32(const sad_mlp_args *args, sad_stream_t stream);
+
+/* SPEC.md §8 steps 2-4.  xyz3[B,M3,3], c[B,K,6] -> cand[B,K,3], radius[B,K]; anchor[3] host. */
+int sad_candidates_f32(const float *xyz3, const float *c, int B, int M3, int K, float shift_max,
+                       float r_min, float r_max, const float *anchor, float *cand, float *radius,
+                       sad_stream_t stream);
+/* SPEC.md §9.  cand[B,K,3], o[B,K,10] -> boxes[B,K,9]; anchors[9] host (3 classes x lwh). */
+int sad_decode_boxes_f32(const float *cand, const float *o, int B, int K, const float *anchors,
+                         float *boxes, sad_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SAD_AMD_H */

@@ -1,0 +1,95 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library builds, loads and exports every symbol
+include/sad_amd.h declares; the Python surface refuses CPU tensors (no silent fallback)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from conftest import ROOT
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "sad_amd.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(sad_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_exported(sad):
+    from sad_amd import _lib
+    _lib.build()
+    handle = ctypes.CDLL(_lib.SO_PATH)
+    names = _declared_symbols()
+    assert len(names) >= 16
+    for n in names:
+        assert hasattr(handle, n), f"{n} declared in include/sad_amd.h but not exported"
+    assert set(names) == set(_lib.SIGNATURES), "ctypes signature table out of sync with the header"
+    assert _lib.lib().sad_version() == 1
+
+
+def test_no_oracle_in_product_path():
+    """The product package must never import or call the oracle (or any CPU fallback)."""
+    pkg = os.path.join(ROOT, "3dsad-main_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in src and "from oracle" not in src, f
+                assert "libsad_oracle" not in src and "orc_" not in src, f
+
+
+def test_host_side_argument_errors(sad):
+    """Error paths that need no GPU: bad arguments come back as negative codes + a message."""
+    from sad_amd import _lib
+    L = _lib.lib()
+    assert L.sad_fps_f32(None, 1, 8, 4, None, None, None) == -1
+    assert b"NULL" in L.sad_last_error()
+    buf = ctypes.create_string_buffer(64)
+    p = ctypes.cast(buf, ctypes.c_void_p)
+    assert L.sad_fps_f32(p, 1, 8, 9, p, None, None) == -1            # M > N
+    assert L.sad_knn_f32(p, p, 1, 8, 2, 65, p, None) == -1          # K > 64
+    assert L.sad_ball_query_f32(p, p, 0.5, None, 1, 8, 2, 65, p, None) == -1   # nsample > 64
+    assert L.sad_group_points(p, p, 1, 1, 8, 2, 2, 3, p, None) == -1  # elem_size 3
+    assert L.sad_set_option(b"no_such_option", 1) == -1
+    assert L.sad_fps_workspace_bytes(2, 16384) == 0
+    assert L.sad_fps_workspace_bytes(2, 65536) == 2 * 65536 * 4
+    dims = (ctypes.c_int * 4)(259, 256, 512, 1024)
+    n = L.sad_mlp_packed_floats(3, dims, 1)
+    kp = [264, 256, 512]
+    npad = [256, 512, 1024]
+    assert n == sum(a + a * k for a, k in zip(npad, kp))
+
+
+def test_ops_refuse_cpu_tensors(sad):
+    import torch
+    from sad_amd import ops
+    x = torch.zeros(1, 16, 3)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        ops.fps(x, 4)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        ops.ball_query(0.2, 4, x, x)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        ops.group_points(torch.zeros(1, 2, 16), torch.zeros(1, 2, 2, dtype=torch.int32))
+
+
+def test_config_work_accounting(sad):
+    """SURVEY.md §8(d) figures: the roofline numbers in bench.py come from these."""
+    from sad_amd import config
+    w = config.work_per_scene(config.KITTI)
+    assert w["fps_updates"] == 71827456 and w["fps_steps"] == 5632
+    assert w["pair_tests"] == 215744512
+    assert abs(w["ball_query_bytes"] / 1e6 - 3.86) < 0.01
+    assert abs(w["group_points_bytes"] / 1e6 - 91.6) < 0.1
+    assert abs(w["mlp_flops"] / 1e9 - 31.0) < 0.1
+    names = [n for n, _ in config.mlp_layers(config.KITTI)]
+    assert names[0] == "sa1.b0" and names[-1] == "head" and "cluster.b1" in names
+
+
+def test_synth_is_deterministic(sad):
+    import numpy as np
+    from sad_amd import synth
+    a, b = synth.make_scene(3), synth.make_scene(3)
+    assert a.shape == (16384, 4) and a.dtype == np.float32
+    np.testing.assert_array_equal(a, b)
+    assert not np.array_equal(a, synth.make_scene(4))
+    assert a[:, 0].min() >= 0 and a[:, 0].max() <= 70.4 and abs(a[:, 1]).max() <= 40

@@ -1,0 +1,212 @@
+"""GPU parity of the fused group -> MLP -> max kernel, sa_module and the detector (-m gpu)."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def _t(a, dev):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def _close(got, want, what):
+    diff = np.abs(got.astype(np.float64) - want.astype(np.float64))
+    rel = diff / (1.0 + np.abs(want))
+    print(f"[parity] {what}: max|diff|={diff.max():.3e} bit-exact={np.array_equal(got, want)}")
+    assert rel.max() <= TOL, f"{what}: max rel diff {rel.max():.3e} > {TOL}"
+
+
+PLAIN_CASES = [
+    # (rows, dims, relu_mask or None)
+    (37, [7, 12, 5], None),
+    (1000, [128, 64], None),
+    (300, [384, 128], None),
+    (257, [768, 256], None),
+    (130, [1536, 512], None),           # k-chunked staging
+    (256, [512, 256, 256, 10], 0b011),  # head: last layer linear
+    (100, [256, 128, 6], 0b01),         # candidate MLP
+    (64, [33, 40, 50, 60, 70], None),   # odd widths, 4 layers
+]
+
+
+@pytest.mark.parametrize("rows,dims,mask", PLAIN_CASES)
+def test_mlp_rows_parity(orc, sad, dev, rows, dims, mask):
+    from sad_amd import ops, synth
+    rng = np.random.default_rng(sum(dims) + rows)
+    layers = synth.make_mlp_weights(dims, rng)
+    x = rng.normal(size=(rows, dims[0])).astype(np.float32)
+    mlp = ops.PackedMLP(layers, False, dev, relu_mask=mask)
+    got = mlp.rows(_t(x, dev)).cpu().numpy()
+    want = orc.mlp_rows(x, layers, relu_mask=mask)
+    _close(got, want, f"mlp_rows {dims}")
+    # writing into a slice of a wider buffer leaves the rest untouched
+    import torch
+    buf = torch.full((rows, dims[-1] + 12), -7.0, device=dev)
+    mlp.rows(_t(x, dev), out=buf, col_off=8)
+    b = buf.cpu().numpy()
+    _close(b[:, 8:8 + dims[-1]], want, "slice")
+    assert (b[:, :8] == -7).all() and (b[:, 8 + dims[-1]:] == -7).all()
+
+
+GROUPED_CASES = [
+    # (B, N, M, S, C, mlp, radius)
+    (1, 1024, 256, 32, 0, [64, 64, 128], 0.2),        # BASELINE configs[0]
+    (2, 2048, 512, 32, 1, [16, 16, 32], 0.15),        # SA1 branch shape (C=1, strided feature view)
+    (2, 2048, 512, 64, 1, [32, 32, 64], 0.3),         # nsample 64: pooling across two row tiles
+    (2, 1024, 256, 32, 64, [64, 64, 128], 0.25),      # SA2
+    (2, 1024, 256, 64, 64, [64, 96, 128], 0.4),
+    (2, 512, 128, 32, 128, [128, 192, 256], 0.5),     # SA3
+    (2, 256, 64, 16, 256, [256, 256, 512], 0.6),      # cluster branch 0 (nsample 16)
+    (1, 256, 64, 32, 256, [256, 512, 1024], 0.8),     # cluster branch 1 (8 waves)
+    (1, 300, 37, 24, 5, [20, 30], 0.4),               # odd everything: nsample 24 padded to 32
+    (1, 200, 19, 8, 3, [8], 0.5),
+]
+
+
+@pytest.mark.parametrize("B,N,M,S,C,mlp,r", GROUPED_CASES)
+def test_grouped_mlp_parity(orc, sad, dev, B, N, M, S, C, mlp, r):
+    from sad_amd import ops, synth
+    rng = np.random.default_rng(N + M + S + C)
+    xyz = rng.uniform(0, 1, (B, N, 3)).astype(np.float32)
+    fidx = orc.fps(xyz, M)
+    new_xyz = orc.gather_xyz(xyz, fidx)
+    idx = orc.ball_query(r, S, xyz, new_xyz)
+    layers = synth.make_mlp_weights([C + 3] + mlp, rng)
+    X = _t(xyz, dev)
+    if C == 1:   # like the detector: features are a strided view into the [B,N,4] point tensor
+        pts = np.concatenate([xyz, rng.uniform(0, 1, (B, N, 1)).astype(np.float32)], -1)
+        feat = np.ascontiguousarray(pts[:, :, 3:])
+        F = _t(pts, dev)[:, :, 3:]
+    elif C:
+        feat = rng.normal(size=(B, N, C)).astype(np.float32)
+        F = _t(feat, dev)
+    else:
+        feat, F = None, None
+    got = ops.PackedMLP(layers, True, dev).grouped(X, F, _t(new_xyz, dev), _t(idx, dev)).cpu().numpy()
+    want = orc.sa_group_mlp_max(xyz, feat, new_xyz, idx, layers)
+    _close(got, want, f"grouped C={C} S={S} mlp={mlp}")
+
+
+@pytest.mark.parametrize("rw", [1, 2, 4])
+def test_grouped_mlp_rows_per_wave_option(orc, sad, dev, rw):
+    """Every row-tiles-per-wave variant of the kernel gives the same answer."""
+    from sad_amd import _lib, ops, synth
+    rng = np.random.default_rng(77)
+    xyz = rng.uniform(0, 1, (2, 1024, 3)).astype(np.float32)
+    feat = rng.normal(size=(2, 1024, 16)).astype(np.float32)
+    new_xyz = orc.gather_xyz(xyz, orc.fps(xyz, 200))
+    idx = orc.ball_query(0.2, 32, xyz, new_xyz)
+    layers = synth.make_mlp_weights([19, 32, 32, 64], rng)
+    _lib.set_option("mlp_rw", rw)
+    try:
+        got = ops.PackedMLP(layers, True, dev).grouped(_t(xyz, dev), _t(feat, dev), _t(new_xyz, dev), _t(idx, dev)).cpu().numpy()
+    finally:
+        _lib.set_option("mlp_rw", 0)
+    _close(got, orc.sa_group_mlp_max(xyz, feat, new_xyz, idx, layers), f"rw={rw}")
+
+
+def test_golden_config0_on_gpu(sad, dev):
+    """BASELINE.json configs[0] against the COMMITTED golden vectors (no oracle build involved)."""
+    from sad_amd import config, ops, synth
+    from sad_amd.sa_module import SAModule
+    g = np.load(os.path.join(GOLDEN, "config0.npz"))
+    st = config.CONFIG0_SA
+    X = _t(g["xyz"], dev)
+    fidx = ops.fps(X, st.npoint)
+    np.testing.assert_array_equal(fidx.cpu().numpy(), g["fps_idx"])
+    new_xyz = ops.gather_xyz(X, fidx)
+    np.testing.assert_array_equal(new_xyz.cpu().numpy(), g["new_xyz"])
+    bidx = ops.ball_query(st.radii[0], st.nsamples[0], X, new_xyz)
+    np.testing.assert_array_equal(bidx.cpu().numpy(), g["ball_idx"])
+    np.testing.assert_array_equal(ops.knn_query(16, X, new_xyz).cpu().numpy(), g["knn_idx"])
+    layers = synth.make_mlp_weights([3, 64, 64, 128], np.random.default_rng(7))
+    mod = SAModule(0, st.npoint, st.radii[0], st.nsamples[0], [64, 64, 128], dev, weights={"b0": layers})
+    nx, nf = mod(X, None)                       # drop-in surface: features [B,C',M]
+    np.testing.assert_array_equal(nx.cpu().numpy(), g["new_xyz"])
+    assert tuple(nf.shape) == (1, 128, 256)
+    _close(nf.transpose(1, 2).cpu().numpy(), g["feat"], "config0 sa_module")
+
+
+def test_sa_module_msg_dropin_surface(orc, sad, dev):
+    """sa_module(xyz [B,N,3], features [B,C,N]) -> (new_xyz, new_features [B,C',M]) vs the oracle."""
+    from sad_amd import config, synth
+    from sad_amd.sa_module import SAModuleMSG
+    cfg = config.TINY
+    st = cfg.stages[1]
+    rng = np.random.default_rng(5)
+    w = {f"b{i}": synth.make_mlp_weights([64 + 3] + list(m), rng) for i, m in enumerate(st.mlps)}
+    w["agg"] = synth.make_mlp_weights([sum(m[-1] for m in st.mlps), st.agg], rng)
+    pts = synth.make_tiny_batch(50, 2, 512)
+    xyz = np.ascontiguousarray(pts[:, :, :3])
+    feat_cm = rng.normal(size=(2, 64, 512)).astype(np.float32)
+    mod = SAModuleMSG(64, st, dev, w)
+    nx, nf = mod(_t(xyz, dev), _t(feat_cm, dev))
+    ow = {f"sa.b{i}": w[f"b{i}"] for i in range(3)}
+    ow["sa.agg"] = w["agg"]
+    tr = {}
+    onx, onf = orc.sa_module(xyz, np.ascontiguousarray(feat_cm.transpose(0, 2, 1)), st, ow, "sa", tr)
+    np.testing.assert_array_equal(nx.cpu().numpy(), onx)
+    assert tuple(nf.shape) == (2, st.agg, st.npoint)
+    _close(nf.transpose(1, 2).cpu().numpy(), onf, "sa_module MSG")
+
+
+@pytest.mark.parametrize("overlap", [False, True])
+def test_detector_tiny_end_to_end(orc, sad, dev, overlap):
+    """3 SA stages -> size-adaptive cluster layer -> head, TINY topology, vs oracle and golden."""
+    import torch
+    from sad_amd import config, synth
+    from sad_amd.detector import SADDetector
+    cfg = config.TINY
+    g = np.load(os.path.join(GOLDEN, "tiny_detector.npz"))
+    w = synth.make_weights(cfg, 0)
+    pts = synth.make_tiny_batch(0, 2, cfg.n_points)
+    det = SADDetector(cfg, w, dev, overlap_fps=overlap)
+    tr = {}
+    boxes = det(_t(pts, dev), tr)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(tr["sa3"]["new_xyz"].cpu().numpy(),
+                                  orc.gather_xyz(orc.gather_xyz(orc.gather_xyz(
+                                      np.ascontiguousarray(pts[:, :, :3]), g["sa1_fps"]), g["sa2_fps"]), g["sa3_fps"]))
+    _close(tr["sa3"]["out"].cpu().numpy(), g["sa3_out"], "sa3 features")
+    rad = tr["cluster"]["radius"].cpu().numpy()
+    _close(rad, g["radius"], "adaptive radius")
+    if np.array_equal(rad, g["radius"]) and np.array_equal(tr["cluster"]["cand"].cpu().numpy(), g["cand"]):
+        np.testing.assert_array_equal(tr["cluster"]["ball_idx"][0].cpu().numpy(), g["cl_idx0"])
+        np.testing.assert_array_equal(tr["cluster"]["ball_idx"][1].cpu().numpy(), g["cl_idx1"])
+    _close(tr["cluster"]["head"].cpu().numpy(), g["head"], "head output")
+    b = boxes.cpu().numpy()
+    assert b.shape == (2, cfg.n_cand, 9)
+    np.testing.assert_array_equal(b[..., 8], g["boxes"][..., 8])
+    _close(b, g["boxes"], "boxes")
+
+
+def test_detector_kitti_stagewise(orc, sad, dev):
+    """BASELINE configs[1] topology at full size (16384 pts): one scene, each GPU stage checked
+    against the oracle fed with the GPU's own upstream tensors (so nothing compounds)."""
+    import torch
+    from sad_amd import config, synth
+    from sad_amd.detector import SADDetector
+    cfg = config.KITTI
+    w = synth.make_weights(cfg, 0)
+    pts = synth.make_batch(0, 1)
+    det = SADDetector(cfg, w, dev)
+    tr = {}
+    boxes = det(_t(pts, dev), tr)
+    torch.cuda.synchronize()
+    xyz = np.ascontiguousarray(pts[:, :, :3])
+    feat = np.ascontiguousarray(pts[:, :, 3:])
+    for si, st in enumerate(cfg.stages):
+        name = f"sa{si + 1}"
+        otr = {}
+        onx, onf = orc.sa_module(xyz, feat, st, w, name, otr)
+        np.testing.assert_array_equal(tr[name]["new_xyz"].cpu().numpy(), onx)
+        got = tr[name]["out"].cpu().numpy()
+        _close(got, onf, f"{name} features (16384-pt scene)")
+        xyz, feat = onx, got      # continue from the GPU's features
+    assert boxes.shape == (1, cfg.n_cand, 9) and bool(torch.isfinite(boxes).all())

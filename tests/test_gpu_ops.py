@@ -1,0 +1,180 @@
+"""GPU parity tests (run on the MI355X box with -m gpu): every HIP kernel, called through the
+C-ABI via the Python operator surface, against the CPU spec-oracle on the same seeded inputs —
+bit-exact for indices, <= 1e-4 for float features (the MFMA chain is expected to be bit-exact and
+the observed max difference is printed) — plus the committed golden vectors, the edge cases, and
+size-independent properties at BASELINE.json's full sizes.
+
+PARITY UNPINNED vs the upstream reference: it ships no implementation (/root/reference/README.md:1-2);
+the oracle restates this repository's SPEC.md."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4  # BASELINE.json north_star: "fp32 features/boxes within 1e-4"
+
+
+def _t(a, dev):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def _rand_xyz(seed, B, N, scale=1.0):
+    return (np.random.default_rng(seed).uniform(0, 1, (B, N, 3)) * scale).astype(np.float32)
+
+
+# ---------------------------------------------------------------- fps
+@pytest.mark.parametrize("B,N,M", [(2, 64, 16), (3, 257, 100), (2, 1024, 256), (2, 2048, 512),
+                                   (2, 3000, 700), (2, 4096, 1024), (1, 8192, 512), (2, 16384, 1024),
+                                   (1, 5, 5), (1, 1, 1)])
+@pytest.mark.parametrize("dpp", [0, 1])
+def test_fps_parity(orc, sad, dev, B, N, M, dpp):
+    from sad_amd import _lib, ops
+    _lib.set_option("fps_dpp", dpp)
+    try:
+        xyz = _rand_xyz(100 + N, B, N)
+        got = ops.fps(_t(xyz, dev), M).cpu().numpy()
+    finally:
+        _lib.set_option("fps_dpp", 0)
+    np.testing.assert_array_equal(got, orc.fps(xyz, M))
+
+
+def test_fps_big_n_workspace_path(orc, sad, dev):
+    from sad_amd import ops
+    xyz = _rand_xyz(7, 1, 20000)
+    np.testing.assert_array_equal(ops.fps(_t(xyz, dev), 300).cpu().numpy(), orc.fps(xyz, 300))
+
+
+def test_fps_edge_cases(orc, sad, dev):
+    from sad_amd import ops
+    g = np.load(os.path.join(GOLDEN, "edge_cases.npz"))
+    np.testing.assert_array_equal(ops.fps(_t(g["line_xyz"], dev), 5).cpu().numpy(), g["line_fps5"])
+    np.testing.assert_array_equal(ops.fps(_t(g["dup_xyz"], dev), 6).cpu().numpy(), g["dup_fps6"])
+    # a regular grid is full of exact distance ties -> exercises lowest-index tie-breaking everywhere
+    ax = np.arange(8, dtype=np.float32)
+    grid = np.stack(np.meshgrid(ax, ax, ax, indexing="ij"), -1).reshape(1, 512, 3)
+    np.testing.assert_array_equal(ops.fps(_t(grid, dev), 200).cpu().numpy(), orc.fps(grid, 200))
+
+
+def test_fps_full_size_properties(orc, sad, dev):
+    """BASELINE configs[1] size (16384 -> 4096): exact vs oracle on one scene, properties on a batch."""
+    from sad_amd import ops, synth
+    pts = synth.make_batch(0, 4)
+    xyz = np.ascontiguousarray(pts[:, :, :3])
+    got = ops.fps(_t(xyz, dev), 4096).cpu().numpy()
+    np.testing.assert_array_equal(got[:1], orc.fps(xyz[:1], 4096))
+    for b in range(4):
+        assert got[b, 0] == 0 and len(set(got[b].tolist())) == 4096
+    # greedy property on scene 3: pick i maximises the min-distance to picks < i
+    sel = xyz[3][got[3, :64]]
+    d = ((xyz[3][:, None, :] - sel[None, :, :]) ** 2).sum(-1)
+    for i in (1, 2, 10, 63):
+        assert np.argmax(d[:, :i].min(1)) == got[3, i]
+
+
+# ---------------------------------------------------------------- ball query / knn
+@pytest.mark.parametrize("B,N,M,r,S", [(2, 700, 100, 0.1, 8), (2, 700, 100, 0.2, 32), (1, 1000, 33, 0.45, 16),
+                                       (2, 513, 64, 2.0, 64), (1, 64, 7, 0.3, 1), (2, 4096, 1024, 0.08, 32),
+                                       (1, 100, 3, 0.2, 24)])
+def test_ball_query_parity(orc, sad, dev, B, N, M, r, S):
+    from sad_amd import ops
+    xyz = _rand_xyz(200 + N, B, N)
+    new_xyz = np.ascontiguousarray(xyz[:, :M])
+    got = ops.ball_query(r, S, _t(xyz, dev), _t(new_xyz, dev)).cpu().numpy()
+    np.testing.assert_array_equal(got, orc.ball_query(r, S, xyz, new_xyz))
+
+
+def test_ball_query_adaptive_and_multi(orc, sad, dev):
+    from sad_amd import ops, synth
+    g = np.load(os.path.join(GOLDEN, "adaptive.npz"))
+    xyz = np.ascontiguousarray(synth.make_tiny_batch(100, 2, 2048)[:, :, :3])
+    new_xyz = orc.gather_xyz(xyz, g["fps_idx"])
+    X, C, R = _t(xyz, dev), _t(new_xyz, dev), _t(g["radius"], dev)
+    np.testing.assert_array_equal(ops.ball_query(R, 16, X, C).cpu().numpy(), g["ball_idx"])
+    # constant tensor radius == scalar radius
+    import torch
+    const = torch.full((2, 128), 0.7, device=dev)
+    np.testing.assert_array_equal(ops.ball_query(const, 16, X, C).cpu().numpy(),
+                                  ops.ball_query(0.7, 16, X, C).cpu().numpy())
+    # multi-radius: one pass over the pairs, same answers as separate calls
+    outs = ops.ball_query_multi((0.4, 0.8, 1.6), (32, 32, 64), X, C)
+    for o, r, s in zip(outs, (0.4, 0.8, 1.6), (32, 32, 64)):
+        np.testing.assert_array_equal(o.cpu().numpy(), orc.ball_query(r, s, xyz, new_xyz))
+    # multi-radius with a per-centroid base radius (SPEC.md §8 step 5)
+    outs = ops.ball_query_multi((1.0, 2.0), (16, 32), X, C, R)
+    for o, sc, s in zip(outs, (1.0, 2.0), (16, 32)):
+        want = orc.ball_query((np.float32(sc) * g["radius"]).astype(np.float32), s, xyz, new_xyz)
+        np.testing.assert_array_equal(o.cpu().numpy(), want)
+
+
+def test_ball_query_edge_cases(orc, sad, dev):
+    from sad_amd import ops
+    g = np.load(os.path.join(GOLDEN, "edge_cases.npz"))
+    L, Cn = _t(g["line_xyz"], dev), _t(g["line_cen"], dev)
+    np.testing.assert_array_equal(ops.ball_query(2.0, 4, L, Cn).cpu().numpy(), g["line_bq_r2_s4"])
+    np.testing.assert_array_equal(ops.ball_query(1.5, 8, L, Cn).cpu().numpy(), g["line_bq_r1.5_s8"])
+    np.testing.assert_array_equal(ops.knn_query(3, L, Cn).cpu().numpy(), g["line_knn3"])
+    D = _t(g["dup_xyz"], dev)
+    np.testing.assert_array_equal(ops.ball_query(0.5, 4, D, D[:, :3].contiguous()).cpu().numpy(), g["dup_bq"])
+    Sx = _t(g["strict_xyz"], dev)
+    np.testing.assert_array_equal(ops.ball_query(5.0, 4, Sx, Sx[:, :1].contiguous()).cpu().numpy(), g["strict_bq"])
+
+
+def test_ball_query_full_size(orc, sad, dev):
+    """SA1 size (16384 x 4096, three radii) on KITTI-shaped scenes: exact on a slice of centroids,
+    properties on all."""
+    from sad_amd import ops, synth
+    xyz = np.ascontiguousarray(synth.make_batch(0, 2)[:, :, :3])
+    fidx = orc.fps(xyz, 4096)
+    new_xyz = orc.gather_xyz(xyz, fidx)
+    outs = ops.ball_query_multi((0.2, 0.4, 0.8), (32, 32, 64), _t(xyz, dev), _t(new_xyz, dev))
+    sub = np.ascontiguousarray(new_xyz[:, :512])
+    for o, r, s in zip(outs, (0.2, 0.4, 0.8), (32, 32, 64)):
+        o = o.cpu().numpy()
+        np.testing.assert_array_equal(o[:, :512], orc.ball_query(r, s, xyz, sub))
+        # every returned index is inside the ball; the centroid itself (a scene point) is always found
+        p = np.take_along_axis(xyz[:, None, :, :], o[..., None].astype(np.int64), axis=2)
+        d2 = ((p - new_xyz[:, :, None, :]) ** 2).sum(-1)
+        assert (d2 < np.float32(r) ** 2 * 1.0001).all()
+        assert (np.diff(o, axis=2) >= 0).mean() > 0.5  # ascending until the padding starts
+
+
+@pytest.mark.parametrize("B,N,M,K", [(2, 300, 30, 9), (1, 2048, 100, 32), (1, 70, 5, 64), (2, 1000, 17, 1)])
+def test_knn_parity(orc, sad, dev, B, N, M, K):
+    from sad_amd import ops
+    xyz = _rand_xyz(300 + N, B, N)
+    xyz[0, 10] = xyz[0, 20]
+    new_xyz = np.ascontiguousarray(xyz[:, :M])
+    got = ops.knn_query(K, _t(xyz, dev), _t(new_xyz, dev)).cpu().numpy()
+    np.testing.assert_array_equal(got, orc.knn_query(K, xyz, new_xyz))
+
+
+# ---------------------------------------------------------------- group / gather
+@pytest.mark.parametrize("dtype", ["float32", "float16"])
+@pytest.mark.parametrize("B,C,N,M,S", [(2, 5, 77, 9, 4), (2, 67, 4096, 1024, 32), (1, 3, 100, 7, 3)])
+def test_group_gather_parity(orc, sad, dev, dtype, B, C, N, M, S):
+    from sad_amd import ops
+    rng = np.random.default_rng(400 + N)
+    feat = rng.normal(size=(B, C, N)).astype(dtype)
+    idx = rng.integers(0, N, (B, M, S)).astype(np.int32)
+    got = ops.group_points(_t(feat, dev), _t(idx, dev)).cpu().numpy()
+    np.testing.assert_array_equal(got, orc.group_points(feat, idx))
+    i2 = np.ascontiguousarray(idx[:, :, 0])
+    np.testing.assert_array_equal(ops.gather_points(_t(feat, dev), _t(i2, dev)).cpu().numpy(),
+                                  orc.gather_points(feat, i2))
+    xyz = rng.normal(size=(B, N, 3)).astype(np.float32)
+    np.testing.assert_array_equal(ops.gather_xyz(_t(xyz, dev), _t(i2, dev)).cpu().numpy(), orc.gather_xyz(xyz, i2))
+
+
+def test_group_points_bf16(sad, dev):
+    import torch
+    from sad_amd import ops
+    feat = torch.randn(2, 8, 500, device=dev).bfloat16()
+    idx = torch.randint(0, 500, (2, 40, 16), device=dev, dtype=torch.int32)
+    got = ops.group_points(feat, idx)
+    want = torch.gather(feat[:, :, None, :].expand(-1, -1, 40, -1), 3, idx.long()[:, None].expand(-1, 8, -1, -1))
+    assert torch.equal(got, want)
