@@ -37,7 +37,7 @@ __global__ __launch_bounds__(256) void candidates_kernel(const float *__restrict
     const float ll = sz[0] * sz[0], ww = sz[1] * sz[1], hh = sz[2] * sz[2];
     float sum = ll + ww;
     sum = sum + hh;
-    float r = 0.5f * __fsqrt_rn(sum);  // correctly rounded, as sqrtf on the host
+    float r = 0.5f * sqrtf(sum);  // correctly rounded (IEEE) under hipcc defaults, as on the host
     r = r < r_min ? r_min : r;
     r = r > r_max ? r_max : r;
     radius[(size_t)b * K + i] = r;

@@ -31,17 +31,19 @@ class SADDetector(nn.Module):
             w = {f"b{i}": weights[f"sa{si + 1}.b{i}"] for i in range(len(st.mlps))}
             if st.agg:
                 w["agg"] = weights[f"sa{si + 1}.agg"]
-            m = SAModuleMSG(c, st, self.device, w)
+            m = SAModuleMSG(c, st, self.device, w, name=f"sa{si + 1}")
             self.stages.append(m)
             c = m.out_channels
         self.cand_mlp = ops.PackedMLP(weights["cand"], False, self.device,
-                                      relu_mask=(1 << (len(weights["cand"]) - 1)) - 1)
-        self.cluster_branches = [ops.PackedMLP(weights[f"cluster.b{i}"], True, self.device)
+                                      relu_mask=(1 << (len(weights["cand"]) - 1)) - 1, name="cand")
+        self.cluster_branches = [ops.PackedMLP(weights[f"cluster.b{i}"], True, self.device,
+                                               name=f"cluster.b{i}")
                                  for i in range(len(cfg.cluster_mlps))]
         self.cluster_cat = sum(m[-1] for m in cfg.cluster_mlps)
-        self.cluster_agg = ops.PackedMLP(weights["cluster.agg"], False, self.device)
+        self.cluster_agg = ops.PackedMLP(weights["cluster.agg"], False, self.device,
+                                         name="cluster.agg")
         self.head = ops.PackedMLP(weights["head"], False, self.device,
-                                  relu_mask=(1 << (len(weights["head"]) - 1)) - 1)
+                                  relu_mask=(1 << (len(weights["head"]) - 1)) - 1, name="head")
         self._anchor = (ctypes.c_float * 3)(*cfg.anchor_car)
         self._anchors = (ctypes.c_float * 9)(*[v for a in cfg.anchors for v in a])
         self.overlap_fps = overlap_fps
@@ -56,21 +58,30 @@ class SADDetector(nn.Module):
             out.append(cur)
         return out
 
-    def forward(self, points: torch.Tensor, trace: Optional[dict] = None) -> torch.Tensor:
-        """points [B,N,3+in_feat] f32 on the GPU -> boxes [B,K,9]."""
+    def forward(self, points: torch.Tensor, trace: Optional[dict] = None,
+                input_ready: bool = False) -> torch.Tensor:
+        """points [B,N,3+in_feat] f32 on the GPU -> boxes [B,K,9].
+
+        ``input_ready=True`` promises that ``points`` is not being produced by work still queued on
+        the current stream (e.g. a resident batch): the sampling stream then starts immediately
+        instead of waiting for the current stream, so the FPS chain of this call overlaps the MLP
+        kernels of the previous call."""
         cfg = self.cfg
         if not points.is_cuda:
             raise RuntimeError("points: expected a GPU tensor (sad_amd has no CPU path)")
         points = points.contiguous()
         B, N, D = points.shape
-        xyz = points[:, :, :3].contiguous()
         feat = points[:, :, 3:] if D > 3 else None   # strided view [B,N,in_feat], no copy
         main = torch.cuda.current_stream()
         if self.overlap_fps:
             side = self._side
-            side.wait_stream(main)
+            if not input_ready:
+                side.wait_stream(main)
             evs = []
             with torch.cuda.stream(side):
+                xyz = points[:, :, :3].contiguous()
+                ev_xyz = torch.cuda.Event()
+                ev_xyz.record(side)
                 cur = xyz
                 centroids = []
                 for m in self.stages:
@@ -79,10 +90,12 @@ class SADDetector(nn.Module):
                     ev = torch.cuda.Event()
                     ev.record(side)
                     evs.append(ev)
-            for t in centroids:
+            points.record_stream(side)
+            for t in centroids + [xyz]:
                 t.record_stream(main)
-            xyz.record_stream(side)
+            main.wait_event(ev_xyz)
         else:
+            xyz = points[:, :, :3].contiguous()
             centroids = self._sample_chain(xyz)
             evs = [None] * len(centroids)
         cur_xyz, cur_feat = xyz, feat

@@ -23,6 +23,32 @@ def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
+# Optional per-launch timing for bench.py: when LAUNCH_LOG is a list, every operator brackets its
+# C-ABI call with HIP events recorded on the stream the kernel is launched on and appends
+# (kind, name, start_event, end_event).  None (the default) adds nothing to the launch path.
+LAUNCH_LOG: Optional[list] = None
+
+
+class _timed:
+    __slots__ = ("kind", "name", "ev")
+
+    def __init__(self, kind: str, name: str = ""):
+        self.kind, self.name, self.ev = kind, name, None
+
+    def __enter__(self):
+        if LAUNCH_LOG is not None:
+            self.ev = torch.cuda.Event(enable_timing=True)
+            self.ev.record(torch.cuda.current_stream())
+        return self
+
+    def __exit__(self, *exc):
+        if self.ev is not None:
+            end = torch.cuda.Event(enable_timing=True)
+            end.record(torch.cuda.current_stream())
+            LAUNCH_LOG.append((self.kind, self.name, self.ev, end))
+        return False
+
+
 def _need(t: torch.Tensor, name: str, dtype, ndim: int) -> torch.Tensor:
     if not isinstance(t, torch.Tensor):
         raise TypeError(f"{name}: expected a torch.Tensor")
@@ -46,8 +72,9 @@ def fps(xyz: torch.Tensor, npoint: int) -> torch.Tensor:
     idx = torch.empty((B, npoint), dtype=torch.int32, device=xyz.device)
     ws_bytes = lib().sad_fps_workspace_bytes(B, N)
     ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=xyz.device) if ws_bytes else None
-    check(lib().sad_fps_f32(xyz.data_ptr(), B, N, npoint, idx.data_ptr(),
-                            ws.data_ptr() if ws is not None else None, _stream()), "sad_fps_f32")
+    with _timed("fps", f"N{N}"):
+        check(lib().sad_fps_f32(xyz.data_ptr(), B, N, npoint, idx.data_ptr(),
+                                ws.data_ptr() if ws is not None else None, _stream()), "sad_fps_f32")
     return idx
 
 
@@ -88,8 +115,9 @@ def group_points(features: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
     B, C, N = features.shape
     _, M, S = idx.shape
     out = torch.empty((B, C, M, S), dtype=features.dtype, device=features.device)
-    check(lib().sad_group_points(features.data_ptr(), idx.data_ptr(), B, C, N, M, S, esz,
-                                 out.data_ptr(), _stream()), "sad_group_points")
+    with _timed("group_points", f"C{C}N{N}M{M}S{S}"):
+        check(lib().sad_group_points(features.data_ptr(), idx.data_ptr(), B, C, N, M, S, esz,
+                                     out.data_ptr(), _stream()), "sad_group_points")
     return out
 
 
@@ -140,8 +168,9 @@ def ball_query_multi(radii: Sequence[float], nsamples: Sequence[int], xyz: torch
         if tuple(radius_pc.shape) != (B, M):
             raise ValueError(f"radius_pc must be [B,M]=({B},{M})")
         pc = radius_pc.data_ptr()
-    check(lib().sad_ball_query_multi_f32(xyz.data_ptr(), new_xyz.data_ptr(), n, r_arr, pc, s_arr, p_arr,
-                                         B, N, M, _stream()), "sad_ball_query_multi_f32")
+    with _timed("ball_query", f"N{N}M{M}x{n}"):
+        check(lib().sad_ball_query_multi_f32(xyz.data_ptr(), new_xyz.data_ptr(), n, r_arr, pc, s_arr,
+                                             p_arr, B, N, M, _stream()), "sad_ball_query_multi_f32")
     return outs
 
 
@@ -165,7 +194,9 @@ class PackedMLP:
     ``relu_mask`` bit l = ReLU after layer l (default: all layers).
     """
 
-    def __init__(self, layers, first_has_xyz: bool, device, relu_mask: Optional[int] = None):
+    def __init__(self, layers, first_has_xyz: bool, device, relu_mask: Optional[int] = None,
+                 name: str = ""):
+        self.name = name
         if not 1 <= len(layers) <= _lib.MAX_LAYERS:
             raise ValueError(f"1..{_lib.MAX_LAYERS} layers supported")
         self.device = torch.device(device)
@@ -232,7 +263,8 @@ class PackedMLP:
         a.xyz, a.new_xyz, a.idx = xyz.data_ptr(), new_xyz.data_ptr(), idx.data_ptr()
         a.B, a.N, a.M, a.S, a.C = B, N, M, S, C
         a.out, a.ld_out, a.col_off = out.data_ptr(), out.stride(-2), col_off
-        check(lib().sad_mlp_chain_f32(ctypes.byref(a), _stream()), "sad_mlp_chain_f32")
+        with _timed("mlp", self.name):
+            check(lib().sad_mlp_chain_f32(ctypes.byref(a), _stream()), "sad_mlp_chain_f32")
         return out
 
     def rows(self, x: torch.Tensor, out: Optional[torch.Tensor] = None, col_off: int = 0
@@ -257,7 +289,8 @@ class PackedMLP:
         a.feat, a.ld_feat = x2.data_ptr(), x2.stride(0)
         a.B, a.N, a.M, a.S, a.C = 1, 0, R, 1, C
         a.out, a.ld_out, a.col_off = out.data_ptr(), out.stride(-2), col_off
-        check(lib().sad_mlp_chain_f32(ctypes.byref(a), _stream()), "sad_mlp_chain_f32")
+        with _timed("mlp", self.name):
+            check(lib().sad_mlp_chain_f32(ctypes.byref(a), _stream()), "sad_mlp_chain_f32")
         return out
 
     def _check_out(self, out: torch.Tensor, rows: int, col_off: int) -> None:

@@ -27,7 +27,7 @@ class SAModuleMSG(nn.Module):
     as numpy arrays (BatchNorm folded); seeded Kaiming-uniform weights are drawn when omitted."""
 
     def __init__(self, in_channels: int, stage: SAStage, device, weights: Optional[dict] = None,
-                 seed: int = 0):
+                 seed: int = 0, name: str = "sa"):
         super().__init__()
         self.stage = stage
         self.in_channels = in_channels
@@ -38,10 +38,11 @@ class SAModuleMSG(nn.Module):
                        for i, m in enumerate(stage.mlps)}
             if stage.agg:
                 weights["agg"] = make_mlp_weights([sum(m[-1] for m in stage.mlps), stage.agg], rng)
-        self.branches = [ops.PackedMLP(weights[f"b{i}"], True, self.device)
+        self.branches = [ops.PackedMLP(weights[f"b{i}"], True, self.device, name=f"{name}.b{i}")
                          for i in range(len(stage.mlps))]
         self.cat_channels = sum(m[-1] for m in stage.mlps)
-        self.agg = ops.PackedMLP(weights["agg"], False, self.device) if stage.agg else None
+        self.agg = (ops.PackedMLP(weights["agg"], False, self.device, name=f"{name}.agg")
+                    if stage.agg else None)
         self.out_channels = stage.agg if stage.agg else self.cat_channels
 
     def sample(self, xyz: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:

@@ -1,0 +1,192 @@
+#!/usr/bin/env python3
+"""bench.py — scenes/sec of the SA + size-adaptive-cluster + head path on N MI355X (one node).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload (BASELINE.json metric / configs[1..3]): per GPU a resident batch of 32 synthetic
+KITTI-shaped 16 384-point scenes -> 3-stage multi-radius SA backbone (fp32) -> size-adaptive
+cluster layer -> box/cls head -> boxes[32,256,9]; with N > 1 every rank processes its own 32 scenes
+(weak scaling) and ONE RCCL all_gather of the boxes closes each step.  A step = one such pass.
+Inputs are already in HBM when the timed region starts.
+
+One JSON line on rank 0: the contract fields plus
+  roofline     — the dominant kernel (mlp_chain_kernel: every fused gather+MLP+max / MLP launch of a
+                 step) against the dense f32 MFMA peak, timed with HIP events on its own stream
+                 inside the timed region;
+  kernels      — the same for fps / ball_query (against the HBM roofline, algorithmic bytes);
+  cpu_baseline — this repository's CPU spec-oracle (kind "port": the upstream reference ships no
+                 CPU path) on a bounded sample of the same scenes, same host.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_MFMA_F32_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: dense f32 MFMA
+PEAK_HBM_GBPS = 8000.0         # HBM3E spec
+
+
+def usable_cores() -> int:
+    n = len(os.sched_getaffinity(0))
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = max(1, min(n, int(float(q) / float(p) + 0.5)))
+    except Exception:
+        pass
+    return n
+
+
+def cpu_baseline(cfg, weights, scenes: int, repeats: int = 2):
+    """Oracle forward on `scenes` scenes of the same workload; best of `repeats`."""
+    import oracle
+    from sad_amd import synth
+    cores = usable_cores()
+    os.environ["OMP_NUM_THREADS"] = str(cores)
+    oracle.build()
+    pts = synth.make_batch(0, scenes, cfg.n_points)
+    best = None
+    for _ in range(repeats):
+        t0 = time.perf_counter()
+        oracle.detector_forward(pts, cfg, weights)
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    return {"value": round(scenes / best, 4), "unit": "scenes/s", "cores": cores, "kind": "port",
+            "sample": f"{scenes} scenes of the same 16384-pt batch through oracle.detector_forward "
+                      f"(C + OpenMP, {cores} threads), best of {repeats}; the upstream reference has no CPU path"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=32, help="scenes per GPU per step")
+    ap.add_argument("--no-overlap", action="store_true", help="run FPS on the main stream")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--cpu-scenes", type=int, default=32)
+    ap.add_argument("--no-launch-timing", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import sad_amd  # noqa: F401
+    from sad_amd import config, ops, synth
+    from sad_amd.detector import SADDetector
+    from sad_amd.dist import all_gather_boxes
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path is the only path (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)   # RCCL on ROCm
+
+    cfg = config.KITTI
+    weights = synth.make_weights(cfg, 0)
+    det = SADDetector(cfg, weights, dev, overlap_fps=not args.no_overlap)
+    B = args.batch
+    points = torch.from_numpy(synth.make_batch(rank * B, B, cfg.n_points)).to(dev)
+    torch.cuda.synchronize()
+
+    def step():
+        boxes = det(points, input_ready=True)
+        return all_gather_boxes(boxes)
+
+    for _ in range(args.warmup):
+        out = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+        torch.cuda.synchronize()
+    if not args.no_launch_timing:
+        ops.LAUNCH_LOG = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+        torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    log, ops.LAUNCH_LOG = ops.LAUNCH_LOG, None
+    assert out.shape == (world * B, cfg.n_cand, 9) and bool(torch.isfinite(out).all())
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        work = config.work_per_scene(cfg)
+        per_kind = {}
+        per_name = {}
+        for kind, name, e0, e1 in (log or []):
+            ms = e0.elapsed_time(e1)
+            per_kind[kind] = per_kind.get(kind, 0.0) + ms
+            per_name[(kind, name)] = per_name.get((kind, name), 0.0) + ms
+        steps = args.steps
+        res = {
+            "metric": "scenes/sec (16384-pt KITTI-shaped) through SA+cluster path",
+            "value": round(world * B * steps / elapsed, 2),
+            "unit": "scenes/s",
+            "n_gpus": world, "steps": steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / steps, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "configs[1-2]: batch 32 x 16384-pt KITTI-shaped scenes per GPU, "
+                                   "3-stage multi-radius SA backbone fp32 + size-adaptive cluster layer + box head",
+                       "scenes_per_gpu": B, "global_batch": world * B, "n_points": cfg.n_points,
+                       "parallelism": f"batch-sharded x{world}, one all_gather of boxes",
+                       "fps_overlap": not args.no_overlap},
+        }
+        if log:
+            mlp_ms = per_kind.get("mlp", 0.0) / steps
+            flops = work["mlp_flops"] * B
+            ach = flops / (mlp_ms * 1e-3) / 1e12 if mlp_ms > 0 else 0.0
+            n_mlp = sum(1 for k, _, _, _ in log if k == "mlp") // steps
+            res["roofline"] = {
+                "kernel": f"mlp_chain_kernel ({n_mlp} launches per step, summed)",
+                "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_MFMA_F32_TFLOPS,
+                "unit": "TFLOP/s", "frac": round(ach / PEAK_MFMA_F32_TFLOPS, 4), "traffic": None,
+                "flop_per_step": flops, "ms_per_step": round(mlp_ms, 3)}
+            kern = []
+            fps_ms = per_kind.get("fps", 0.0) / steps
+            if fps_ms > 0:
+                kern.append({"kernel": "fps_reg_kernel (3 launches per step, side stream)",
+                             "ms_per_step": round(fps_ms, 3),
+                             "updates_per_s": round(work["fps_updates"] * B / (fps_ms * 1e-3) / 1e9, 2),
+                             "unit": "G distance-updates/s",
+                             "us_per_serial_step": round(1e3 * fps_ms / work["fps_steps"], 3),
+                             "bound": "serial latency (neither HBM nor MFMA)"})
+            bq_ms = per_kind.get("ball_query", 0.0) / steps
+            if bq_ms > 0:
+                gbps = work["ball_query_bytes"] * B / (bq_ms * 1e-3) / 1e9
+                kern.append({"kernel": "ball_query_kernel (4 launches per step)", "ms_per_step": round(bq_ms, 3),
+                             "bound": "hbm", "achieved": round(gbps, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+                             "frac": round(gbps / PEAK_HBM_GBPS, 5),
+                             "pair_tests_per_s": round(work["pair_tests"] * B / (bq_ms * 1e-3) / 1e12, 3)})
+            res["kernels"] = kern
+            res["mlp_launches_ms"] = {n: round(v / steps, 3) for (k, n), v in sorted(per_name.items()) if k == "mlp"}
+        if not args.no_cpu and world == 1:
+            res["cpu_baseline"] = cpu_baseline(cfg, weights, args.cpu_scenes)
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -13,6 +13,7 @@
  * keeps every a*b+c that is not written as fmaf() un-fused, exactly as the HIP kernels are built.
  * Results do not depend on the thread count: every output element is computed by one thread.
  */
+#include <immintrin.h>
 #include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -148,23 +149,37 @@ ORC_API void orc_group_points(const void *feat, const int32_t *idx, int B, int C
  * ---------------------------------------------------------------------------------------- */
 static void layer_rows(const float *x, int ldx, int rows, const float *wT, const float *bias,
                        int Cin, int Cout, int relu, float *y, int ldy) {
+    /* Register-blocked so the CPU baseline is an honest one: a 6-row x 16-channel tile of chains
+     * lives in 12 ymm accumulators across the whole k loop; _mm256_fmadd_ps is fmaf per element
+     * (one rounding), so the result is the same k-ascending chain as the scalar tail below. */
     int r = 0;
-    for (; r + 4 <= rows; r += 4) { /* 4-row blocking: reuse each wT row for 4 chains */
-        float *y0 = y + (size_t)(r + 0) * ldy, *y1 = y + (size_t)(r + 1) * ldy;
-        float *y2 = y + (size_t)(r + 2) * ldy, *y3 = y + (size_t)(r + 3) * ldy;
-        for (int o = 0; o < Cout; ++o) { y0[o] = bias[o]; y1[o] = bias[o]; y2[o] = bias[o]; y3[o] = bias[o]; }
-        for (int k = 0; k < Cin; ++k) {
-            const float *w = wT + (size_t)k * Cout;
-            float a0 = x[(size_t)(r + 0) * ldx + k], a1 = x[(size_t)(r + 1) * ldx + k];
-            float a2 = x[(size_t)(r + 2) * ldx + k], a3 = x[(size_t)(r + 3) * ldx + k];
-#pragma omp simd
-            for (int o = 0; o < Cout; ++o) {
-                y0[o] = fmaf(w[o], a0, y0[o]);
-                y1[o] = fmaf(w[o], a1, y1[o]);
-                y2[o] = fmaf(w[o], a2, y2[o]);
-                y3[o] = fmaf(w[o], a3, y3[o]);
+    for (; r + 6 <= rows; r += 6) {
+        const float *xr = x + (size_t)r * ldx;
+        int o = 0;
+        for (; o + 16 <= Cout; o += 16) {
+            __m256 acc[6][2];
+            const __m256 b0 = _mm256_loadu_ps(bias + o), b1 = _mm256_loadu_ps(bias + o + 8);
+            for (int i = 0; i < 6; ++i) { acc[i][0] = b0; acc[i][1] = b1; }
+            for (int k = 0; k < Cin; ++k) {
+                const __m256 w0 = _mm256_loadu_ps(wT + (size_t)k * Cout + o);
+                const __m256 w1 = _mm256_loadu_ps(wT + (size_t)k * Cout + o + 8);
+                for (int i = 0; i < 6; ++i) {
+                    const __m256 a = _mm256_broadcast_ss(xr + (size_t)i * ldx + k);
+                    acc[i][0] = _mm256_fmadd_ps(w0, a, acc[i][0]);
+                    acc[i][1] = _mm256_fmadd_ps(w1, a, acc[i][1]);
+                }
+            }
+            for (int i = 0; i < 6; ++i) {
+                _mm256_storeu_ps(y + (size_t)(r + i) * ldy + o, acc[i][0]);
+                _mm256_storeu_ps(y + (size_t)(r + i) * ldy + o + 8, acc[i][1]);
             }
         }
+        for (; o < Cout; ++o)
+            for (int i = 0; i < 6; ++i) {
+                float acc = bias[o];
+                for (int k = 0; k < Cin; ++k) acc = fmaf(wT[(size_t)k * Cout + o], xr[(size_t)i * ldx + k], acc);
+                y[(size_t)(r + i) * ldy + o] = acc;
+            }
     }
     for (; r < rows; ++r) {
         float *y0 = y + (size_t)r * ldy;
@@ -202,7 +217,7 @@ ORC_API void orc_mlp_rows(const float *x, int64_t R, int L, const int *dims, con
         wT[l] = transpose_w(W[l], dims[l + 1], dims[l]);
         if (dims[l + 1] > maxc) maxc = dims[l + 1];
     }
-    const int RB = 64;
+    const int RB = 96;
 #pragma omp parallel
     {
         float *buf0 = (float *)malloc(sizeof(float) * (size_t)RB * maxc);
