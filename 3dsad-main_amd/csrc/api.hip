@@ -6,7 +6,7 @@
 namespace sad {
 
 static thread_local char g_err[512] = "";
-static int g_opt[OPT_COUNT] = {0, 0};
+static int g_opt[OPT_COUNT] = {};
 
 void set_error(const char *fmt, ...) {
     va_list ap;
@@ -27,5 +27,8 @@ SAD_API int sad_set_option(const char *key, int value) {
     SAD_REQUIRE(key, "sad_set_option: NULL key");
     if (!strcmp(key, "fps_dpp")) { sad::g_opt[sad::OPT_FPS_DPP] = value; return SAD_OK; }
     if (!strcmp(key, "mlp_rw")) { sad::g_opt[sad::OPT_MLP_RW] = value; return SAD_OK; }
+    if (!strcmp(key, "mlp_budget_kb")) { sad::g_opt[sad::OPT_MLP_BUDGET_KB] = value; return SAD_OK; }
+    if (!strcmp(key, "bq_variant")) { sad::g_opt[sad::OPT_BQ_VARIANT] = value; return SAD_OK; }
+    if (!strcmp(key, "fps_variant")) { sad::g_opt[sad::OPT_FPS_VARIANT] = value; return SAD_OK; }
     return sad::fail(SAD_EINVAL, "sad_set_option: unknown key '%s'", key);
 }

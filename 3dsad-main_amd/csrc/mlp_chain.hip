@@ -46,25 +46,108 @@ struct MlpParams {
     int bufA_rows, bufB_rows;
     int cpr, cshift;       // float4 chunks per feature row (0 = scalar path), log2 of lanes per row
     int vec_out;           // 16-B output stores allowed
+    int bias_total;        // sum of np[l]: biases are copied to LDS once per workgroup
 };
 
-__device__ __forceinline__ float xor_max(float v, int off) {
-    const float o = __shfl_xor(v, off, 64);
+// LDS activation image of a tile of R rows.  Channels are grouped in k-blocks of 8; inside a block
+// the even channels (plane 0) and the odd channels (plane 1) are separate [row][4] arrays, so lane
+// (j,h) of a wave fetches the four B operands of a k-step (k = 8t + 2e + h, e = 0..3) for its row
+// with ONE conflict-free ds_read_b128:   float index = (((c>>3)*2 + (c&1))*R + row)*4 + ((c&7)>>1)
+__device__ __forceinline__ int act_idx(int c, int r, int R) {
+    return ((((c >> 3) << 1) + (c & 1)) * R + r) * 4 + ((c & 7) >> 1);
+}
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_max(float v) {
+    const float o = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
     return o > v ? o : v;
 }
 
-// One 8-deep k-step (four MFMA k-pairs) for all RW row tiles of this wave.
+// max over aligned groups of 2^steps lanes (steps <= 5), every lane of a group gets the result
+__device__ __forceinline__ float group_max(float v, int steps) {
+    if (steps > 0) v = dpp_max<0xB1>(v);   // quad_perm [1,0,3,2]
+    if (steps > 1) v = dpp_max<0x4E>(v);   // quad_perm [2,3,0,1]
+    if (steps > 2) v = dpp_max<0x141>(v);  // row_half_mirror
+    if (steps > 3) v = dpp_max<0x140>(v);  // row_mirror
+    if (steps > 4) {
+        const float o = __shfl_xor(v, 16, 64);
+        v = o > v ? o : v;
+    }
+    return v;
+}
+
+// The k-loop of one output tile: acc[rt] += W[oc tile, k0 : k0 + 8*n4] * X[k, rows of tile rt].
+// af: this lane's A fragments (one float4 = 4 k-pairs per k-step, 64 float4 apart per k-step),
+// bp: this lane's B operands (one float4 per k-step, kbs float4 apart per k-step, 32 per row tile).
+// Software pipeline written out by hand (hipcc otherwise sinks each load to its use): a ring of
+// four A registers refilled right after use (L2 latency covered by three k-steps of MFMAs) and two
+// B registers (LDS latency covered by one k-step).
 template <int RW>
-__device__ __forceinline__ void kstep(f32x16 (&acc)[RW], const float4 a, const float *__restrict__ in,
-                                      int RP) {
-    const float av[4] = {a.x, a.y, a.z, a.w};
+struct BFrag { float4 v[RW]; };
+
+template <int RW>
+__device__ __forceinline__ void mma4(f32x16 (&acc)[RW], const float4 a, const BFrag<RW> &b) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
+    for (int rt = 0; rt < RW; ++rt) acc[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.v[rt].x, acc[rt], 0, 0, 0);
 #pragma unroll
-        for (int rt = 0; rt < RW; ++rt) {
-            const float bv = in[(2 * e) * RP + rt * 32];
-            acc[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], bv, acc[rt], 0, 0, 0);
+    for (int rt = 0; rt < RW; ++rt) acc[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.v[rt].y, acc[rt], 0, 0, 0);
+#pragma unroll
+    for (int rt = 0; rt < RW; ++rt) acc[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.v[rt].z, acc[rt], 0, 0, 0);
+#pragma unroll
+    for (int rt = 0; rt < RW; ++rt) acc[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.v[rt].w, acc[rt], 0, 0, 0);
+}
+
+template <int RW>
+__device__ __forceinline__ BFrag<RW> ldb(const float4 *__restrict__ bp, int t, int n4, int kbs) {
+    BFrag<RW> b;
+    const int tc = t < n4 ? t : n4 - 1;
+#pragma unroll
+    for (int rt = 0; rt < RW; ++rt) b.v[rt] = bp[tc * kbs + rt * 32];
+    return b;
+}
+
+__device__ __forceinline__ float4 lda(const float4 *__restrict__ af, int t, int n4) {
+    return af[(t < n4 ? t : n4 - 1) * 64];
+}
+
+template <int RW>
+__device__ __forceinline__ void mma_ktile(f32x16 (&acc)[RW], const float4 *__restrict__ af, int n4,
+                                          const float4 *__restrict__ bp, int kbs) {
+    float4 a0 = lda(af, 0, n4), a1 = lda(af, 1, n4), a2 = lda(af, 2, n4), a3 = lda(af, 3, n4);
+    BFrag<RW> b0 = ldb<RW>(bp, 0, n4, kbs), b1 = ldb<RW>(bp, 1, n4, kbs);
+    int t = 0;
+    if (n4 >= 4) {
+        // Opaque touch: keeps InstCombine from folding the loop PHIs of loads into "load at use".
+        asm volatile("" : "+v"(a0.x), "+v"(a1.x), "+v"(a2.x), "+v"(a3.x));
+#pragma unroll
+        for (int rt = 0; rt < RW; ++rt) asm volatile("" : "+v"(b0.v[rt].x), "+v"(b1.v[rt].x));
+        for (; t + 4 <= n4; t += 4) {
+            // sched_barrier(0): the refill of a register must stay right behind the MFMAs that
+            // consumed it (the machine scheduler otherwise clusters all refills at the loop end)
+            mma4<RW>(acc, a0, b0);
+            a0 = lda(af, t + 4, n4);
+            b0 = ldb<RW>(bp, t + 2, n4, kbs);
+            __builtin_amdgcn_sched_barrier(0);
+            mma4<RW>(acc, a1, b1);
+            a1 = lda(af, t + 5, n4);
+            b1 = ldb<RW>(bp, t + 3, n4, kbs);
+            __builtin_amdgcn_sched_barrier(0);
+            mma4<RW>(acc, a2, b0);
+            a2 = lda(af, t + 6, n4);
+            b0 = ldb<RW>(bp, t + 4, n4, kbs);
+            __builtin_amdgcn_sched_barrier(0);
+            mma4<RW>(acc, a3, b1);
+            a3 = lda(af, t + 7, n4);
+            b1 = ldb<RW>(bp, t + 5, n4, kbs);
+            __builtin_amdgcn_sched_barrier(0);
         }
+    }
+    const int rem = n4 - t;   // 0..3 k-steps left; a0..a2 / b0,b1 already hold them
+    if (rem > 0) mma4<RW>(acc, a0, b0);
+    if (rem > 1) mma4<RW>(acc, a1, b1);
+    if (rem > 2) {
+        b0 = ldb<RW>(bp, t + 2, n4, kbs);
+        mma4<RW>(acc, a2, b0);
     }
 }
 
@@ -80,15 +163,15 @@ __global__ __launch_bounds__(W * 64) void mlp_chain_kernel(const MlpParams p) {
     const int wn = wave & (WN - 1);
     const int wm = wave >> p.wn_shift;
     const int R = 32 * RW * WM;
-    const int RP = R + 1;
     float *bufA = smem;
-    float *bufB = smem + (size_t)p.bufA_rows * RP;
-    int *sm_idx = reinterpret_cast<int *>(bufB + (size_t)p.bufB_rows * RP);
+    float *bufB = smem + (size_t)p.bufA_rows * R;
+    float *sbias = bufB + (size_t)p.bufB_rows * R;
+    int *sm_idx = reinterpret_cast<int *>(sbias + p.bias_total);
     const long long r0 = (long long)blockIdx.x * R;
     const int koff = p.grouped ? 4 : 0;
     const int Sp = 1 << p.sp_shift;
 
-    // ---- per-row source index: grouped -> global point index b*N + idx, plain -> row -----------
+    // ---- per-row source index (grouped: global point index b*N + idx; plain: row) and biases ----
     for (int r = tid; r < R; r += W * 64) {
         long long gr = r0 + r;
         if (gr >= p.total_rows) gr = p.total_rows - 1;
@@ -102,22 +185,30 @@ __global__ __launch_bounds__(W * 64) void mlp_chain_kernel(const MlpParams p) {
             sm_idx[r] = (int)gr;
         }
     }
+    {
+        int bo = 0;
+        for (int l = 0; l < p.L; ++l) {
+            for (int c = tid; c < p.np[l]; c += W * 64) sbias[bo + c] = p.packed[p.off[l] + c];
+            bo += p.np[l];
+        }
+    }
     __syncthreads();
 
     const int nchunks = (p.kp[0] + p.kc - 1) / p.kc;
+    int bias_off = 0;
 
     for (int l = 0; l < p.L; ++l) {
         const float *in = (l & 1) ? bufB : bufA;
         float *outb = (l & 1) ? bufA : bufB;
         const int n_oc = p.np[l] >> 5;
         const int nrounds = (n_oc + WN - 1) >> p.wn_shift;
-        const float *wl = p.packed + p.off[l];
-        const float *bias = wl;
-        const float4 *frags = reinterpret_cast<const float4 *>(wl + p.np[l]);
+        const float4 *frags = reinterpret_cast<const float4 *>(p.packed + p.off[l] + p.np[l]);
         const int nT4 = p.kp[l] >> 3;
         const bool last = (l == p.L - 1);
         const bool relu = (p.relu_mask >> l) & 1;
         const int lchunks = (l == 0) ? nchunks : 1;
+        // channels of this layer's output the next layer actually reads (its padded K)
+        const int keep = last ? p.cout_last : p.kp[l + 1];
 
         for (int round = 0; round < nrounds; ++round) {
             const int oc = wn + (round << p.wn_shift);
@@ -125,10 +216,15 @@ __global__ __launch_bounds__(W * 64) void mlp_chain_kernel(const MlpParams p) {
             f32x16 acc[RW];
             if (have) {
 #pragma unroll
-                for (int g = 0; g < 16; ++g) {
-                    const float bv = bias[oc * 32 + 8 * (g >> 2) + (g & 3) + 4 * h];
+                for (int a = 0; a < 4; ++a) {
+                    const float4 bv = *reinterpret_cast<const float4 *>(sbias + bias_off + oc * 32 + 8 * a + 4 * h);
 #pragma unroll
-                    for (int rt = 0; rt < RW; ++rt) acc[rt][g] = bv;
+                    for (int rt = 0; rt < RW; ++rt) {
+                        acc[rt][4 * a + 0] = bv.x;
+                        acc[rt][4 * a + 1] = bv.y;
+                        acc[rt][4 * a + 2] = bv.z;
+                        acc[rt][4 * a + 3] = bv.w;
+                    }
                 }
             }
             for (int ck = 0; ck < lchunks; ++ck) {
@@ -136,22 +232,20 @@ __global__ __launch_bounds__(W * 64) void mlp_chain_kernel(const MlpParams p) {
                 int k1 = (l == 0) ? k0 + p.kc : p.kp[l];
                 if (k1 > p.kp[l]) k1 = p.kp[l];
                 if (l == 0 && (round == 0 || lchunks > 1)) {
-                    // ---- stage input channels [k0,k1) of the tile into bufA (rows k - k0) -------
+                    // ---- stage input channels [k0,k1) of the tile into bufA (channel c - k0) -----
                     if (!(round == 0 && ck == 0)) __syncthreads();  // previous readers are done
-                    if (p.grouped && k0 == 0) {  // rows 0..3 = point - centroid, 0 (SPEC.md §6)
+                    if (p.grouped && k0 == 0) {  // channels 0..3 = point - centroid, 0 (SPEC.md §6)
                         for (int r = tid; r < R; r += W * 64) {
                             long long gr = r0 + r;
                             if (gr >= p.total_rows) gr = p.total_rows - 1;
                             const float *q = p.xyz + (long long)sm_idx[r] * 3;
                             const float *c = p.new_xyz + (gr >> p.sp_shift) * 3;
-                            bufA[0 * RP + r] = q[0] - c[0];
-                            bufA[1 * RP + r] = q[1] - c[1];
-                            bufA[2 * RP + r] = q[2] - c[2];
-                            bufA[3 * RP + r] = 0.f;
+                            *reinterpret_cast<float2 *>(bufA + (size_t)(0 * R + r) * 4) = make_float2(q[0] - c[0], q[2] - c[2]);
+                            *reinterpret_cast<float2 *>(bufA + (size_t)(1 * R + r) * 4) = make_float2(q[1] - c[1], 0.f);
                         }
                     }
                     const int f0 = (k0 > koff ? k0 : koff) - koff;         // first feature channel
-                    int f1 = k1 - koff;                                    // one past the last
+                    const int f1 = k1 - koff;                              // one past the last
                     const int fl = f1 < p.C ? f1 : p.C;
                     if (p.cpr > 0) {
                         const int cprp = 1 << p.cshift;
@@ -160,44 +254,28 @@ __global__ __launch_bounds__(W * 64) void mlp_chain_kernel(const MlpParams p) {
                             const float *src = p.feat + (long long)sm_idx[r] * p.ld_feat;
                             for (int ch = (f0 >> 2) + (lane & (cprp - 1)); ch < (fl >> 2); ch += cprp) {
                                 const float4 v = *reinterpret_cast<const float4 *>(src + 4 * ch);
-                                float *d = bufA + (size_t)(koff + 4 * ch - k0) * RP + r;
-                                d[0] = v.x;
-                                d[RP] = v.y;
-                                d[2 * RP] = v.z;
-                                d[3 * RP] = v.w;
+                                const int c = koff + 4 * ch - k0;  // multiple of 4
+                                float *d = bufA + ((size_t)((c >> 3) << 1) * R + r) * 4 + ((c & 7) >> 1);
+                                *reinterpret_cast<float2 *>(d) = make_float2(v.x, v.z);                 // even channels
+                                *reinterpret_cast<float2 *>(d + (size_t)R * 4) = make_float2(v.y, v.w);  // odd channels
                             }
                         }
                     } else {
                         for (int r = tid; r < R; r += W * 64) {
                             const float *src = p.feat + (long long)sm_idx[r] * p.ld_feat;
-                            for (int c = f0; c < fl; ++c) bufA[(size_t)(koff + c - k0) * RP + r] = src[c];
+                            for (int c = f0; c < fl; ++c) bufA[act_idx(koff + c - k0, r, R)] = src[c];
                         }
                     }
                     // zero the channel padding [koff + C, kp) that falls inside this chunk
                     const int z0 = (koff + p.C > k0 ? koff + p.C : k0);
                     for (int k = z0 + wave; k < k1; k += W)
-                        for (int r = lane; r < R; r += 64) bufA[(size_t)(k - k0) * RP + r] = 0.f;
+                        for (int r = lane; r < R; r += 64) bufA[act_idx(k - k0, r, R)] = 0.f;
                     __syncthreads();
                 }
                 if (have) {
-                    const float *inw = in + (size_t)h * RP + (wm * RW) * 32 + j;  // + k*RP per k-pair
+                    const float4 *bp = reinterpret_cast<const float4 *>(in) + (size_t)h * R + (wm * RW) * 32 + j;
                     const float4 *af = frags + ((size_t)oc * nT4 + (k0 >> 3)) * 64 + lane;
-                    const int n4 = (k1 - k0) >> 3;
-                    float4 a0 = af[0];
-                    float4 a1 = af[(1 < n4 ? 1 : n4 - 1) * 64];
-                    float4 a2 = af[(2 < n4 ? 2 : n4 - 1) * 64];
-                    float4 a3 = af[(3 < n4 ? 3 : n4 - 1) * 64];
-                    for (int t = 0; t < n4; t += 4) {
-                        const float4 b0 = af[(t + 4 < n4 ? t + 4 : n4 - 1) * 64];
-                        const float4 b1 = af[(t + 5 < n4 ? t + 5 : n4 - 1) * 64];
-                        const float4 b2 = af[(t + 6 < n4 ? t + 6 : n4 - 1) * 64];
-                        const float4 b3 = af[(t + 7 < n4 ? t + 7 : n4 - 1) * 64];
-                        kstep<RW>(acc, a0, inw + (size_t)(8 * t) * RP, RP);
-                        if (t + 1 < n4) kstep<RW>(acc, a1, inw + (size_t)(8 * t + 8) * RP, RP);
-                        if (t + 2 < n4) kstep<RW>(acc, a2, inw + (size_t)(8 * t + 16) * RP, RP);
-                        if (t + 3 < n4) kstep<RW>(acc, a3, inw + (size_t)(8 * t + 24) * RP, RP);
-                        a0 = b0; a1 = b1; a2 = b2; a3 = b3;
-                    }
+                    mma_ktile<RW>(acc, af, (k1 - k0) >> 3, bp, 2 * R);
                 }
             }
             if (!have) continue;
@@ -209,11 +287,17 @@ __global__ __launch_bounds__(W * 64) void mlp_chain_kernel(const MlpParams p) {
                     for (int g = 0; g < 16; ++g) acc[rt][g] = acc[rt][g] > 0.f ? acc[rt][g] : 0.f;
             }
             if (!last) {
+                // channel c = oc*32 + 8a + q + 4h -> k-block oc*4 + a, plane q&1, slot (q>>1) + 2h
 #pragma unroll
-                for (int rt = 0; rt < RW; ++rt)
+                for (int a = 0; a < 4; ++a) {
+                    if (oc * 32 + 8 * a >= keep) continue;   // the next layer never reads these
 #pragma unroll
-                    for (int g = 0; g < 16; ++g)
-                        outb[(size_t)(oc * 32 + 8 * (g >> 2) + (g & 3) + 4 * h) * RP + (wm * RW + rt) * 32 + j] = acc[rt][g];
+                    for (int rt = 0; rt < RW; ++rt) {
+                        float *d = outb + ((size_t)((oc * 4 + a) * 2) * R + (wm * RW + rt) * 32 + j) * 4 + 2 * h;
+                        *reinterpret_cast<float2 *>(d) = make_float2(acc[rt][4 * a + 0], acc[rt][4 * a + 2]);
+                        *reinterpret_cast<float2 *>(d + (size_t)R * 4) = make_float2(acc[rt][4 * a + 1], acc[rt][4 * a + 3]);
+                    }
+                }
             } else if (!p.grouped) {
                 // plain rows: lane (j,h) holds row j, channels oc*32 + 8a + 4h + (0..3)
 #pragma unroll
@@ -243,16 +327,12 @@ __global__ __launch_bounds__(W * 64) void mlp_chain_kernel(const MlpParams p) {
                 }
                 const int lsteps = p.sp_shift < 5 ? p.sp_shift : 5;  // butterfly steps inside a half
                 const int rstep = (p.sp_shift == 6) ? 2 : 1;
+                const int gl = (p.sp_shift < 5) ? Sp : 32;          // lanes per group inside a half
 #pragma unroll
                 for (int rt = 0; rt < RW; rt += 1) {
                     if (rstep == 2 && (rt & 1)) continue;
 #pragma unroll
-                    for (int g = 0; g < 16; ++g) {
-                        float v = acc[rt][g];
-                        for (int s = 0; s < lsteps; ++s) v = xor_max(v, 1 << s);
-                        acc[rt][g] = v;
-                    }
-                    const int gl = (p.sp_shift < 5) ? Sp : 32;      // lanes per group inside a half
+                    for (int g = 0; g < 16; ++g) acc[rt][g] = group_max(acc[rt][g], lsteps);
                     if ((j & (gl - 1)) != 0) continue;
                     const long long row = r0 + (wm * RW + rt) * 32 + j;
                     const long long grp = row >> p.sp_shift;
@@ -272,6 +352,7 @@ __global__ __launch_bounds__(W * 64) void mlp_chain_kernel(const MlpParams p) {
                 }
             }
         }
+        bias_off += p.np[l];
         __syncthreads();
     }
 }
@@ -429,13 +510,17 @@ SAD_API int sad_mlp_chain_f32(const sad_mlp_args *a, sad_stream_t stream) {
     };
     // ---- choose the workgroup geometry -----------------------------------------------------
     // W waves, WN along output tiles; R = 32*RW*(W/WN) rows per workgroup.
-    const size_t BUDGET2 = 78 * 1024, BUDGET1 = 156 * 1024;
+    const int bkb = sad::get_option(sad::OPT_MLP_BUDGET_KB);
+    const size_t BUDGET2 = (size_t)(bkb > 0 ? bkb : 78) * 1024, BUDGET1 = 156 * 1024;
+    int bias_total = 0;
+    for (int l = 0; l < a->L; ++l) bias_total += g.np[l];
+    p.bias_total = bias_total;
     int W = 4, wn_shift = 0, RW = 1, kc = g.kp[0];
     auto lds_bytes = [&](int w, int wns, int rw, int kcc) {
         int ra, rb;
         lds_rows(kcc, ra, rb);
         const size_t R = 32 * (size_t)rw * (w >> wns);
-        return ((size_t)(ra + rb) * (R + 1) + R) * 4 + 16;
+        return ((size_t)(ra + rb) * R + R + (size_t)bias_total) * 4 + 16;
     };
     {
         if (max_noc >= 16 && min_noc >= 8) W = 8;

@@ -71,6 +71,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-scenes", type=int, default=32)
     ap.add_argument("--no-launch-timing", action="store_true")
+    ap.add_argument("--opt", action="append", default=[], help="tuning knob key=value (sad_set_option)")
     args = ap.parse_args()
 
     import numpy as np
@@ -95,6 +96,10 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)   # RCCL on ROCm
 
+    from sad_amd import _lib
+    for kv in args.opt:
+        k, v = kv.split("=")
+        _lib.set_option(k, int(v))
     cfg = config.KITTI
     weights = synth.make_weights(cfg, 0)
     det = SADDetector(cfg, weights, dev, overlap_fps=not args.no_overlap)
@@ -150,7 +155,7 @@ def main():
                                    "3-stage multi-radius SA backbone fp32 + size-adaptive cluster layer + box head",
                        "scenes_per_gpu": B, "global_batch": world * B, "n_points": cfg.n_points,
                        "parallelism": f"batch-sharded x{world}, one all_gather of boxes",
-                       "fps_overlap": not args.no_overlap},
+                       "fps_overlap": not args.no_overlap, "opts": args.opt},
         }
         if log:
             mlp_ms = per_kind.get("mlp", 0.0) / steps
