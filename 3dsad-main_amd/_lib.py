@@ -30,6 +30,7 @@ class MlpArgs(ctypes.Structure):
         ("L", ctypes.c_int), ("dims", ctypes.c_int * (MAX_LAYERS + 1)),
         ("packed", vp), ("relu_mask", ctypes.c_int),
         ("out", vp), ("ld_out", ctypes.c_int), ("col_off", ctypes.c_int),
+        ("geometry", ctypes.c_int),
     ]
 
 

@@ -132,6 +132,107 @@ __global__ __launch_bounds__(THREADS) void fps_reg_kernel(const float *__restric
     }
 }
 
+// ---- v2: 64-bit (distance, ~index) keys, DPP/readlane reductions, pick coordinates via LDS -------
+// key = float_bits(min_dist) << 32 | ~index : unsigned max = largest distance, ties -> lowest index
+// (min-distances are >= 0, so their bit patterns order like the floats).  Per step: PPT distance
+// updates per lane, a wave arg-max (4 DPP butterflies + 4 readlanes), the wave's winning lane puts
+// its key and its point's coordinates into LDS, ONE barrier, every wave reduces the 16 keys and
+// reads the winner's coordinates back from LDS — no global access on the serial chain.
+typedef unsigned long long u64;
+
+template <int CTRL>
+__device__ __forceinline__ u64 dpp_u64(u64 v) {
+    const unsigned lo = __builtin_amdgcn_update_dpp(0u, (unsigned)v, CTRL, 0xF, 0xF, false);
+    const unsigned hi = __builtin_amdgcn_update_dpp(0u, (unsigned)(v >> 32), CTRL, 0xF, 0xF, false);
+    return ((u64)hi << 32) | lo;
+}
+__device__ __forceinline__ u64 umax64(u64 a, u64 b) { return a > b ? a : b; }
+__device__ __forceinline__ u64 row_max_u64(u64 k) {  // max over each row of 16 lanes
+    k = umax64(k, dpp_u64<0xB1>(k));
+    k = umax64(k, dpp_u64<0x4E>(k));
+    k = umax64(k, dpp_u64<0x141>(k));
+    k = umax64(k, dpp_u64<0x140>(k));
+    return k;
+}
+__device__ __forceinline__ u64 readlane_u64(u64 v, int l) {
+    const unsigned lo = __builtin_amdgcn_readlane((unsigned)v, l);
+    const unsigned hi = __builtin_amdgcn_readlane((unsigned)(v >> 32), l);
+    return ((u64)hi << 32) | lo;
+}
+
+template <int THREADS, int PPT>
+__global__ __launch_bounds__(THREADS) void fps_key_kernel(const float *__restrict__ xyz, int N,
+                                                          int M, int *__restrict__ idx_out) {
+    constexpr int NW = THREADS / 64;
+    typedef float fvec __attribute__((ext_vector_type(PPT)));
+    __shared__ u64 s_key[2][16];
+    __shared__ float s_xyz[2][16][4];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const float *p = xyz + (size_t)blockIdx.x * N * 3;
+    int *out = idx_out + (size_t)blockIdx.x * M;
+
+    fvec px, py, pz, md;
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+        const int j = k * THREADS + tid;
+        if (j < N) {
+            px[k] = p[j * 3 + 0];
+            py[k] = p[j * 3 + 1];
+            pz[k] = p[j * 3 + 2];
+            md[k] = __builtin_inff();
+        } else {  // padding: distance 0 and an index above every real one never beats a real point
+            px[k] = py[k] = pz[k] = 0.f;
+            md[k] = 0.f;
+        }
+    }
+    if (tid == 0) out[0] = 0;
+    float cx = p[0], cy = p[1], cz = p[2];
+    for (int i = 1; i < M; ++i) {
+        // whole-vector form: independent per-point chains the scheduler can interleave (packed f32)
+        const fvec dx = px - cx, dy = py - cy, dz = pz - cz;
+        const fvec d = (dx * dx + dy * dy) + dz * dz;          // SPEC.md §1 order, no contraction
+        md = __builtin_elementwise_min(md, d);                 // no NaNs by contract (SPEC.md)
+        float bd = md[0];
+        int bk = 0;
+#pragma unroll
+        for (int k = 1; k < PPT; ++k) {
+            if (md[k] > bd) {  // strict: ascending k keeps the thread's lowest index
+                bd = md[k];
+                bk = k;
+            }
+        }
+        const unsigned j = (unsigned)(bk * THREADS + tid);
+        u64 key = ((u64)__builtin_bit_cast(unsigned, bd) << 32) | (unsigned)(~j);
+        key = row_max_u64(key);
+        const u64 k0 = readlane_u64(key, 0), k1 = readlane_u64(key, 16), k2 = readlane_u64(key, 32), k3 = readlane_u64(key, 48);
+        const u64 wkey = umax64(umax64(k0, k1), umax64(k2, k3));   // wave-uniform
+        const unsigned wj = ~(unsigned)wkey;                        // the wave's best point
+        const int buf = i & 1;
+        if ((unsigned)tid == (wj & (THREADS - 1))) {                // its owner lane (in this wave)
+            const int kk = __builtin_amdgcn_readfirstlane((int)(wj / THREADS));
+            s_key[buf][wave] = wkey;
+            s_xyz[buf][wave][0] = px[kk];
+            s_xyz[buf][wave][1] = py[kk];
+            s_xyz[buf][wave][2] = pz[kk];
+        }
+        __syncthreads();
+        u64 g = s_key[buf][lane & (NW - 1)];
+        if constexpr (NW == 16) {
+            g = row_max_u64(g);
+        } else {
+            g = umax64(g, dpp_u64<0xB1>(g));
+            g = umax64(g, dpp_u64<0x4E>(g));
+        }
+        const unsigned gj = __builtin_amdgcn_readfirstlane(~(unsigned)g);
+        const int gw = (gj & (THREADS - 1)) >> 6;                   // wave that owns the winner
+        cx = s_xyz[buf][gw][0];
+        cy = s_xyz[buf][gw][1];
+        cz = s_xyz[buf][gw][2];
+        if (tid == 0) out[i] = (int)gj;
+    }
+}
+
 // Any N: min-distances in a global workspace (L2-resident), coordinates re-read every step.
 __global__ __launch_bounds__(1024) void fps_big_kernel(const float *__restrict__ xyz, int N, int M,
                                                        float *__restrict__ mind_ws,
@@ -176,6 +277,10 @@ __global__ __launch_bounds__(1024) void fps_big_kernel(const float *__restrict__
 
 template <int THREADS, int PPT>
 void launch_reg(const float *xyz, int B, int N, int M, int *idx, hipStream_t st, bool dpp) {
+    if (sad::get_option(sad::OPT_FPS_VARIANT) != 1) {  // default: the key kernel; 1 = (d, idx) pair kernel
+        hipLaunchKernelGGL((fps_key_kernel<THREADS, PPT>), dim3(B), dim3(THREADS), 0, st, xyz, N, M, idx);
+        return;
+    }
     if (dpp)
         hipLaunchKernelGGL((fps_reg_kernel<THREADS, PPT, true>), dim3(B), dim3(THREADS), 0, st, xyz, N, M, idx);
     else

@@ -499,50 +499,69 @@ SAD_API int sad_mlp_chain_f32(const sad_mlp_args *a, sad_stream_t stream) {
     } else {
         p.cpr = 0; p.cshift = 0;
     }
-    // LDS rows: bufA holds inputs of even layers / outputs of odd layers, bufB the others
+    // LDS rows: bufA holds inputs of even layers / outputs of odd layers, bufB the others.  A layer's
+    // output only needs the channels the next layer reads (its padded K).
     auto lds_rows = [&](int kc, int &ra, int &rb) {
-        ra = kc; rb = 1;
-        for (int l = 0; l < a->L; ++l) {
-            if (l == a->L - 1) break;  // the last layer's output never touches LDS
+        ra = kc; rb = 8;
+        for (int l = 0; l + 1 < a->L; ++l) {  // the last layer's output never touches LDS
             int &dst = (l & 1) ? ra : rb;
-            dst = g.np[l] > dst ? g.np[l] : dst;
+            const int keep = g.kp[l + 1];
+            dst = keep > dst ? keep : dst;
         }
     };
-    // ---- choose the workgroup geometry -----------------------------------------------------
-    // W waves, WN along output tiles; R = 32*RW*(W/WN) rows per workgroup.
-    const int bkb = sad::get_option(sad::OPT_MLP_BUDGET_KB);
-    const size_t BUDGET2 = (size_t)(bkb > 0 ? bkb : 78) * 1024, BUDGET1 = 156 * 1024;
     int bias_total = 0;
     for (int l = 0; l < a->L; ++l) bias_total += g.np[l];
     p.bias_total = bias_total;
-    int W = 4, wn_shift = 0, RW = 1, kc = g.kp[0];
     auto lds_bytes = [&](int w, int wns, int rw, int kcc) {
         int ra, rb;
         lds_rows(kcc, ra, rb);
         const size_t R = 32 * (size_t)rw * (w >> wns);
         return ((size_t)(ra + rb) * R + R + (size_t)bias_total) * 4 + 16;
     };
-    {
-        if (max_noc >= 16 && min_noc >= 8) W = 8;
-        int wmax = 0;
-        while ((1 << (wmax + 1)) <= W) ++wmax;                 // log2(W)
-        int wns0 = 0;                                          // WN <= narrowest layer's tile count
-        while (wns0 < wmax && (1 << (wns0 + 1)) <= min_noc) ++wns0;
-        const int rw_min = (grouped && sp_shift == 6) ? 2 : 1; // 64-row pooling groups span 2 tiles
-        const int rw_opt = sad::get_option(sad::OPT_MLP_RW);
+    // ---- choose the workgroup geometry -----------------------------------------------------
+    // W waves, WN along output tiles; R = 32*RW*(W/WN) rows per workgroup.
+    const int bkb = sad::get_option(sad::OPT_MLP_BUDGET_KB);
+    const size_t BUDGET2 = (size_t)(bkb > 0 ? bkb : 78) * 1024, BUDGET1 = 156 * 1024;
+    const int rw_min = (grouped && sp_shift == 6) ? 2 : 1;  // 64-row pooling groups span 2 tiles
+    int W = 8, wn_shift = 0, RW = 1, kc = g.kp[0];
+    int geom = a->geometry ? a->geometry : sad::get_option(sad::OPT_MLP_FORCE);
+    if (geom) {
+        const int fw = geom / 100, fwns = (geom / 10) % 10, frw = geom % 10;
+        const bool ok = (fw == 4 || fw == 8) && (1 << fwns) <= fw && (frw == 1 || frw == 2 || frw == 4) && frw >= rw_min;
+        if (!ok) return sad::fail(SAD_EUNSUPPORTED, "sad_mlp_chain_f32: geometry %d is not valid here", geom);
+        W = fw; wn_shift = fwns; RW = frw;
+        if (lds_bytes(W, wn_shift, RW, kc) > BUDGET1) {
+            kc = g.kp[0] < 256 ? g.kp[0] : 256;
+            if (kc == g.kp[0] || lds_bytes(W, wn_shift, RW, kc) > BUDGET1)
+                return sad::fail(SAD_EUNSUPPORTED, "sad_mlp_chain_f32: geometry %d does not fit LDS", geom);
+        }
+    } else {
+        // Heuristic (PackedMLP.autotune measures instead): 8 waves; WN = flop-weighted mean number
+        // of output tiles rounded down to a power of two (few idle waves, weights shared through
+        // LDS rows rather than re-read per wave); then the most rows per wave that still leave two
+        // workgroups per CU and at least two workgroups per CU-slot of work.
+        double wsum = 0, fsum = 0;
+        for (int l = 0; l < a->L; ++l) {
+            const double f = (double)g.kp[l] * g.np[l];
+            wsum += f * (g.np[l] / 32);
+            fsum += f;
+        }
+        int wns0 = 0;
+        while (wns0 < 3 && (2 << wns0) <= wsum / fsum + 1e-9) ++wns0;
         bool found = false;
-        // preference: fewest idle waves (small WN), then most rows per wave, two workgroups per CU
-        // before one, whole-input staging before k-chunked staging.
         for (int pass = 0; pass < 3 && !found; ++pass) {
             const size_t budget = pass == 0 ? BUDGET2 : BUDGET1;
             const int kcc = pass < 2 ? g.kp[0] : (g.kp[0] < 256 ? g.kp[0] : 256);
-            for (int wns = wns0; wns <= wmax && !found; ++wns)
-                for (int rw = 4; rw >= rw_min && !found; rw >>= 1) {
-                    if ((rw_opt == 1 || rw_opt == 2 || rw_opt == 4) && rw != rw_opt && rw_opt >= rw_min) continue;
-                    if (lds_bytes(W, wns, rw, kcc) <= budget) {
-                        wn_shift = wns; RW = rw; kc = kcc; found = true;
-                    }
+            for (int wns = wns0; wns <= 3 && !found; ++wns) {
+                int best_rw = 0;
+                for (int rw = 4; rw >= rw_min; rw >>= 1) {
+                    if (lds_bytes(8, wns, rw, kcc) > budget) continue;
+                    if (!best_rw) best_rw = rw;   // largest that fits
+                    const long long R = 32LL * rw * (8 >> wns);
+                    if ((p.total_rows + R - 1) / R >= 1024 || rw == rw_min) { best_rw = rw; break; }
                 }
+                if (best_rw) { wn_shift = wns; RW = best_rw; kc = kcc; found = true; }
+            }
         }
         if (!found) return sad::fail(SAD_EUNSUPPORTED, "sad_mlp_chain_f32: layer widths do not fit LDS");
     }

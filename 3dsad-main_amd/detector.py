@@ -49,6 +49,20 @@ class SADDetector(nn.Module):
         self.overlap_fps = overlap_fps
         self._side = torch.cuda.Stream(device=self.device) if overlap_fps else None
 
+    def autotune(self, points: torch.Tensor) -> dict:
+        """One synchronous forward pass during which every MLP launch times its workgroup
+        geometries on the real shapes and keeps the fastest.  Returns {launch name: geometry}."""
+        prev, ops.AUTOTUNE = ops.AUTOTUNE, True
+        ov, self.overlap_fps = self.overlap_fps, False
+        try:
+            self.forward(points)
+            torch.cuda.synchronize()
+        finally:
+            ops.AUTOTUNE, self.overlap_fps = prev, ov
+        mlps = [b for m in self.stages for b in m.branches] + [m.agg for m in self.stages if m.agg]
+        mlps += [self.cand_mlp, self.cluster_agg, self.head] + self.cluster_branches
+        return {m.name: list(m._geom.values())[-1] for m in mlps if m._geom}
+
     def _sample_chain(self, xyz):
         """All three stages' (new_xyz) — coordinates only."""
         out = []

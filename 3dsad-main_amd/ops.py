@@ -28,6 +28,10 @@ def _stream() -> int:
 # (kind, name, start_event, end_event).  None (the default) adds nothing to the launch path.
 LAUNCH_LOG: Optional[list] = None
 
+# When True, PackedMLP measures the workgroup geometries of mlp_chain_kernel on the first call for
+# each shape and keeps the fastest (SADDetector.autotune() switches it on for one forward pass).
+AUTOTUNE: bool = False
+
 
 class _timed:
     __slots__ = ("kind", "name", "ev")
@@ -197,6 +201,7 @@ class PackedMLP:
     def __init__(self, layers, first_has_xyz: bool, device, relu_mask: Optional[int] = None,
                  name: str = ""):
         self.name = name
+        self._geom = {}
         if not 1 <= len(layers) <= _lib.MAX_LAYERS:
             raise ValueError(f"1..{_lib.MAX_LAYERS} layers supported")
         self.device = torch.device(device)
@@ -221,6 +226,41 @@ class PackedMLP:
                                          self.packed.data_ptr(), _stream()), "sad_mlp_pack_f32")
             torch.cuda.current_stream().synchronize()  # ws/bs may be freed after this returns
         self.out_channels = self.dims[-1]
+
+    # Geometries tried by the autotuner: W*100 + log2(WN)*10 + RW (include/sad_amd.h, sad_mlp_args).
+    _CANDIDATES = [w * 100 + n * 10 + r for w in (8, 4) for n in range(4) if (1 << n) <= w
+                   for r in (1, 2, 4)]
+
+    def _launch(self, a: MlpArgs) -> None:
+        """Enqueue the chain.  With AUTOTUNE on, the first call for a shape times every workgroup
+        geometry that fits (a few ms, synchronous) and the fastest one is reused afterwards."""
+        key = (bool(a.idx), a.B, a.N, a.M, a.S, a.ld_out)
+        geom = self._geom.get(key)
+        if geom is None and AUTOTUNE:
+            geom = self._tune(a)
+            self._geom[key] = geom
+        a.geometry = geom or 0
+        with _timed("mlp", self.name):
+            check(lib().sad_mlp_chain_f32(ctypes.byref(a), _stream()), "sad_mlp_chain_f32")
+
+    def _tune(self, a: MlpArgs) -> int:
+        stream = torch.cuda.current_stream()
+        best, best_ms = 0, None
+        for code in [0] + self._CANDIDATES:
+            a.geometry = code
+            if lib().sad_mlp_chain_f32(ctypes.byref(a), _stream()) != 0:
+                continue            # does not fit LDS / not valid for this nsample
+            stream.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            for _ in range(3):
+                lib().sad_mlp_chain_f32(ctypes.byref(a), _stream())
+            e1.record(stream)
+            stream.synchronize()
+            ms = e0.elapsed_time(e1)
+            if best_ms is None or ms < best_ms * 0.98:   # prefer earlier entries on ties
+                best, best_ms = code, ms
+        return best
 
     def _args(self) -> MlpArgs:
         a = MlpArgs()
@@ -263,8 +303,7 @@ class PackedMLP:
         a.xyz, a.new_xyz, a.idx = xyz.data_ptr(), new_xyz.data_ptr(), idx.data_ptr()
         a.B, a.N, a.M, a.S, a.C = B, N, M, S, C
         a.out, a.ld_out, a.col_off = out.data_ptr(), out.stride(-2), col_off
-        with _timed("mlp", self.name):
-            check(lib().sad_mlp_chain_f32(ctypes.byref(a), _stream()), "sad_mlp_chain_f32")
+        self._launch(a)
         return out
 
     def rows(self, x: torch.Tensor, out: Optional[torch.Tensor] = None, col_off: int = 0
@@ -289,8 +328,7 @@ class PackedMLP:
         a.feat, a.ld_feat = x2.data_ptr(), x2.stride(0)
         a.B, a.N, a.M, a.S, a.C = 1, 0, R, 1, C
         a.out, a.ld_out, a.col_off = out.data_ptr(), out.stride(-2), col_off
-        with _timed("mlp", self.name):
-            check(lib().sad_mlp_chain_f32(ctypes.byref(a), _stream()), "sad_mlp_chain_f32")
+        self._launch(a)
         return out
 
     def _check_out(self, out: torch.Tensor, rows: int, col_off: int) -> None:

@@ -71,6 +71,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-scenes", type=int, default=32)
     ap.add_argument("--no-launch-timing", action="store_true")
+    ap.add_argument("--no-autotune", action="store_true", help="use the built-in geometry heuristic")
     ap.add_argument("--opt", action="append", default=[], help="tuning knob key=value (sad_set_option)")
     args = ap.parse_args()
 
@@ -106,6 +107,8 @@ def main():
     B = args.batch
     points = torch.from_numpy(synth.make_batch(rank * B, B, cfg.n_points)).to(dev)
     torch.cuda.synchronize()
+
+    tuned = None if args.no_autotune else det.autotune(points)
 
     def step():
         boxes = det(points, input_ready=True)
@@ -155,7 +158,8 @@ def main():
                                    "3-stage multi-radius SA backbone fp32 + size-adaptive cluster layer + box head",
                        "scenes_per_gpu": B, "global_batch": world * B, "n_points": cfg.n_points,
                        "parallelism": f"batch-sharded x{world}, one all_gather of boxes",
-                       "fps_overlap": not args.no_overlap, "opts": args.opt},
+                       "fps_overlap": not args.no_overlap, "opts": args.opt,
+                       "mlp_geometry": tuned if tuned is not None else "heuristic"},
         }
         if log:
             mlp_ms = per_kind.get("mlp", 0.0) / steps

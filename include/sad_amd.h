@@ -107,6 +107,10 @@ typedef struct sad_mlp_args {
     float *out;
     int ld_out;
     int col_off;
+    /* workgroup geometry: 0 = built-in heuristic; else W*100 + log2(WN)*10 + RW with W in {4,8}
+     * waves, WN waves along the 32-channel output tiles, RW in {1,2,4} row tiles of 32 rows per
+     * wave.  A geometry that does not fit LDS returns SAD_EUNSUPPORTED (autotuners skip it). */
+    int geometry;
 } sad_mlp_args;
 int sad_mlp_chain_f32(const sad_mlp_args *args, sad_stream_t stream);
 

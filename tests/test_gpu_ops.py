@@ -31,15 +31,18 @@ def _rand_xyz(seed, B, N, scale=1.0):
 @pytest.mark.parametrize("B,N,M", [(2, 64, 16), (3, 257, 100), (2, 1024, 256), (2, 2048, 512),
                                    (2, 3000, 700), (2, 4096, 1024), (1, 8192, 512), (2, 16384, 1024),
                                    (1, 5, 5), (1, 1, 1)])
-@pytest.mark.parametrize("dpp", [0, 1])
-def test_fps_parity(orc, sad, dev, B, N, M, dpp):
+@pytest.mark.parametrize("variant", ["shfl", "dpp", "key"])
+def test_fps_parity(orc, sad, dev, B, N, M, variant):
+    """Every FPS kernel variant (selected with sad_set_option) gives the oracle's indices."""
     from sad_amd import _lib, ops
-    _lib.set_option("fps_dpp", dpp)
+    _lib.set_option("fps_dpp", 1 if variant == "dpp" else 0)
+    _lib.set_option("fps_variant", {"shfl": 1, "dpp": 1, "key": 2}[variant])
     try:
         xyz = _rand_xyz(100 + N, B, N)
         got = ops.fps(_t(xyz, dev), M).cpu().numpy()
     finally:
         _lib.set_option("fps_dpp", 0)
+        _lib.set_option("fps_variant", 0)
     np.testing.assert_array_equal(got, orc.fps(xyz, M))
 
 
@@ -49,8 +52,17 @@ def test_fps_big_n_workspace_path(orc, sad, dev):
     np.testing.assert_array_equal(ops.fps(_t(xyz, dev), 300).cpu().numpy(), orc.fps(xyz, 300))
 
 
-def test_fps_edge_cases(orc, sad, dev):
-    from sad_amd import ops
+@pytest.mark.parametrize("variant", [1, 2])
+def test_fps_edge_cases(orc, sad, dev, variant):
+    from sad_amd import _lib, ops
+    _lib.set_option("fps_variant", variant)
+    try:
+        _fps_edge_cases(orc, dev, ops)
+    finally:
+        _lib.set_option("fps_variant", 0)
+
+
+def _fps_edge_cases(orc, dev, ops):
     g = np.load(os.path.join(GOLDEN, "edge_cases.npz"))
     np.testing.assert_array_equal(ops.fps(_t(g["line_xyz"], dev), 5).cpu().numpy(), g["line_fps5"])
     np.testing.assert_array_equal(ops.fps(_t(g["dup_xyz"], dev), 6).cpu().numpy(), g["dup_fps6"])
