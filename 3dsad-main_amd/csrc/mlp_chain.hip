@@ -53,8 +53,10 @@ struct MlpParams {
 // the even channels (plane 0) and the odd channels (plane 1) are separate [row][4] arrays, so lane
 // (j,h) of a wave fetches the four B operands of a k-step (k = 8t + 2e + h, e = 0..3) for its row
 // with ONE conflict-free ds_read_b128:   float index = (((c>>3)*2 + (c&1))*R + row)*4 + ((c&7)>>1)
-__device__ __forceinline__ int act_idx(int c, int r, int R) {
-    return ((((c >> 3) << 1) + (c & 1)) * R + r) * 4 + ((c & 7) >> 1);
+// Each plane is PS = 4R + 8 floats long: the 8-float pad staggers the planes over the LDS banks so
+// the staging stores of one row (16 lanes, 16 different planes) do not all hit one bank.
+__device__ __forceinline__ int act_idx(int c, int r, int PS) {
+    return (((c >> 3) << 1) + (c & 1)) * PS + r * 4 + ((c & 7) >> 1);
 }
 
 template <int CTRL>
@@ -110,44 +112,41 @@ __device__ __forceinline__ float4 lda(const float4 *__restrict__ af, int t, int 
     return af[(t < n4 ? t : n4 - 1) * 64];
 }
 
-template <int RW>
+template <int RW, int D>
 __device__ __forceinline__ void mma_ktile(f32x16 (&acc)[RW], const float4 *__restrict__ af, int n4,
                                           const float4 *__restrict__ bp, int kbs) {
-    float4 a0 = lda(af, 0, n4), a1 = lda(af, 1, n4), a2 = lda(af, 2, n4), a3 = lda(af, 3, n4);
-    BFrag<RW> b0 = ldb<RW>(bp, 0, n4, kbs), b1 = ldb<RW>(bp, 1, n4, kbs);
-    int t = 0;
-    if (n4 >= 4) {
-        // Opaque touch: keeps InstCombine from folding the loop PHIs of loads into "load at use".
-        asm volatile("" : "+v"(a0.x), "+v"(a1.x), "+v"(a2.x), "+v"(a3.x));
+    // ring of D A registers (refilled right behind the MFMAs that consumed them: L2 latency is
+    // covered by D-1 k-steps of MFMAs) and two B registers (LDS latency: one k-step)
+    float4 a[D];
 #pragma unroll
-        for (int rt = 0; rt < RW; ++rt) asm volatile("" : "+v"(b0.v[rt].x), "+v"(b1.v[rt].x));
-        for (; t + 4 <= n4; t += 4) {
-            // sched_barrier(0): the refill of a register must stay right behind the MFMAs that
-            // consumed it (the machine scheduler otherwise clusters all refills at the loop end)
-            mma4<RW>(acc, a0, b0);
-            a0 = lda(af, t + 4, n4);
-            b0 = ldb<RW>(bp, t + 2, n4, kbs);
-            __builtin_amdgcn_sched_barrier(0);
-            mma4<RW>(acc, a1, b1);
-            a1 = lda(af, t + 5, n4);
-            b1 = ldb<RW>(bp, t + 3, n4, kbs);
-            __builtin_amdgcn_sched_barrier(0);
-            mma4<RW>(acc, a2, b0);
-            a2 = lda(af, t + 6, n4);
-            b0 = ldb<RW>(bp, t + 4, n4, kbs);
-            __builtin_amdgcn_sched_barrier(0);
-            mma4<RW>(acc, a3, b1);
-            a3 = lda(af, t + 7, n4);
-            b1 = ldb<RW>(bp, t + 5, n4, kbs);
-            __builtin_amdgcn_sched_barrier(0);
+    for (int u = 0; u < D; ++u) a[u] = lda(af, u, n4);
+    BFrag<RW> b[2] = {ldb<RW>(bp, 0, n4, kbs), ldb<RW>(bp, 1, n4, kbs)};
+    int t = 0;
+    if (n4 >= D) {
+        // Opaque touch: keeps InstCombine from folding the loop PHIs of loads into "load at use".
+#pragma unroll
+        for (int u = 0; u < D; ++u) asm volatile("" : "+v"(a[u].x));
+#pragma unroll
+        for (int rt = 0; rt < RW; ++rt) asm volatile("" : "+v"(b[0].v[rt].x), "+v"(b[1].v[rt].x));
+        for (; t + D <= n4; t += D) {
+#pragma unroll
+            for (int u = 0; u < D; ++u) {
+                mma4<RW>(acc, a[u], b[u & 1]);
+                a[u] = lda(af, t + D + u, n4);
+                b[u & 1] = ldb<RW>(bp, t + u + 2, n4, kbs);
+                // the refill must stay right behind the MFMAs that consumed the register (the
+                // machine scheduler otherwise clusters all refills at the loop end)
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
     }
-    const int rem = n4 - t;   // 0..3 k-steps left; a0..a2 / b0,b1 already hold them
-    if (rem > 0) mma4<RW>(acc, a0, b0);
-    if (rem > 1) mma4<RW>(acc, a1, b1);
-    if (rem > 2) {
-        b0 = ldb<RW>(bp, t + 2, n4, kbs);
-        mma4<RW>(acc, a2, b0);
+    const int rem = n4 - t;   // 0..D-1 k-steps left; a[0..rem) and b[0], b[1] already hold them
+#pragma unroll
+    for (int u = 0; u < D - 1; ++u) {
+        if (u < rem) {
+            mma4<RW>(acc, a[u], b[u & 1]);
+            if (u + 2 < rem) b[u & 1] = ldb<RW>(bp, t + u + 2, n4, kbs);
+        }
     }
 }
 
@@ -163,9 +162,10 @@ __global__ __launch_bounds__(W * 64) void mlp_chain_kernel(const MlpParams p) {
     const int wn = wave & (WN - 1);
     const int wm = wave >> p.wn_shift;
     const int R = 32 * RW * WM;
+    const int PS = 4 * R + 8;             // floats per plane (see act_idx)
     float *bufA = smem;
-    float *bufB = smem + (size_t)p.bufA_rows * R;
-    float *sbias = bufB + (size_t)p.bufB_rows * R;
+    float *bufB = smem + (size_t)(p.bufA_rows >> 2) * PS;
+    float *sbias = bufB + (size_t)(p.bufB_rows >> 2) * PS;
     int *sm_idx = reinterpret_cast<int *>(sbias + p.bias_total);
     const long long r0 = (long long)blockIdx.x * R;
     const int koff = p.grouped ? 4 : 0;
@@ -240,8 +240,8 @@ __global__ __launch_bounds__(W * 64) void mlp_chain_kernel(const MlpParams p) {
                             if (gr >= p.total_rows) gr = p.total_rows - 1;
                             const float *q = p.xyz + (long long)sm_idx[r] * 3;
                             const float *c = p.new_xyz + (gr >> p.sp_shift) * 3;
-                            *reinterpret_cast<float2 *>(bufA + (size_t)(0 * R + r) * 4) = make_float2(q[0] - c[0], q[2] - c[2]);
-                            *reinterpret_cast<float2 *>(bufA + (size_t)(1 * R + r) * 4) = make_float2(q[1] - c[1], 0.f);
+                            *reinterpret_cast<float2 *>(bufA + r * 4) = make_float2(q[0] - c[0], q[2] - c[2]);
+                            *reinterpret_cast<float2 *>(bufA + PS + r * 4) = make_float2(q[1] - c[1], 0.f);
                         }
                     }
                     const int f0 = (k0 > koff ? k0 : koff) - koff;         // first feature channel
@@ -255,27 +255,27 @@ __global__ __launch_bounds__(W * 64) void mlp_chain_kernel(const MlpParams p) {
                             for (int ch = (f0 >> 2) + (lane & (cprp - 1)); ch < (fl >> 2); ch += cprp) {
                                 const float4 v = *reinterpret_cast<const float4 *>(src + 4 * ch);
                                 const int c = koff + 4 * ch - k0;  // multiple of 4
-                                float *d = bufA + ((size_t)((c >> 3) << 1) * R + r) * 4 + ((c & 7) >> 1);
-                                *reinterpret_cast<float2 *>(d) = make_float2(v.x, v.z);                 // even channels
-                                *reinterpret_cast<float2 *>(d + (size_t)R * 4) = make_float2(v.y, v.w);  // odd channels
+                                float *d = bufA + (size_t)((c >> 3) << 1) * PS + r * 4 + ((c & 7) >> 1);
+                                *reinterpret_cast<float2 *>(d) = make_float2(v.x, v.z);       // even channels
+                                *reinterpret_cast<float2 *>(d + PS) = make_float2(v.y, v.w);  // odd channels
                             }
                         }
                     } else {
                         for (int r = tid; r < R; r += W * 64) {
                             const float *src = p.feat + (long long)sm_idx[r] * p.ld_feat;
-                            for (int c = f0; c < fl; ++c) bufA[act_idx(koff + c - k0, r, R)] = src[c];
+                            for (int c = f0; c < fl; ++c) bufA[act_idx(koff + c - k0, r, PS)] = src[c];
                         }
                     }
                     // zero the channel padding [koff + C, kp) that falls inside this chunk
                     const int z0 = (koff + p.C > k0 ? koff + p.C : k0);
                     for (int k = z0 + wave; k < k1; k += W)
-                        for (int r = lane; r < R; r += 64) bufA[act_idx(k - k0, r, R)] = 0.f;
+                        for (int r = lane; r < R; r += 64) bufA[act_idx(k - k0, r, PS)] = 0.f;
                     __syncthreads();
                 }
                 if (have) {
-                    const float4 *bp = reinterpret_cast<const float4 *>(in) + (size_t)h * R + (wm * RW) * 32 + j;
+                    const float4 *bp = reinterpret_cast<const float4 *>(in) + (size_t)h * (PS >> 2) + (wm * RW) * 32 + j;
                     const float4 *af = frags + ((size_t)oc * nT4 + (k0 >> 3)) * 64 + lane;
-                    mma_ktile<RW>(acc, af, (k1 - k0) >> 3, bp, 2 * R);
+                    mma_ktile<RW, 4>(acc, af, (k1 - k0) >> 3, bp, PS >> 1);
                 }
             }
             if (!have) continue;
@@ -293,9 +293,9 @@ __global__ __launch_bounds__(W * 64) void mlp_chain_kernel(const MlpParams p) {
                     if (oc * 32 + 8 * a >= keep) continue;   // the next layer never reads these
 #pragma unroll
                     for (int rt = 0; rt < RW; ++rt) {
-                        float *d = outb + ((size_t)((oc * 4 + a) * 2) * R + (wm * RW + rt) * 32 + j) * 4 + 2 * h;
+                        float *d = outb + (size_t)((oc * 4 + a) * 2) * PS + ((wm * RW + rt) * 32 + j) * 4 + 2 * h;
                         *reinterpret_cast<float2 *>(d) = make_float2(acc[rt][4 * a + 0], acc[rt][4 * a + 2]);
-                        *reinterpret_cast<float2 *>(d + (size_t)R * 4) = make_float2(acc[rt][4 * a + 1], acc[rt][4 * a + 3]);
+                        *reinterpret_cast<float2 *>(d + PS) = make_float2(acc[rt][4 * a + 1], acc[rt][4 * a + 3]);
                     }
                 }
             } else if (!p.grouped) {
@@ -516,7 +516,7 @@ SAD_API int sad_mlp_chain_f32(const sad_mlp_args *a, sad_stream_t stream) {
         int ra, rb;
         lds_rows(kcc, ra, rb);
         const size_t R = 32 * (size_t)rw * (w >> wns);
-        return ((size_t)(ra + rb) * R + R + (size_t)bias_total) * 4 + 16;
+        return ((size_t)((ra + rb) / 4) * (4 * R + 8) + R + (size_t)bias_total) * 4 + 16;
     };
     // ---- choose the workgroup geometry -----------------------------------------------------
     // W waves, WN along output tiles; R = 32*RW*(W/WN) rows per workgroup.
