@@ -357,6 +357,111 @@ __global__ __launch_bounds__(W * 64) void mlp_chain_kernel(const MlpParams p) {
     }
 }
 
+// ---- narrow chains on the vector ALU: one (b, m, s) row per lane ------------------------------
+// For SA1-sized chains (3 layers, widths <= 64, <= 8 input channels) a 32x32 MFMA tile is mostly
+// padding and the LDS round trips / barriers of the tiled kernel dominate.  Here every lane carries
+// its row through the whole chain in registers with v_fma_f32 (the same k-ascending fmaf chain, so
+// still bit-identical), weights arrive through the scalar cache as SGPR operands, the max over the
+// nsample lanes of a group is a DPP butterfly, and there is no LDS and no barrier at all.
+struct ValuParams {
+    const float *xyz, *new_xyz, *feat;
+    const int32_t *idx;
+    const float *w[3], *b[3];
+    float *out;
+    long long total_rows;
+    int ld_feat, N, M, S, sp_shift, ld_out, col_off, vec_out;
+};
+
+template <int C0, int C1, int C2, int C3>
+__global__ __launch_bounds__(256) void mlp_valu_kernel(const ValuParams p) {
+    const int lane = threadIdx.x & 63;
+    long long gr = (long long)blockIdx.x * 256 + threadIdx.x;
+    const bool live = gr < p.total_rows;
+    if (!live) gr = p.total_rows - 1;
+    const int Sp = 1 << p.sp_shift;
+    const long long bm = gr >> p.sp_shift;
+    int s = (int)(gr & (Sp - 1));
+    if (s >= p.S) s = 0;
+    const int b = (int)(bm / p.M);
+    const long long pt = (long long)b * p.N + p.idx[bm * p.S + s];
+    float x[C0];
+    {
+        const float *q = p.xyz + pt * 3;
+        const float *c = p.new_xyz + bm * 3;
+        x[0] = q[0] - c[0];
+        x[1] = q[1] - c[1];
+        x[2] = q[2] - c[2];
+#pragma unroll
+        for (int k = 3; k < C0; ++k) x[k] = p.feat[pt * p.ld_feat + (k - 3)];
+    }
+    // k-major weights Wt[k][o]: the chain of output o is still fma(W[o][k], x[k], .) for k ascending
+    float h1[C1], h2[C2], h3[C3];
+#pragma unroll
+    for (int o = 0; o < C1; ++o) h1[o] = p.b[0][o];
+#pragma unroll
+    for (int k = 0; k < C0; ++k)
+#pragma unroll
+        for (int o = 0; o < C1; ++o) h1[o] = __builtin_fmaf(p.w[0][k * C1 + o], x[k], h1[o]);
+#pragma unroll
+    for (int o = 0; o < C1; ++o) h1[o] = __builtin_fmaxf(h1[o], 0.f);
+#pragma unroll
+    for (int o = 0; o < C2; ++o) h2[o] = p.b[1][o];
+#pragma unroll
+    for (int k = 0; k < C1; ++k)
+#pragma unroll
+        for (int o = 0; o < C2; ++o) h2[o] = __builtin_fmaf(p.w[1][k * C2 + o], h1[k], h2[o]);
+#pragma unroll
+    for (int o = 0; o < C2; ++o) h2[o] = __builtin_fmaxf(h2[o], 0.f);
+#pragma unroll
+    for (int o = 0; o < C3; ++o) h3[o] = p.b[2][o];
+#pragma unroll
+    for (int k = 0; k < C2; ++k)
+#pragma unroll
+        for (int o = 0; o < C3; ++o) h3[o] = __builtin_fmaf(p.w[2][k * C3 + o], h2[k], h3[o]);
+#pragma unroll
+    for (int o = 0; o < C3; ++o) h3[o] = __builtin_fmaxf(h3[o], 0.f);
+    // max over the nsample lanes of a group
+    if (p.sp_shift >= 1) {
+#pragma unroll
+        for (int o = 0; o < C3; ++o) h3[o] = dpp_max<0xB1>(h3[o]);
+    }
+    if (p.sp_shift >= 2) {
+#pragma unroll
+        for (int o = 0; o < C3; ++o) h3[o] = dpp_max<0x4E>(h3[o]);
+    }
+    if (p.sp_shift >= 3) {
+#pragma unroll
+        for (int o = 0; o < C3; ++o) h3[o] = dpp_max<0x141>(h3[o]);
+    }
+    if (p.sp_shift >= 4) {
+#pragma unroll
+        for (int o = 0; o < C3; ++o) h3[o] = dpp_max<0x140>(h3[o]);
+    }
+    if (p.sp_shift >= 5) {
+#pragma unroll
+        for (int o = 0; o < C3; ++o) {
+            const float u = __shfl_xor(h3[o], 16, 64);
+            h3[o] = u > h3[o] ? u : h3[o];
+        }
+    }
+    if (p.sp_shift >= 6) {
+#pragma unroll
+        for (int o = 0; o < C3; ++o) {
+            const float u = __shfl_xor(h3[o], 32, 64);
+            h3[o] = u > h3[o] ? u : h3[o];
+        }
+    }
+    if ((lane & (Sp - 1)) != 0 || !live) return;
+    float *o = p.out + bm * p.ld_out + p.col_off;
+    if (p.vec_out) {
+#pragma unroll
+        for (int c = 0; c < C3; c += 4) *reinterpret_cast<float4 *>(o + c) = make_float4(h3[c], h3[c + 1], h3[c + 2], h3[c + 3]);
+    } else {
+#pragma unroll
+        for (int c = 0; c < C3; ++c) o[c] = h3[c];
+    }
+}
+
 // ---- weight packing --------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void pack_kernel(const float *__restrict__ Wm,
                                                    const float *__restrict__ bias, int Cin, int Cout,
@@ -388,11 +493,21 @@ __global__ __launch_bounds__(256) void pack_kernel(const float *__restrict__ Wm,
     dst[t] = ok ? Wm[(size_t)oc * Cin + k] : 0.f;
 }
 
+__global__ __launch_bounds__(256) void transpose_kernel(const float *__restrict__ Wm, int Cout, int Cin,
+                                                        float *__restrict__ Wt) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= Cout * Cin) return;
+    const int k = t / Cout, o = t % Cout;
+    Wt[t] = Wm[(size_t)o * Cin + k];
+}
+
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
 struct Geometry {
     int kp[MAXL], np[MAXL];
-    long long off[MAXL];
+    long long off[MAXL];     // packed layer l: bias block then A fragments
+    long long raw_w[MAXL];   // plain row-major copy W[l][C_out][C_in] (for the VALU kernel)
+    long long raw_b[MAXL];
     long long total;
 };
 
@@ -405,6 +520,12 @@ inline Geometry geometry(int L, const int *dims, int first_has_xyz) {
         g.np[l] = round_up(dims[l + 1], 32);
         g.off[l] = off;
         off += (long long)g.np[l] + (long long)g.np[l] * g.kp[l];
+    }
+    for (int l = 0; l < L; ++l) {
+        g.raw_w[l] = off;
+        off += round_up(dims[l] * dims[l + 1], 4);
+        g.raw_b[l] = off;
+        off += round_up(dims[l + 1], 4);
     }
     g.total = off;
     return g;
@@ -448,6 +569,12 @@ SAD_API int sad_mlp_pack_f32(int L, const int *dims, int first_has_xyz, const fl
         hipLaunchKernelGGL(pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
                            (hipStream_t)stream, Wm[l], bias[l], dims[l], dims[l + 1], g.kp[l], g.np[l],
                            (l == 0 && first_has_xyz) ? 1 : 0, packed + g.off[l]);
+        // k-major copy Wt[k][o] (for the VALU kernel: (o, o+1) weight pairs are adjacent)
+        hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)((dims[l] * dims[l + 1] + 255) / 256)), dim3(256), 0,
+                           (hipStream_t)stream, Wm[l], dims[l + 1], dims[l], packed + g.raw_w[l]);
+        if (hipMemcpyAsync(packed + g.raw_b[l], bias[l], sizeof(float) * dims[l + 1],
+                           hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess)
+            return sad::fail(SAD_ELAUNCH, "sad_mlp_pack_f32: device copy of layer %d failed", l);
     }
     return sad::check_launch("sad_mlp_pack_f32");
 }
@@ -498,6 +625,30 @@ SAD_API int sad_mlp_chain_f32(const sad_mlp_args *a, sad_stream_t stream) {
         p.cshift = cs;
     } else {
         p.cpr = 0; p.cshift = 0;
+    }
+    // ---- narrow 3-layer grouped chains run on the vector ALU (geometry 1 forces, >1 forbids) ----
+    {
+        const int gsel = a->geometry ? a->geometry : sad::get_option(sad::OPT_MLP_FORCE);
+        const int *d = a->dims;
+        const bool all_relu = (a->relu_mask & 7) == 7;
+        int shape = 0;
+        if (grouped && a->L == 3 && all_relu && d[0] == 4 && d[1] == 16 && d[2] == 16 && d[3] == 32) shape = 1;
+        if (grouped && a->L == 3 && all_relu && d[0] == 4 && d[1] == 32 && d[2] == 32 && d[3] == 64) shape = 2;
+        if (gsel == 1 && !shape) return sad::fail(SAD_EUNSUPPORTED, "sad_mlp_chain_f32: no VALU kernel for this chain");
+        if (shape && (gsel == 0 || gsel == 1)) {
+            ValuParams v{};
+            v.xyz = a->xyz; v.new_xyz = a->new_xyz; v.feat = a->feat; v.idx = a->idx; v.out = a->out;
+            for (int l = 0; l < 3; ++l) { v.w[l] = a->packed + g.raw_w[l]; v.b[l] = a->packed + g.raw_b[l]; }
+            v.total_rows = p.total_rows; v.ld_feat = a->ld_feat; v.N = a->N; v.M = a->M; v.S = a->S;
+            v.sp_shift = sp_shift; v.ld_out = a->ld_out; v.col_off = a->col_off; v.vec_out = p.vec_out;
+            const long long nb = (p.total_rows + 255) / 256;
+            SAD_REQUIRE(nb < (1LL << 31), "sad_mlp_chain_f32: too many workgroups");
+            if (shape == 1)
+                hipLaunchKernelGGL((mlp_valu_kernel<4, 16, 16, 32>), dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, v);
+            else
+                hipLaunchKernelGGL((mlp_valu_kernel<4, 32, 32, 64>), dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, v);
+            return sad::check_launch("sad_mlp_chain_f32 (valu)");
+        }
     }
     // LDS rows: bufA holds inputs of even layers / outputs of odd layers, bufB the others.  A layer's
     // output only needs the channels the next layer reads (its padded K).
