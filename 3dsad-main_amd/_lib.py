@@ -48,6 +48,10 @@ SIGNATURES = {
     "sad_ball_query_multi_f32": (ctypes.c_int, [vp, vp, ctypes.c_int, c_f32p, vp,
                                                ctypes.POINTER(ctypes.c_int), ctypes.POINTER(vp),
                                                ctypes.c_int, ctypes.c_int, ctypes.c_int, vp]),
+    "sad_ball_query_grid_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int]),
+    "sad_ball_query_grid_f32": (ctypes.c_int, [vp, vp, ctypes.c_int, c_f32p, ctypes.POINTER(ctypes.c_int),
+                                              ctypes.POINTER(vp), ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                              vp, vp]),
     "sad_knn_f32": (ctypes.c_int, [vp, vp] + [ctypes.c_int] * 4 + [vp, vp]),
     "sad_mlp_packed_floats": (ctypes.c_size_t, [ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.c_int]),
     "sad_mlp_pack_f32": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.c_int,

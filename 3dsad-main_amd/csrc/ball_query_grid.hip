@@ -1,0 +1,310 @@
+// Grid-pruned ball query for gfx950 (SPEC.md §3): same answers as the sequential scan, but each
+// centroid only tests the points of the 27 grid cells around it.  No reference source exists
+// (/root/reference/README.md:1-2).
+//
+// Why: the brute-force kernel performs N*M pair tests (201 M per 16 384-point scene at SA1) for
+// 0.77 MB of compulsory bytes per radius — ~87 tests per byte, VALU-bound at <1 % of the HBM
+// roofline.  A uniform grid with cell edge > r_max cuts the tests by ~100x.
+//
+// How index order survives pruning: candidates arrive in cell order, not index order, so accepted
+// indices are not appended — they set one bit each in a per-wave LDS bitmap (N bits per radius).
+// Scanning the bitmap in ascending bit order with a wave-wide popcount prefix yields the first
+// `nsample` accepted indices in ascending index order, exactly what SPEC.md §3's scan produces.
+//
+// Exactness: the accept test is the same sad::d2f(point, centroid) < r*r.  Pruning is conservative:
+// cell = floor((x - x0) * inv) is a monotone function of x in binary32, the cell edge is r_max *
+// 1.001 (or larger), so a point within r_max of the centroid lies at most one cell away per axis.
+#include "common.h"
+
+namespace {
+
+constexpr int GRID_MAXC = 16384;   // cells per scene (LDS histogram: 64 KB)
+constexpr int BUILD_T = 1024;
+
+struct GridHdr {      // 16 floats / ints at the start of each scene's workspace block
+    float x0, y0, z0, inv;
+    int gx, gy, gz, ncell;
+    int pad[8];
+};
+
+__host__ __device__ inline size_t scene_ws_bytes(int N) {
+    return sizeof(GridHdr) + sizeof(int) * (size_t)(GRID_MAXC + 16) + sizeof(float4) * (size_t)N;
+}
+
+__device__ __forceinline__ int cell_coord(float x, float x0, float inv, int g) {
+    float t = (x - x0) * inv;
+    t = t < -2.f ? -2.f : t;
+    const float hi = (float)(g + 1);
+    t = t > hi ? hi : t;
+    return (int)floorf(t);
+}
+
+// ---- build: bounding box, cell histogram, exclusive scan, scatter of (x,y,z,idx) records ---------
+__global__ __launch_bounds__(BUILD_T) void grid_build_kernel(const float *__restrict__ xyz, int N,
+                                                             float cs_min, char *__restrict__ ws) {
+    extern __shared__ int hist[];               // GRID_MAXC + 64 ints
+    __shared__ float red[6][16];
+    __shared__ int wsum[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float *p = xyz + (size_t)blockIdx.x * N * 3;
+    char *base = ws + (size_t)blockIdx.x * scene_ws_bytes(N);
+    GridHdr *hdr = reinterpret_cast<GridHdr *>(base);
+    int *cell_start = reinterpret_cast<int *>(base + sizeof(GridHdr));
+    float4 *rec = reinterpret_cast<float4 *>(base + sizeof(GridHdr) + sizeof(int) * (size_t)(GRID_MAXC + 16));
+
+    // 1. bounding box
+    float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+    for (int j = tid; j < N; j += BUILD_T)
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const float v = p[j * 3 + d];
+            lo[d] = v < lo[d] ? v : lo[d];
+            hi[d] = v > hi[d] ? v : hi[d];
+        }
+#pragma unroll
+    for (int d = 0; d < 3; ++d)
+        for (int off = 32; off >= 1; off >>= 1) {
+            const float a = __shfl_xor(lo[d], off, 64), b = __shfl_xor(hi[d], off, 64);
+            lo[d] = a < lo[d] ? a : lo[d];
+            hi[d] = b > hi[d] ? b : hi[d];
+        }
+    if (lane == 0)
+#pragma unroll
+        for (int d = 0; d < 3; ++d) { red[d][wave] = lo[d]; red[3 + d][wave] = hi[d]; }
+    for (int c = tid; c < GRID_MAXC + 64; c += BUILD_T) hist[c] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int d = 0; d < 3; ++d)
+        for (int w = 0; w < 16; ++w) {
+            lo[d] = red[d][w] < lo[d] ? red[d][w] : lo[d];
+            hi[d] = red[3 + d][w] > hi[d] ? red[3 + d][w] : hi[d];
+        }
+    // 2. grid geometry (identical in every thread): double the cell edge until the grid fits
+    float cs = cs_min;
+    int gx, gy, gz;
+    for (;;) {
+        const float inv = 1.0f / cs;
+        gx = (int)((hi[0] - lo[0]) * inv) + 1;
+        gy = (int)((hi[1] - lo[1]) * inv) + 1;
+        gz = (int)((hi[2] - lo[2]) * inv) + 1;
+        if ((long long)gx * gy * gz <= GRID_MAXC) break;
+        cs = cs * 2.0f;
+    }
+    const float inv = 1.0f / cs;
+    const int ncell = gx * gy * gz;
+    if (tid == 0) {
+        hdr->x0 = lo[0]; hdr->y0 = lo[1]; hdr->z0 = lo[2]; hdr->inv = inv;
+        hdr->gx = gx; hdr->gy = gy; hdr->gz = gz; hdr->ncell = ncell;
+    }
+    // 3. histogram
+    auto cell_of = [&](float x, float y, float z) {
+        int ix = cell_coord(x, lo[0], inv, gx), iy = cell_coord(y, lo[1], inv, gy), iz = cell_coord(z, lo[2], inv, gz);
+        ix = ix < 0 ? 0 : (ix > gx - 1 ? gx - 1 : ix);
+        iy = iy < 0 ? 0 : (iy > gy - 1 ? gy - 1 : iy);
+        iz = iz < 0 ? 0 : (iz > gz - 1 ? gz - 1 : iz);
+        return (iz * gy + iy) * gx + ix;
+    };
+    for (int j = tid; j < N; j += BUILD_T) atomicAdd(&hist[cell_of(p[j * 3], p[j * 3 + 1], p[j * 3 + 2])], 1);
+    __syncthreads();
+    // 4. exclusive scan over the cells: thread t owns cells [t*CPT, (t+1)*CPT)
+    constexpr int CPT = GRID_MAXC / BUILD_T;   // 16
+    int loc[CPT];
+    int sum = 0;
+#pragma unroll
+    for (int k = 0; k < CPT; ++k) {
+        loc[k] = sum;
+        sum += hist[tid * CPT + k];
+    }
+    int incl = sum;                             // inclusive scan of `sum` over the wave
+    for (int off = 1; off < 64; off <<= 1) {
+        const int v = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += v;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    int wbase = 0;
+    for (int w = 0; w < wave; ++w) wbase += wsum[w];
+    const int tbase = wbase + incl - sum;
+#pragma unroll
+    for (int k = 0; k < CPT; ++k) {
+        const int c = tid * CPT + k;
+        const int s = tbase + loc[k];
+        hist[c] = s;                            // becomes the running write offset of the cell
+        cell_start[c] = s;                      // cells >= ncell are empty: start = N
+    }
+    if (tid == BUILD_T - 1) cell_start[GRID_MAXC] = tbase + sum;   // = N
+    __syncthreads();
+    // 5. scatter records (order inside a cell is irrelevant: the query restores index order)
+    for (int j = tid; j < N; j += BUILD_T) {
+        const float x = p[j * 3], y = p[j * 3 + 1], z = p[j * 3 + 2];
+        const int pos = atomicAdd(&hist[cell_of(x, y, z)], 1);
+        rec[pos] = make_float4(x, y, z, __int_as_float(j));
+    }
+}
+
+// ---- query -------------------------------------------------------------------------------------
+struct GQParams {
+    float radii[SAD_MAX_RADII];
+    int nsample[SAD_MAX_RADII];
+    int32_t *idx[SAD_MAX_RADII];
+};
+
+constexpr int GQ_WAVES = 4;
+constexpr int GQ_CPW = 4;     // centroids per wave, processed one after the other
+
+template <int NR>
+__global__ __launch_bounds__(GQ_WAVES * 64) void grid_query_kernel(const float *__restrict__ new_xyz,
+                                                                   const char *__restrict__ ws,
+                                                                   GQParams prm, int N, int M) {
+    extern __shared__ unsigned bm_all[];        // GQ_WAVES * NR * NWP words, zero between centroids
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int b = blockIdx.y;
+    const int NW = (N + 31) >> 5;               // bitmap words
+    const int WPL = (NW + 63) >> 6;             // words per lane in the scan
+    const int NWP = WPL * 64;                   // padded words per bitmap
+    unsigned *bm = bm_all + (size_t)wave * NR * NWP;
+    const char *base = ws + (size_t)b * scene_ws_bytes(N);
+    const GridHdr *hdr = reinterpret_cast<const GridHdr *>(base);
+    const int *cell_start = reinterpret_cast<const int *>(base + sizeof(GridHdr));
+    const float4 *rec = reinterpret_cast<const float4 *>(base + sizeof(GridHdr) + sizeof(int) * (size_t)(GRID_MAXC + 16));
+    const float x0 = hdr->x0, y0 = hdr->y0, z0 = hdr->z0, inv = hdr->inv;
+    const int gx = hdr->gx, gy = hdr->gy, gz = hdr->gz;
+
+    for (int w = lane; w < NR * NWP; w += 64) bm[w] = 0u;
+
+    for (int cc = 0; cc < GQ_CPW; ++cc) {
+        const int m = (blockIdx.x * GQ_WAVES + wave) * GQ_CPW + cc;
+        if (m >= M) break;                      // wave-uniform
+        const float *q = new_xyz + ((size_t)b * M + m) * 3;
+        const float cx = q[0], cy = q[1], cz = q[2];
+        float r2[NR];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) r2[r] = prm.radii[r] * prm.radii[r];
+        const int ix = cell_coord(cx, x0, inv, gx), iy = cell_coord(cy, y0, inv, gy), iz = cell_coord(cz, z0, inv, gz);
+        // nine runs of up to three x-adjacent cells (contiguous in the record array): lane l < 9
+        int rs = 0, rl = 0;
+        {
+            const int dy = lane % 3 - 1, dz = (lane / 3) % 3 - 1;
+            const int yy = iy + dy, zz = iz + dz;
+            const int xlo = ix - 1 < 0 ? 0 : ix - 1, xhi = ix + 1 > gx - 1 ? gx - 1 : ix + 1;
+            if (lane < 9 && yy >= 0 && yy < gy && zz >= 0 && zz < gz && xlo <= xhi) {
+                const int c0 = (zz * gy + yy) * gx;
+                rs = cell_start[c0 + xlo];
+                rl = cell_start[c0 + xhi + 1] - rs;
+            }
+        }
+        int rstart[9], roff[10];
+        roff[0] = 0;
+#pragma unroll
+        for (int r = 0; r < 9; ++r) {
+            rstart[r] = __builtin_amdgcn_readlane(rs, r);
+            roff[r + 1] = roff[r] + __builtin_amdgcn_readlane(rl, r);
+        }
+        const int T = roff[9];
+        for (int i0 = 0; i0 < T; i0 += 64) {
+            const int i = i0 + lane;
+            const bool valid = i < T;
+            int src = rstart[0] + i;
+#pragma unroll
+            for (int r = 1; r < 9; ++r) src = i >= roff[r] ? rstart[r] + (i - roff[r]) : src;
+            const float4 pr = rec[valid ? src : 0];
+            const float d = sad::d2f(pr.x, pr.y, pr.z, cx, cy, cz);
+            const unsigned j = (unsigned)__float_as_int(pr.w);
+#pragma unroll
+            for (int r = 0; r < NR; ++r)
+                if (valid && d < r2[r]) atomicOr(&bm[r * NWP + (j >> 5)], 1u << (j & 31));
+        }
+        // scan each bitmap in ascending bit order; a lane owns WPL consecutive words
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const int S = prm.nsample[r];
+            int32_t *out = prm.idx[r] + ((size_t)b * M + m) * S;
+            unsigned *bw = bm + r * NWP + lane * WPL;
+            int cnt = 0;
+            for (int k = 0; k < WPL; ++k) cnt += __builtin_popcount(bw[k]);
+            int incl = cnt;
+            for (int off = 1; off < 64; off <<= 1) {
+                const int v = __shfl_up(incl, off, 64);
+                if (lane >= off) incl += v;
+            }
+            int slot = incl - cnt;                              // exclusive prefix
+            const int total = __builtin_amdgcn_readlane(incl, 63);
+            int myfirst = 0;
+            if (cnt) {
+                for (int k = 0; k < WPL; ++k) {
+                    unsigned wd = bw[k];
+                    if (!wd) continue;
+                    bw[k] = 0u;                                 // leave the bitmap clean
+                    const int wbase = (lane * WPL + k) << 5;
+                    if (slot == 0 && !myfirst) myfirst = wbase + __builtin_ctz(wd);
+                    while (wd && slot < S) {
+                        const int bit = __builtin_ctz(wd);
+                        wd &= wd - 1;
+                        out[slot++] = wbase + bit;
+                    }
+                    slot += __builtin_popcount(wd);             // bits beyond nsample
+                }
+            }
+            // SPEC.md §3 padding: the remaining slots repeat the first (lowest) accepted index
+            const unsigned long long has = __ballot(cnt != 0);
+            int first = 0;
+            if (has) first = __builtin_amdgcn_readlane(myfirst, __builtin_ctzll(has));
+            for (int s = (total < S ? total : S) + lane; s < S; s += 64) out[s] = first;
+        }
+    }
+}
+
+template <int NR>
+void launch_query(const float *new_xyz, const char *ws, const GQParams &prm, int B, int N, int M,
+                  hipStream_t st) {
+    const int NW = (N + 31) >> 5, WPL = (NW + 63) >> 6;
+    const size_t lds = sizeof(unsigned) * (size_t)GQ_WAVES * NR * WPL * 64;
+    dim3 grid((M + GQ_WAVES * GQ_CPW - 1) / (GQ_WAVES * GQ_CPW), B);
+    hipLaunchKernelGGL((grid_query_kernel<NR>), grid, dim3(GQ_WAVES * 64), lds, st, new_xyz, ws, prm, N, M);
+}
+
+}  // namespace
+
+SAD_API size_t sad_ball_query_grid_workspace_bytes(int B, int N) {
+    if (B < 1 || N < 1) return 0;
+    return (size_t)B * scene_ws_bytes(N);
+}
+
+SAD_API int sad_ball_query_grid_f32(const float *xyz, const float *new_xyz, int n_radii,
+                                    const float *radii, const int *nsamples, int32_t *const *idx,
+                                    int B, int N, int M, void *workspace, sad_stream_t stream) {
+    SAD_REQUIRE(xyz && new_xyz && radii && nsamples && idx && workspace, "sad_ball_query_grid_f32: NULL pointer");
+    SAD_REQUIRE(B >= 1 && B <= 65535 && N >= 1 && M >= 1, "sad_ball_query_grid_f32: need B,N,M >= 1");
+    SAD_REQUIRE(n_radii >= 1 && n_radii <= SAD_MAX_RADII, "sad_ball_query_grid_f32: n_radii=%d not in 1..%d", n_radii, SAD_MAX_RADII);
+    SAD_REQUIRE(N <= 65536, "sad_ball_query_grid_f32: N=%d > 65536 (bitmap would not fit LDS)", N);
+    SAD_REQUIRE((uintptr_t)workspace % 16 == 0, "sad_ball_query_grid_f32: workspace must be 16-byte aligned");
+    GQParams prm{};
+    float rmax = 0.f;
+    for (int r = 0; r < n_radii; ++r) {
+        SAD_REQUIRE(nsamples[r] >= 1 && nsamples[r] <= 64 && idx[r], "sad_ball_query_grid_f32: bad nsample/idx");
+        SAD_REQUIRE(radii[r] > 0.f, "sad_ball_query_grid_f32: radius must be > 0");
+        prm.radii[r] = radii[r];
+        prm.nsample[r] = nsamples[r];
+        prm.idx[r] = idx[r];
+        rmax = radii[r] > rmax ? radii[r] : rmax;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&grid_build_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(grid_build_kernel, dim3(B), dim3(BUILD_T), sizeof(int) * (GRID_MAXC + 64), st, xyz, N,
+                       rmax * 1.001f, (char *)workspace);
+    if (int e = sad::check_launch("sad_ball_query_grid_f32 (build)")) return e;
+    const char *ws = (const char *)workspace;
+    switch (n_radii) {
+        case 1: launch_query<1>(new_xyz, ws, prm, B, N, M, st); break;
+        case 2: launch_query<2>(new_xyz, ws, prm, B, N, M, st); break;
+        case 3: launch_query<3>(new_xyz, ws, prm, B, N, M, st); break;
+        default: launch_query<4>(new_xyz, ws, prm, B, N, M, st); break;
+    }
+    return sad::check_launch("sad_ball_query_grid_f32 (query)");
+}

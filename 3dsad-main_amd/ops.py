@@ -28,6 +28,10 @@ def _stream() -> int:
 # (kind, name, start_event, end_event).  None (the default) adds nothing to the launch path.
 LAUNCH_LOG: Optional[list] = None
 
+# ball_query_multi uses the grid-pruned kernel for scenes with at least this many points (scalar
+# radii only); below it the brute-force scan is already cheap.  Set very large to force brute force.
+GRID_MIN_POINTS: int = 2048
+
 # When True, PackedMLP measures the workgroup geometries of mlp_chain_kernel on the first call for
 # each shape and keeps the fastest (SADDetector.autotune() switches it on for one forward pass).
 AUTOTUNE: bool = False
@@ -172,6 +176,14 @@ def ball_query_multi(radii: Sequence[float], nsamples: Sequence[int], xyz: torch
         if tuple(radius_pc.shape) != (B, M):
             raise ValueError(f"radius_pc must be [B,M]=({B},{M})")
         pc = radius_pc.data_ptr()
+    if pc is None and N >= GRID_MIN_POINTS and N <= 65536 and min(radii) > 0:
+        # grid-pruned kernel: same indices, ~100x fewer pair tests (csrc/ball_query_grid.hip)
+        ws = torch.empty((lib().sad_ball_query_grid_workspace_bytes(B, N),), dtype=torch.uint8,
+                         device=xyz.device)
+        with _timed("ball_query", f"N{N}M{M}x{n}"):
+            check(lib().sad_ball_query_grid_f32(xyz.data_ptr(), new_xyz.data_ptr(), n, r_arr, s_arr, p_arr,
+                                                B, N, M, ws.data_ptr(), _stream()), "sad_ball_query_grid_f32")
+        return outs
     with _timed("ball_query", f"N{N}M{M}x{n}"):
         check(lib().sad_ball_query_multi_f32(xyz.data_ptr(), new_xyz.data_ptr(), n, r_arr, pc, s_arr,
                                              p_arr, B, N, M, _stream()), "sad_ball_query_multi_f32")

@@ -74,6 +74,15 @@ int sad_ball_query_multi_f32(const float *xyz, const float *new_xyz, int n_radii
                              const float *radii, const float *radius_pc, const int *nsamples,
                              int32_t *const *idx, int B, int N, int M, sad_stream_t stream);
 
+/* Same results as sad_ball_query_multi_f32 with scalar radii, computed through a per-scene uniform
+ * grid (cell edge > max radius): each centroid tests only the 27 cells around it and index order is
+ * restored through an LDS bitmap.  Needs sad_ball_query_grid_workspace_bytes(B,N) bytes of 16-byte
+ * aligned device workspace (rebuilt on every call); N <= 65536. */
+size_t sad_ball_query_grid_workspace_bytes(int B, int N);
+int sad_ball_query_grid_f32(const float *xyz, const float *new_xyz, int n_radii, const float *radii,
+                            const int *nsamples, int32_t *const *idx, int B, int N, int M,
+                            void *workspace, sad_stream_t stream);
+
 /* SPEC.md §4.  -> idx[B,M,K] sorted by (d2, index); K <= 64, K <= N. */
 int sad_knn_f32(const float *xyz, const float *new_xyz, int B, int N, int M, int K, int32_t *idx,
                 sad_stream_t stream);

@@ -57,7 +57,8 @@ def test_host_side_argument_errors(sad):
     n = L.sad_mlp_packed_floats(3, dims, 1)
     kp = [264, 256, 512]
     npad = [256, 512, 1024]
-    assert n == sum(a + a * k for a, k in zip(npad, kp))
+    raw = sum(-(-ci * co // 4) * 4 + -(-co // 4) * 4 for ci, co in zip((259, 256, 512), (256, 512, 1024)))
+    assert n == sum(a + a * k for a, k in zip(npad, kp)) + raw   # MFMA fragments + plain k-major copy
 
 
 def test_ops_refuse_cpu_tensors(sad):

@@ -100,6 +100,49 @@ def test_ball_query_parity(orc, sad, dev, B, N, M, r, S):
     np.testing.assert_array_equal(got, orc.ball_query(r, S, xyz, new_xyz))
 
 
+@pytest.mark.parametrize("B,N,M,radii,ns", [
+    (2, 4096, 1024, (0.05, 0.1, 0.2), (32, 32, 64)),     # unit cube: 3-D grid, dense cells
+    (2, 3000, 300, (0.3,), (16,)),                       # one radius, N not a multiple of 32
+    (1, 2048, 2048, (0.02, 0.5), (8, 64)),               # tiny and huge ball (grid doubles its cells)
+    (2, 16384, 512, (0.2, 0.4, 0.8, 1.2), (32, 32, 64, 48)),   # four radii
+])
+def test_ball_query_grid_vs_oracle(orc, sad, dev, B, N, M, radii, ns):
+    """The grid-pruned kernel (LDS bitmap restores index order) returns the oracle's indices."""
+    from sad_amd import ops
+    if N == 16384:
+        from sad_amd import synth
+        xyz = np.ascontiguousarray(synth.make_batch(7, B)[:, :, :3])
+    else:
+        xyz = _rand_xyz(500 + N, B, N)
+    new_xyz = np.ascontiguousarray(xyz[:, ::max(1, N // M)][:, :M])
+    new_xyz[:, 0] += 100.0            # a centroid far outside the grid: empty balls
+    assert N >= ops.GRID_MIN_POINTS
+    outs = ops.ball_query_multi(radii, ns, _t(xyz, dev), _t(new_xyz, dev))
+    for o, r, s in zip(outs, radii, ns):
+        np.testing.assert_array_equal(o.cpu().numpy(), orc.ball_query(r, s, xyz, new_xyz))
+    # and the brute-force kernel agrees with the grid kernel
+    old, ops.GRID_MIN_POINTS = ops.GRID_MIN_POINTS, 1 << 30
+    try:
+        outs2 = ops.ball_query_multi(radii, ns, _t(xyz, dev), _t(new_xyz, dev))
+    finally:
+        ops.GRID_MIN_POINTS = old
+    for a, b2 in zip(outs, outs2):
+        assert bool((a == b2).all())
+
+
+def test_ball_query_grid_duplicates_and_plane(orc, sad, dev):
+    """Degenerate geometry: all points in one plane / many duplicates / a single cell."""
+    from sad_amd import ops
+    rng = np.random.default_rng(3)
+    xyz = rng.uniform(0, 10, (1, 4096, 3)).astype(np.float32)
+    xyz[:, :, 2] = 1.5                       # flat: gz = 1
+    xyz[0, 100:300] = xyz[0, 50]             # 200 duplicates of one point
+    new_xyz = np.ascontiguousarray(xyz[:, :256])
+    for r, s in ((0.3, 16), (25.0, 64)):     # 25.0: every point in every ball, grid = one cell
+        got = ops.ball_query_multi((r,), (s,), _t(xyz, dev), _t(new_xyz, dev))[0].cpu().numpy()
+        np.testing.assert_array_equal(got, orc.ball_query(r, s, xyz, new_xyz))
+
+
 def test_ball_query_adaptive_and_multi(orc, sad, dev):
     from sad_amd import ops, synth
     g = np.load(os.path.join(GOLDEN, "adaptive.npz"))
