@@ -289,8 +289,10 @@ void launch_reg(const float *xyz, int B, int N, int M, int *idx, hipStream_t st,
 
 }  // namespace
 
+// N > 16384: min-distance array of the global-workspace kernel; 2048 <= N <= 16384: the Z-order
+// permutation of the bucketed kernel (optional: without it the plain register kernel runs).
 SAD_API size_t sad_fps_workspace_bytes(int B, int N) {
-    if (B <= 0 || N <= 16384) return 0;
+    if (B <= 0 || N < 2048) return 0;
     return (size_t)B * (size_t)N * sizeof(float);
 }
 
@@ -306,6 +308,9 @@ SAD_API int sad_fps_f32(const float *xyz, int B, int N, int M, int32_t *idx, voi
         hipLaunchKernelGGL(fps_big_kernel, dim3(B), dim3(1024), 0, st, xyz, N, M, (float *)workspace, idx);
         return sad::check_launch("sad_fps_f32");
     }
+    const int variant = sad::get_option(sad::OPT_FPS_VARIANT);   // 0 auto, 1 pair, 2 key, 3 bucket
+    if (workspace && N >= 2048 && (variant == 0 || variant == 3))
+        return sad::launch_fps_bucket(xyz, B, N, M, idx, workspace, st);
     if (N <= 2048) {
         const int ppt = (N + 255) / 256;
         if (ppt <= 1) launch_reg<256, 1>(xyz, B, N, M, idx, st, dpp);

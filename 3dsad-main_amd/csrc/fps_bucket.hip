@@ -1,0 +1,287 @@
+// Bucketed farthest point sampling for gfx950 (SPEC.md §2): the same indices as the plain scan,
+// with most of the per-step distance updates skipped.  No reference source exists
+// (/root/reference/README.md:1-2).
+//
+// Idea (exact, not approximate).  Points are first binned into Z-order grid cells so that each
+// thread owns PPT spatially coherent points and each wave a compact region.  A sampling step with
+// new centre c changes min_dist[p] only if d2(p,c) < min_dist[p].  For a box B containing the
+// points of a thread (or wave), q = clamp(c, B) is the closest point of the box, and in binary32 the
+// SPEC §1 expression is monotone in each |coordinate difference|, so d2f(q,c) <= d2f(p,c) for every
+// p in B.  Hence if d2f(q,c) >= max_{p in B} min_dist[p], nothing in B changes and its cached
+// (max distance, index) key is still valid.  After a few hundred samples almost every wave is
+// skipped on every step, and what remains per step is the serial chain: publish key -> barrier ->
+// 16-key arg-max -> read the winner's coordinates from LDS.
+#include "common.h"
+
+namespace {
+
+typedef unsigned long long u64;
+constexpr int SORT_T = 1024;
+constexpr int SORT_CELLS = 16384;   // 32 x 32 (Z-order) x 16
+
+__device__ __forceinline__ int morton_cell(int ix, int iy, int iz) {
+    int m = 0;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) m |= (((ix >> i) & 1) << (2 * i)) | (((iy >> i) & 1) << (2 * i + 1));
+    return (m << 4) | iz;
+}
+
+// One workgroup per scene: perm[pos] = original index of the pos-th point in Z-order cell order.
+__global__ __launch_bounds__(SORT_T) void fps_sort_kernel(const float *__restrict__ xyz, int N,
+                                                          int *__restrict__ perm_out) {
+    extern __shared__ int hist[];               // SORT_CELLS ints
+    __shared__ float red[6][16];
+    __shared__ int wsum[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float *p = xyz + (size_t)blockIdx.x * N * 3;
+    int *perm = perm_out + (size_t)blockIdx.x * N;
+    float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+    for (int j = tid; j < N; j += SORT_T)
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const float v = p[j * 3 + d];
+            lo[d] = v < lo[d] ? v : lo[d];
+            hi[d] = v > hi[d] ? v : hi[d];
+        }
+#pragma unroll
+    for (int d = 0; d < 3; ++d)
+        for (int off = 32; off >= 1; off >>= 1) {
+            const float a = __shfl_xor(lo[d], off, 64), b = __shfl_xor(hi[d], off, 64);
+            lo[d] = a < lo[d] ? a : lo[d];
+            hi[d] = b > hi[d] ? b : hi[d];
+        }
+    if (lane == 0)
+#pragma unroll
+        for (int d = 0; d < 3; ++d) { red[d][wave] = lo[d]; red[3 + d][wave] = hi[d]; }
+    for (int c = tid; c < SORT_CELLS; c += SORT_T) hist[c] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int d = 0; d < 3; ++d)
+        for (int w = 0; w < 16; ++w) {
+            lo[d] = red[d][w] < lo[d] ? red[d][w] : lo[d];
+            hi[d] = red[3 + d][w] > hi[d] ? red[3 + d][w] : hi[d];
+        }
+    const float ex = hi[0] - lo[0], ey = hi[1] - lo[1], ez = hi[2] - lo[2];
+    const float sx = ex > 0.f ? 32.0f / ex : 0.f, sy = ey > 0.f ? 32.0f / ey : 0.f, sz = ez > 0.f ? 16.0f / ez : 0.f;
+    auto cell_of = [&](int j) {
+        int ix = (int)((p[j * 3 + 0] - lo[0]) * sx), iy = (int)((p[j * 3 + 1] - lo[1]) * sy), iz = (int)((p[j * 3 + 2] - lo[2]) * sz);
+        ix = ix < 0 ? 0 : (ix > 31 ? 31 : ix);
+        iy = iy < 0 ? 0 : (iy > 31 ? 31 : iy);
+        iz = iz < 0 ? 0 : (iz > 15 ? 15 : iz);
+        return morton_cell(ix, iy, iz);
+    };
+    for (int j = tid; j < N; j += SORT_T) atomicAdd(&hist[cell_of(j)], 1);
+    __syncthreads();
+    constexpr int CPT = SORT_CELLS / SORT_T;    // 16 cells per thread
+    int loc[CPT];
+    int sum = 0;
+#pragma unroll
+    for (int k = 0; k < CPT; ++k) {
+        loc[k] = sum;
+        sum += hist[tid * CPT + k];
+    }
+    int incl = sum;
+    for (int off = 1; off < 64; off <<= 1) {
+        const int v = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += v;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    int wbase = 0;
+    for (int w = 0; w < wave; ++w) wbase += wsum[w];
+    const int tbase = wbase + incl - sum;
+#pragma unroll
+    for (int k = 0; k < CPT; ++k) hist[tid * CPT + k] = tbase + loc[k];
+    __syncthreads();
+    for (int j = tid; j < N; j += SORT_T) perm[atomicAdd(&hist[cell_of(j)], 1)] = j;
+}
+
+template <int CTRL>
+__device__ __forceinline__ u64 dpp_u64(u64 v) {
+    const unsigned lo = __builtin_amdgcn_update_dpp(0u, (unsigned)v, CTRL, 0xF, 0xF, false);
+    const unsigned hi = __builtin_amdgcn_update_dpp(0u, (unsigned)(v >> 32), CTRL, 0xF, 0xF, false);
+    return ((u64)hi << 32) | lo;
+}
+__device__ __forceinline__ u64 umax64(u64 a, u64 b) { return a > b ? a : b; }
+__device__ __forceinline__ u64 row_max_u64(u64 k) {
+    k = umax64(k, dpp_u64<0xB1>(k));
+    k = umax64(k, dpp_u64<0x4E>(k));
+    k = umax64(k, dpp_u64<0x141>(k));
+    k = umax64(k, dpp_u64<0x140>(k));
+    return k;
+}
+__device__ __forceinline__ u64 readlane_u64(u64 v, int l) {
+    const unsigned lo = __builtin_amdgcn_readlane((unsigned)v, l);
+    const unsigned hi = __builtin_amdgcn_readlane((unsigned)(v >> 32), l);
+    return ((u64)hi << 32) | lo;
+}
+__device__ __forceinline__ u64 wave_max_u64(u64 k) {
+    k = row_max_u64(k);
+    return umax64(umax64(readlane_u64(k, 0), readlane_u64(k, 16)), umax64(readlane_u64(k, 32), readlane_u64(k, 48)));
+}
+__device__ __forceinline__ float clampf(float v, float lo, float hi) {
+    v = v < lo ? lo : v;
+    return v > hi ? hi : v;
+}
+__device__ __forceinline__ float rdl_f(float v, int l) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+}
+
+template <int THREADS, int PPT>
+__global__ __launch_bounds__(THREADS) void fps_bucket_kernel(const float *__restrict__ xyz,
+                                                             const int *__restrict__ perm_in, int N,
+                                                             int M, int *__restrict__ idx_out) {
+    constexpr int NW = THREADS / 64;
+    typedef float fvec __attribute__((ext_vector_type(PPT)));
+    typedef int ivec __attribute__((ext_vector_type(PPT)));
+    __shared__ u64 s_key[2][16];
+    __shared__ float s_xyz[2][16][4];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const float *p = xyz + (size_t)blockIdx.x * N * 3;
+    const int *perm = perm_in + (size_t)blockIdx.x * N;
+    int *out = idx_out + (size_t)blockIdx.x * M;
+
+    fvec px, py, pz, md;
+    ivec oi;
+    float tlo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, thi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+        const int pos = tid * PPT + k;
+        if (pos < N) {
+            const int j = perm[pos];
+            px[k] = p[j * 3 + 0];
+            py[k] = p[j * 3 + 1];
+            pz[k] = p[j * 3 + 2];
+            md[k] = __builtin_inff();
+            oi[k] = j;
+            tlo[0] = px[k] < tlo[0] ? px[k] : tlo[0]; thi[0] = px[k] > thi[0] ? px[k] : thi[0];
+            tlo[1] = py[k] < tlo[1] ? py[k] : tlo[1]; thi[1] = py[k] > thi[1] ? py[k] : thi[1];
+            tlo[2] = pz[k] < tlo[2] ? pz[k] : tlo[2]; thi[2] = pz[k] > thi[2] ? pz[k] : thi[2];
+        } else {  // padding: distance 0 and the largest index never beat a real point
+            px[k] = py[k] = pz[k] = 0.f;
+            md[k] = 0.f;
+            oi[k] = 0x7fffffff;
+        }
+    }
+    // per-thread cache: largest min-distance, its slot and key (ties -> lowest original index)
+    float tmax;
+    int tbk;
+    u64 tkey;
+    auto thread_best = [&]() {
+        float bd = md[0];
+        int bk = 0, bo = oi[0];
+#pragma unroll
+        for (int k = 1; k < PPT; ++k) {
+            const bool t = md[k] > bd || (md[k] == bd && oi[k] < bo);
+            bd = t ? md[k] : bd;
+            bo = t ? oi[k] : bo;
+            bk = t ? k : bk;
+        }
+        tmax = bd;
+        tbk = bk;
+        tkey = ((u64)__builtin_bit_cast(unsigned, bd) << 32) | (unsigned)(~(unsigned)bo);
+    };
+    thread_best();
+    // wave bounding box (fixed) and wave cache: key + coordinates of the wave's best point
+    float wlo[3], whi[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        float a = tlo[d], b = thi[d];
+        for (int off = 32; off >= 1; off >>= 1) {
+            const float a2 = __shfl_xor(a, off, 64), b2 = __shfl_xor(b, off, 64);
+            a = a2 < a ? a2 : a;
+            b = b2 > b ? b2 : b;
+        }
+        wlo[d] = rdl_f(a, 0);
+        whi[d] = rdl_f(b, 0);
+    }
+    u64 wkey;
+    float wx, wy, wz, wmaxf;
+    auto wave_best = [&]() {
+        wkey = wave_max_u64(tkey);
+        const unsigned long long own = __ballot(tkey == wkey);     // exactly one lane (indices are unique)
+        const int ol = __builtin_ctzll(own);
+        const int kk = __builtin_amdgcn_readlane(tbk, ol);
+        wx = rdl_f(px[kk], ol);
+        wy = rdl_f(py[kk], ol);
+        wz = rdl_f(pz[kk], ol);
+        wmaxf = __builtin_bit_cast(float, (unsigned)(wkey >> 32));
+    };
+    wave_best();
+
+    if (tid == 0) out[0] = 0;
+    float cx = p[0], cy = p[1], cz = p[2];
+    for (int i = 1; i < M; ++i) {
+        // wave-level skip test (wave-uniform values)
+        const float dqw = sad::d2f(clampf(cx, wlo[0], whi[0]), clampf(cy, wlo[1], whi[1]), clampf(cz, wlo[2], whi[2]), cx, cy, cz);
+        if (dqw < wmaxf) {
+            const float dqt = sad::d2f(clampf(cx, tlo[0], thi[0]), clampf(cy, tlo[1], thi[1]), clampf(cz, tlo[2], thi[2]), cx, cy, cz);
+            if (__any(dqt < tmax)) {
+                const fvec dx = px - cx, dy = py - cy, dz = pz - cz;
+                const fvec d = (dx * dx + dy * dy) + dz * dz;   // SPEC.md §1 order, no contraction
+                md = __builtin_elementwise_min(md, d);
+                thread_best();
+                wave_best();
+            }
+        }
+        const int buf = i & 1;
+        if (lane == 0) {
+            s_key[buf][wave] = wkey;
+            s_xyz[buf][wave][0] = wx;
+            s_xyz[buf][wave][1] = wy;
+            s_xyz[buf][wave][2] = wz;
+        }
+        __syncthreads();
+        const u64 mine = s_key[buf][lane & (NW - 1)];
+        u64 g = mine;
+        if constexpr (NW == 16) {
+            g = row_max_u64(g);
+        } else {
+            g = umax64(g, dpp_u64<0xB1>(g));
+            g = umax64(g, dpp_u64<0x4E>(g));
+        }
+        const u64 gk = readlane_u64(g, 0);
+        const int slot = __builtin_ctzll(__ballot(mine == gk)) & (NW - 1);
+        cx = rdl_f(s_xyz[buf][slot][0], 0);   // wave-uniform: keeps the skip tests on the scalar branch path
+        cy = rdl_f(s_xyz[buf][slot][1], 0);
+        cz = rdl_f(s_xyz[buf][slot][2], 0);
+        if (tid == 0) out[i] = (int)(~(unsigned)gk);
+    }
+}
+
+template <int THREADS, int PPT>
+void launch_bucket(const float *xyz, const int *perm, int B, int N, int M, int *idx, hipStream_t st) {
+    hipLaunchKernelGGL((fps_bucket_kernel<THREADS, PPT>), dim3(B), dim3(THREADS), 0, st, xyz, perm, N, M, idx);
+}
+
+}  // namespace
+
+namespace sad {
+
+// Called by sad_fps_f32 when a workspace (B*N ints) is available and N <= 16384.
+int launch_fps_bucket(const float *xyz, int B, int N, int M, int32_t *idx, void *workspace, hipStream_t st) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&fps_sort_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        attr_set = true;
+    }
+    int *perm = (int *)workspace;
+    hipLaunchKernelGGL(fps_sort_kernel, dim3(B), dim3(SORT_T), sizeof(int) * SORT_CELLS, st, xyz, N, perm);
+    if (int e = check_launch("sad_fps_f32 (sort)")) return e;
+    if (N <= 2048) {
+        const int ppt = (N + 255) / 256;
+        if (ppt <= 2) launch_bucket<256, 2>(xyz, perm, B, N, M, idx, st);
+        else if (ppt <= 4) launch_bucket<256, 4>(xyz, perm, B, N, M, idx, st);
+        else launch_bucket<256, 8>(xyz, perm, B, N, M, idx, st);
+    } else {
+        const int ppt = (N + 1023) / 1024;
+        if (ppt <= 4) launch_bucket<1024, 4>(xyz, perm, B, N, M, idx, st);
+        else if (ppt <= 8) launch_bucket<1024, 8>(xyz, perm, B, N, M, idx, st);
+        else launch_bucket<1024, 16>(xyz, perm, B, N, M, idx, st);
+    }
+    return check_launch("sad_fps_f32 (bucket)");
+}
+
+}  // namespace sad

@@ -51,7 +51,8 @@ def test_host_side_argument_errors(sad):
     assert L.sad_ball_query_f32(p, p, 0.5, None, 1, 8, 2, 65, p, None) == -1   # nsample > 64
     assert L.sad_group_points(p, p, 1, 1, 8, 2, 2, 3, p, None) == -1  # elem_size 3
     assert L.sad_set_option(b"no_such_option", 1) == -1
-    assert L.sad_fps_workspace_bytes(2, 16384) == 0
+    assert L.sad_fps_workspace_bytes(2, 1024) == 0
+    assert L.sad_fps_workspace_bytes(2, 16384) == 2 * 16384 * 4   # Z-order permutation (bucketed kernel)
     assert L.sad_fps_workspace_bytes(2, 65536) == 2 * 65536 * 4
     dims = (ctypes.c_int * 4)(259, 256, 512, 1024)
     n = L.sad_mlp_packed_floats(3, dims, 1)

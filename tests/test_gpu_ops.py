@@ -31,12 +31,12 @@ def _rand_xyz(seed, B, N, scale=1.0):
 @pytest.mark.parametrize("B,N,M", [(2, 64, 16), (3, 257, 100), (2, 1024, 256), (2, 2048, 512),
                                    (2, 3000, 700), (2, 4096, 1024), (1, 8192, 512), (2, 16384, 1024),
                                    (1, 5, 5), (1, 1, 1)])
-@pytest.mark.parametrize("variant", ["shfl", "dpp", "key"])
+@pytest.mark.parametrize("variant", ["shfl", "dpp", "key", "bucket"])
 def test_fps_parity(orc, sad, dev, B, N, M, variant):
     """Every FPS kernel variant (selected with sad_set_option) gives the oracle's indices."""
     from sad_amd import _lib, ops
     _lib.set_option("fps_dpp", 1 if variant == "dpp" else 0)
-    _lib.set_option("fps_variant", {"shfl": 1, "dpp": 1, "key": 2}[variant])
+    _lib.set_option("fps_variant", {"shfl": 1, "dpp": 1, "key": 2, "bucket": 3}[variant])
     try:
         xyz = _rand_xyz(100 + N, B, N)
         got = ops.fps(_t(xyz, dev), M).cpu().numpy()
@@ -52,7 +52,7 @@ def test_fps_big_n_workspace_path(orc, sad, dev):
     np.testing.assert_array_equal(ops.fps(_t(xyz, dev), 300).cpu().numpy(), orc.fps(xyz, 300))
 
 
-@pytest.mark.parametrize("variant", [1, 2])
+@pytest.mark.parametrize("variant", [1, 2, 3])
 def test_fps_edge_cases(orc, sad, dev, variant):
     from sad_amd import _lib, ops
     _lib.set_option("fps_variant", variant)
@@ -70,6 +70,14 @@ def _fps_edge_cases(orc, dev, ops):
     ax = np.arange(8, dtype=np.float32)
     grid = np.stack(np.meshgrid(ax, ax, ax, indexing="ij"), -1).reshape(1, 512, 3)
     np.testing.assert_array_equal(ops.fps(_t(grid, dev), 200).cpu().numpy(), orc.fps(grid, 200))
+    # the same with enough points for the bucketed kernel: 16^3 lattice (ties everywhere) + duplicates
+    ax = np.arange(16, dtype=np.float32)
+    grid = np.stack(np.meshgrid(ax, ax, ax, indexing="ij"), -1).reshape(1, 4096, 3).copy()
+    grid[0, 1000:1100] = grid[0, 7]
+    np.testing.assert_array_equal(ops.fps(_t(grid, dev), 1500).cpu().numpy(), orc.fps(grid, 1500))
+    flat = grid.copy()
+    flat[:, :, 2] = 0.25                      # degenerate extent in z
+    np.testing.assert_array_equal(ops.fps(_t(flat, dev), 600).cpu().numpy(), orc.fps(flat, 600))
 
 
 def test_fps_full_size_properties(orc, sad, dev):

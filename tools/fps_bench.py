@@ -18,7 +18,7 @@ def timeit(fn, reps=3):
 cur = xyz
 for N, M in ((16384, 4096), (4096, 1024), (1024, 512)):
     ref = None
-    for name, dpp, var in (("shfl", 0, 1), ("dpp", 1, 1), ("key", 0, 2)):
+    for name, dpp, var in (("shfl", 0, 1), ("dpp", 1, 1), ("key", 0, 2), ("bucket", 0, 3)):
         _lib.set_option("fps_dpp", dpp); _lib.set_option("fps_variant", var)
         t = timeit(lambda: ops.fps(cur, M))
         idx = ops.fps(cur, M)
