@@ -47,6 +47,9 @@ struct MlpParams {
     int cpr, cshift;       // float4 chunks per feature row (0 = scalar path), log2 of lanes per row
     int vec_out;           // 16-B output stores allowed
     int bias_total;        // sum of np[l]: biases are copied to LDS once per workgroup
+    int G;                 // grouped mode: (b,m) groups per workgroup
+    int nodedup;           // tuning/A-B switch: compute the padded duplicate rows too
+    long long total_groups; // B*M
 };
 
 // LDS activation image of a tile of R rows.  Channels are grouped in k-blocks of 8; inside a block
@@ -150,6 +153,22 @@ __device__ __forceinline__ void mma_ktile(f32x16 (&acc)[RW], const float4 *__res
     }
 }
 
+// Group of the last compact row (used for the clamped rows past the end of the last pass).
+__device__ __forceinline__ int s_off_last_group(const int *s_off, int G, int T) {
+    int lo = 0, hi = G;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (s_off[mid] <= T - 1) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+// Atomic max on floats that are known to be >= +0 (outputs of a ReLU): their bit patterns order
+// like unsigned integers.
+__device__ __forceinline__ void atomic_max_pos(float *addr, float v) {
+    atomicMax(reinterpret_cast<unsigned *>(addr), __builtin_bit_cast(unsigned, v));
+}
+
 template <int W, int RW>
 __global__ __launch_bounds__(W * 64) void mlp_chain_kernel(const MlpParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -166,25 +185,12 @@ __global__ __launch_bounds__(W * 64) void mlp_chain_kernel(const MlpParams p) {
     float *bufA = smem;
     float *bufB = smem + (size_t)(p.bufA_rows >> 2) * PS;
     float *sbias = bufB + (size_t)(p.bufB_rows >> 2) * PS;
-    int *sm_idx = reinterpret_cast<int *>(sbias + p.bias_total);
-    const long long r0 = (long long)blockIdx.x * R;
+    int *sm_idx = reinterpret_cast<int *>(sbias + p.bias_total);   // [R] source row / point index
+    int *sm_gid = sm_idx + R;                                      // [R] group of the row (-1: none)
+    int *s_off = sm_gid + R;                                       // [G+1] first compact row of a group
     const int koff = p.grouped ? 4 : 0;
-    const int Sp = 1 << p.sp_shift;
 
-    // ---- per-row source index (grouped: global point index b*N + idx; plain: row) and biases ----
-    for (int r = tid; r < R; r += W * 64) {
-        long long gr = r0 + r;
-        if (gr >= p.total_rows) gr = p.total_rows - 1;
-        if (p.grouped) {
-            const long long bm = gr >> p.sp_shift;
-            int s = (int)(gr & (Sp - 1));
-            if (s >= p.S) s = 0;  // padded sample repeats sample 0: the max-pool ignores duplicates
-            const int b = (int)(bm / p.M);
-            sm_idx[r] = (int)((long long)b * p.N + p.idx[bm * p.S + s]);
-        } else {
-            sm_idx[r] = (int)gr;
-        }
-    }
+    // ---- biases -> LDS --------------------------------------------------------------------------
     {
         int bo = 0;
         for (int l = 0; l < p.L; ++l) {
@@ -192,168 +198,248 @@ __global__ __launch_bounds__(W * 64) void mlp_chain_kernel(const MlpParams p) {
             bo += p.np[l];
         }
     }
-    __syncthreads();
-
-    const int nchunks = (p.kp[0] + p.kc - 1) / p.kc;
-    int bias_off = 0;
-
-    for (int l = 0; l < p.L; ++l) {
-        const float *in = (l & 1) ? bufB : bufA;
-        float *outb = (l & 1) ? bufA : bufB;
-        const int n_oc = p.np[l] >> 5;
-        const int nrounds = (n_oc + WN - 1) >> p.wn_shift;
-        const float4 *frags = reinterpret_cast<const float4 *>(p.packed + p.off[l] + p.np[l]);
-        const int nT4 = p.kp[l] >> 3;
-        const bool last = (l == p.L - 1);
-        const bool relu = (p.relu_mask >> l) & 1;
-        const int lchunks = (l == 0) ? nchunks : 1;
-        // channels of this layer's output the next layer actually reads (its padded K)
-        const int keep = last ? p.cout_last : p.kp[l + 1];
-
-        for (int round = 0; round < nrounds; ++round) {
-            const int oc = wn + (round << p.wn_shift);
-            const bool have = oc < n_oc;
-            f32x16 acc[RW];
-            if (have) {
-#pragma unroll
-                for (int a = 0; a < 4; ++a) {
-                    const float4 bv = *reinterpret_cast<const float4 *>(sbias + bias_off + oc * 32 + 8 * a + 4 * h);
-#pragma unroll
-                    for (int rt = 0; rt < RW; ++rt) {
-                        acc[rt][4 * a + 0] = bv.x;
-                        acc[rt][4 * a + 1] = bv.y;
-                        acc[rt][4 * a + 2] = bv.z;
-                        acc[rt][4 * a + 3] = bv.w;
-                    }
-                }
+    // ---- rows of this workgroup -----------------------------------------------------------------
+    // plain mode: rows [r0, r0 + R) of the input, one pass.
+    // grouped mode: G consecutive (b,m) groups.  The trailing samples of a group that repeat its
+    // first index (ball-query padding, SPEC.md §3) are dropped: a duplicate row cannot change the
+    // max-pool, so only the leading `cnt` rows of each group are computed.  The surviving rows of the
+    // G groups are numbered consecutively ("compact rows") and processed R at a time.
+    long long r0 = (long long)blockIdx.x * R;
+    long long g0 = 0;
+    int T = R, npass = 1;
+    if (p.grouped) {
+        g0 = (long long)blockIdx.x * p.G;
+        long long left = p.total_groups - g0;
+        const int ng = (int)(left < p.G ? left : p.G);
+        for (int gi = wave; gi < p.G; gi += W) {           // one wave per group: lane = sample
+            int cnt = 0;
+            if (gi < ng) {
+                const int32_t *ip = p.idx + (g0 + gi) * p.S;
+                const int v = lane < p.S ? ip[lane] : 0;
+                const int first = __builtin_amdgcn_readfirstlane(v);
+                const unsigned long long diff = __ballot(lane < p.S && v != first);
+                cnt = diff ? 64 - __builtin_clzll(diff) : 1;    // last sample that differs from the first, + 1
+                if (p.nodedup) cnt = p.S;
             }
-            for (int ck = 0; ck < lchunks; ++ck) {
-                const int k0 = (l == 0) ? ck * p.kc : 0;
-                int k1 = (l == 0) ? k0 + p.kc : p.kp[l];
-                if (k1 > p.kp[l]) k1 = p.kp[l];
-                if (l == 0 && (round == 0 || lchunks > 1)) {
-                    // ---- stage input channels [k0,k1) of the tile into bufA (channel c - k0) -----
-                    if (!(round == 0 && ck == 0)) __syncthreads();  // previous readers are done
-                    if (p.grouped && k0 == 0) {  // channels 0..3 = point - centroid, 0 (SPEC.md §6)
-                        for (int r = tid; r < R; r += W * 64) {
-                            long long gr = r0 + r;
-                            if (gr >= p.total_rows) gr = p.total_rows - 1;
-                            const float *q = p.xyz + (long long)sm_idx[r] * 3;
-                            const float *c = p.new_xyz + (gr >> p.sp_shift) * 3;
-                            *reinterpret_cast<float2 *>(bufA + r * 4) = make_float2(q[0] - c[0], q[2] - c[2]);
-                            *reinterpret_cast<float2 *>(bufA + PS + r * 4) = make_float2(q[1] - c[1], 0.f);
-                        }
-                    }
-                    const int f0 = (k0 > koff ? k0 : koff) - koff;         // first feature channel
-                    const int f1 = k1 - koff;                              // one past the last
-                    const int fl = f1 < p.C ? f1 : p.C;
-                    if (p.cpr > 0) {
-                        const int cprp = 1 << p.cshift;
-                        const int rpp = 64 >> p.cshift;
-                        for (int r = wave * rpp + (lane >> p.cshift); r < R; r += W * rpp) {
-                            const float *src = p.feat + (long long)sm_idx[r] * p.ld_feat;
-                            for (int ch = (f0 >> 2) + (lane & (cprp - 1)); ch < (fl >> 2); ch += cprp) {
-                                const float4 v = *reinterpret_cast<const float4 *>(src + 4 * ch);
-                                const int c = koff + 4 * ch - k0;  // multiple of 4
-                                float *d = bufA + (size_t)((c >> 3) << 1) * PS + r * 4 + ((c & 7) >> 1);
-                                *reinterpret_cast<float2 *>(d) = make_float2(v.x, v.z);       // even channels
-                                *reinterpret_cast<float2 *>(d + PS) = make_float2(v.y, v.w);  // odd channels
-                            }
-                        }
-                    } else {
-                        for (int r = tid; r < R; r += W * 64) {
-                            const float *src = p.feat + (long long)sm_idx[r] * p.ld_feat;
-                            for (int c = f0; c < fl; ++c) bufA[act_idx(koff + c - k0, r, PS)] = src[c];
-                        }
-                    }
-                    // zero the channel padding [koff + C, kp) that falls inside this chunk
-                    const int z0 = (koff + p.C > k0 ? koff + p.C : k0);
-                    for (int k = z0 + wave; k < k1; k += W)
-                        for (int r = lane; r < R; r += 64) bufA[act_idx(k - k0, r, PS)] = 0.f;
-                    __syncthreads();
+            if (lane == 0) s_off[gi + 1] = cnt;
+        }
+        if (tid == 0) s_off[0] = 0;
+        __syncthreads();
+        if (wave == 0) {                                    // inclusive scan of the counts (G <= 1024)
+            int carry = 0;
+            for (int base = 0; base < p.G; base += 64) {
+                const int gi = base + lane;
+                int v = gi < p.G ? s_off[gi + 1] : 0;
+                for (int off = 1; off < 64; off <<= 1) {
+                    const int u = __shfl_up(v, off, 64);
+                    if (lane >= off) v += u;
                 }
-                if (have) {
-                    const float4 *bp = reinterpret_cast<const float4 *>(in) + (size_t)h * (PS >> 2) + (wm * RW) * 32 + j;
-                    const float4 *af = frags + ((size_t)oc * nT4 + (k0 >> 3)) * 64 + lane;
-                    mma_ktile<RW, 4>(acc, af, (k1 - k0) >> 3, bp, PS >> 1);
-                }
-            }
-            if (!have) continue;
-            // ---- epilogue ---------------------------------------------------------------------
-            if (relu) {
-#pragma unroll
-                for (int rt = 0; rt < RW; ++rt)
-#pragma unroll
-                    for (int g = 0; g < 16; ++g) acc[rt][g] = acc[rt][g] > 0.f ? acc[rt][g] : 0.f;
-            }
-            if (!last) {
-                // channel c = oc*32 + 8a + q + 4h -> k-block oc*4 + a, plane q&1, slot (q>>1) + 2h
-#pragma unroll
-                for (int a = 0; a < 4; ++a) {
-                    if (oc * 32 + 8 * a >= keep) continue;   // the next layer never reads these
-#pragma unroll
-                    for (int rt = 0; rt < RW; ++rt) {
-                        float *d = outb + (size_t)((oc * 4 + a) * 2) * PS + ((wm * RW + rt) * 32 + j) * 4 + 2 * h;
-                        *reinterpret_cast<float2 *>(d) = make_float2(acc[rt][4 * a + 0], acc[rt][4 * a + 2]);
-                        *reinterpret_cast<float2 *>(d + PS) = make_float2(acc[rt][4 * a + 1], acc[rt][4 * a + 3]);
-                    }
-                }
-            } else if (!p.grouped) {
-                // plain rows: lane (j,h) holds row j, channels oc*32 + 8a + 4h + (0..3)
-#pragma unroll
-                for (int rt = 0; rt < RW; ++rt) {
-                    const long long gr = r0 + (wm * RW + rt) * 32 + j;
-                    if (gr >= p.total_rows) continue;
-                    float *o = p.out + gr * p.ld_out + p.col_off;
-#pragma unroll
-                    for (int a = 0; a < 4; ++a) {
-                        const int ch = oc * 32 + 8 * a + 4 * h;
-                        if (p.vec_out && ch + 3 < p.cout_last) {
-                            *reinterpret_cast<float4 *>(o + ch) = make_float4(acc[rt][4 * a], acc[rt][4 * a + 1], acc[rt][4 * a + 2], acc[rt][4 * a + 3]);
-                        } else {
-#pragma unroll
-                            for (int e = 0; e < 4; ++e)
-                                if (ch + e < p.cout_last) o[ch + e] = acc[rt][4 * a + e];
-                        }
-                    }
-                }
-            } else {
-                // max-pool over the Sp rows of each group, then the group leader writes 16 channels
-                if (p.sp_shift == 6) {
-#pragma unroll
-                    for (int rt = 0; rt + 1 < RW; rt += 2)
-#pragma unroll
-                        for (int g = 0; g < 16; ++g) acc[rt][g] = acc[rt + 1][g] > acc[rt][g] ? acc[rt + 1][g] : acc[rt][g];
-                }
-                const int lsteps = p.sp_shift < 5 ? p.sp_shift : 5;  // butterfly steps inside a half
-                const int rstep = (p.sp_shift == 6) ? 2 : 1;
-                const int gl = (p.sp_shift < 5) ? Sp : 32;          // lanes per group inside a half
-#pragma unroll
-                for (int rt = 0; rt < RW; rt += 1) {
-                    if (rstep == 2 && (rt & 1)) continue;
-#pragma unroll
-                    for (int g = 0; g < 16; ++g) acc[rt][g] = group_max(acc[rt][g], lsteps);
-                    if ((j & (gl - 1)) != 0) continue;
-                    const long long row = r0 + (wm * RW + rt) * 32 + j;
-                    const long long grp = row >> p.sp_shift;
-                    if (row >= p.total_rows) continue;
-                    float *o = p.out + grp * p.ld_out + p.col_off;
-#pragma unroll
-                    for (int a = 0; a < 4; ++a) {
-                        const int ch = oc * 32 + 8 * a + 4 * h;
-                        if (p.vec_out && ch + 3 < p.cout_last) {
-                            *reinterpret_cast<float4 *>(o + ch) = make_float4(acc[rt][4 * a], acc[rt][4 * a + 1], acc[rt][4 * a + 2], acc[rt][4 * a + 3]);
-                        } else {
-#pragma unroll
-                            for (int e = 0; e < 4; ++e)
-                                if (ch + e < p.cout_last) o[ch + e] = acc[rt][4 * a + e];
-                        }
-                    }
-                }
+                if (gi < p.G) s_off[gi + 1] = v + carry;
+                carry += __builtin_amdgcn_readlane(v, 63);
             }
         }
-        bias_off += p.np[l];
         __syncthreads();
+        T = s_off[p.G];
+        npass = (T + R - 1) / R;
+    }
+    const int nchunks = (p.kp[0] + p.kc - 1) / p.kc;
+
+    for (int pass = 0; pass < npass; ++pass) {
+        // ---- per-row source index ---------------------------------------------------------------
+        for (int r = tid; r < R; r += W * 64) {
+            if (p.grouped) {
+                int q = pass * R + r;
+                const bool valid = q < T;
+                if (!valid) q = T - 1;
+                int lo = 0, hi = p.G;                       // largest gi with s_off[gi] <= q
+                while (hi - lo > 1) {
+                    const int mid = (lo + hi) >> 1;
+                    if (s_off[mid] <= q) lo = mid; else hi = mid;
+                }
+                const long long gg = g0 + lo;
+                const int b = (int)(gg / p.M);
+                sm_idx[r] = (int)((long long)b * p.N + p.idx[gg * p.S + (q - s_off[lo])]);
+                sm_gid[r] = valid ? lo : -1;
+            } else {
+                long long gr = r0 + r;
+                if (gr >= p.total_rows) gr = p.total_rows - 1;
+                sm_idx[r] = (int)gr;
+            }
+        }
+        __syncthreads();
+
+        int bias_off = 0;
+        for (int l = 0; l < p.L; ++l) {
+            const float *in = (l & 1) ? bufB : bufA;
+            float *outb = (l & 1) ? bufA : bufB;
+            const int n_oc = p.np[l] >> 5;
+            const int nrounds = (n_oc + WN - 1) >> p.wn_shift;
+            const float4 *frags = reinterpret_cast<const float4 *>(p.packed + p.off[l] + p.np[l]);
+            const int nT4 = p.kp[l] >> 3;
+            const bool last = (l == p.L - 1);
+            const bool relu = (p.relu_mask >> l) & 1;
+            const int lchunks = (l == 0) ? nchunks : 1;
+            // channels of this layer's output the next layer actually reads (its padded K)
+            const int keep = last ? p.cout_last : p.kp[l + 1];
+
+            for (int round = 0; round < nrounds; ++round) {
+                const int oc = wn + (round << p.wn_shift);
+                const bool have = oc < n_oc;
+                f32x16 acc[RW];
+                if (have) {
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) {
+                        const float4 bv = *reinterpret_cast<const float4 *>(sbias + bias_off + oc * 32 + 8 * a + 4 * h);
+#pragma unroll
+                        for (int rt = 0; rt < RW; ++rt) {
+                            acc[rt][4 * a + 0] = bv.x;
+                            acc[rt][4 * a + 1] = bv.y;
+                            acc[rt][4 * a + 2] = bv.z;
+                            acc[rt][4 * a + 3] = bv.w;
+                        }
+                    }
+                }
+                for (int ck = 0; ck < lchunks; ++ck) {
+                    const int k0 = (l == 0) ? ck * p.kc : 0;
+                    int k1 = (l == 0) ? k0 + p.kc : p.kp[l];
+                    if (k1 > p.kp[l]) k1 = p.kp[l];
+                    if (l == 0 && (round == 0 || lchunks > 1)) {
+                        // ---- stage input channels [k0,k1) of the tile into bufA (channel c - k0) ---
+                        if (!(round == 0 && ck == 0)) __syncthreads();  // previous readers are done
+                        if (p.grouped && k0 == 0) {  // channels 0..3 = point - centroid, 0 (SPEC §6)
+                            for (int r = tid; r < R; r += W * 64) {
+                                const int gi = sm_gid[r] < 0 ? s_off_last_group(s_off, p.G, T) : sm_gid[r];
+                                const float *q = p.xyz + (long long)sm_idx[r] * 3;
+                                const float *c = p.new_xyz + (g0 + gi) * 3;
+                                *reinterpret_cast<float2 *>(bufA + r * 4) = make_float2(q[0] - c[0], q[2] - c[2]);
+                                *reinterpret_cast<float2 *>(bufA + PS + r * 4) = make_float2(q[1] - c[1], 0.f);
+                            }
+                        }
+                        const int f0 = (k0 > koff ? k0 : koff) - koff;         // first feature channel
+                        const int f1 = k1 - koff;                              // one past the last
+                        const int fl = f1 < p.C ? f1 : p.C;
+                        if (p.cpr > 0) {
+                            const int cprp = 1 << p.cshift;
+                            const int rpp = 64 >> p.cshift;
+                            for (int r = wave * rpp + (lane >> p.cshift); r < R; r += W * rpp) {
+                                const float *src = p.feat + (long long)sm_idx[r] * p.ld_feat;
+                                for (int ch = (f0 >> 2) + (lane & (cprp - 1)); ch < (fl >> 2); ch += cprp) {
+                                    const float4 v = *reinterpret_cast<const float4 *>(src + 4 * ch);
+                                    const int c = koff + 4 * ch - k0;  // multiple of 4
+                                    float *d = bufA + (size_t)((c >> 3) << 1) * PS + r * 4 + ((c & 7) >> 1);
+                                    *reinterpret_cast<float2 *>(d) = make_float2(v.x, v.z);       // even channels
+                                    *reinterpret_cast<float2 *>(d + PS) = make_float2(v.y, v.w);  // odd channels
+                                }
+                            }
+                        } else {
+                            for (int r = tid; r < R; r += W * 64) {
+                                const float *src = p.feat + (long long)sm_idx[r] * p.ld_feat;
+                                for (int c = f0; c < fl; ++c) bufA[act_idx(koff + c - k0, r, PS)] = src[c];
+                            }
+                        }
+                        // zero the channel padding [koff + C, kp) that falls inside this chunk
+                        const int z0 = (koff + p.C > k0 ? koff + p.C : k0);
+                        for (int k = z0 + wave; k < k1; k += W)
+                            for (int r = lane; r < R; r += 64) bufA[act_idx(k - k0, r, PS)] = 0.f;
+                        __syncthreads();
+                    }
+                    if (have) {
+                        const float4 *bp = reinterpret_cast<const float4 *>(in) + (size_t)h * (PS >> 2) + (wm * RW) * 32 + j;
+                        const float4 *af = frags + ((size_t)oc * nT4 + (k0 >> 3)) * 64 + lane;
+                        mma_ktile<RW, 4>(acc, af, (k1 - k0) >> 3, bp, PS >> 1);
+                    }
+                }
+                if (!have) continue;
+                // ---- epilogue -----------------------------------------------------------------
+                if (relu) {
+#pragma unroll
+                    for (int rt = 0; rt < RW; ++rt)
+#pragma unroll
+                        for (int g = 0; g < 16; ++g) acc[rt][g] = acc[rt][g] > 0.f ? acc[rt][g] : 0.f;
+                }
+                if (!last) {
+                    // channel c = oc*32 + 8a + q + 4h -> k-block oc*4 + a, plane q&1, slot (q>>1) + 2h
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) {
+                        if (oc * 32 + 8 * a >= keep) continue;   // the next layer never reads these
+#pragma unroll
+                        for (int rt = 0; rt < RW; ++rt) {
+                            float *d = outb + (size_t)((oc * 4 + a) * 2) * PS + ((wm * RW + rt) * 32 + j) * 4 + 2 * h;
+                            *reinterpret_cast<float2 *>(d) = make_float2(acc[rt][4 * a + 0], acc[rt][4 * a + 2]);
+                            *reinterpret_cast<float2 *>(d + PS) = make_float2(acc[rt][4 * a + 1], acc[rt][4 * a + 3]);
+                        }
+                    }
+                } else if (!p.grouped) {
+                    // plain rows: lane (j,h) holds row j, channels oc*32 + 8a + 4h + (0..3)
+#pragma unroll
+                    for (int rt = 0; rt < RW; ++rt) {
+                        const long long gr = r0 + (wm * RW + rt) * 32 + j;
+                        if (gr >= p.total_rows) continue;
+                        float *o = p.out + gr * p.ld_out + p.col_off;
+#pragma unroll
+                        for (int a = 0; a < 4; ++a) {
+                            const int ch = oc * 32 + 8 * a + 4 * h;
+                            if (p.vec_out && ch + 3 < p.cout_last) {
+                                *reinterpret_cast<float4 *>(o + ch) = make_float4(acc[rt][4 * a], acc[rt][4 * a + 1], acc[rt][4 * a + 2], acc[rt][4 * a + 3]);
+                            } else {
+#pragma unroll
+                                for (int e = 0; e < 4; ++e)
+                                    if (ch + e < p.cout_last) o[ch + e] = acc[rt][4 * a + e];
+                            }
+                        }
+                    }
+                } else {
+                    // max-pool per group: the rows of a group are consecutive lanes (compact rows are
+                    // numbered group by group), so a segmented max-scan over the 32 rows of the tile
+                    // leaves each group's maximum in its last lane.  A group that lies entirely in
+                    // this tile is stored; one that continues in another tile is combined with an
+                    // atomic max (outputs are >= 0 after the ReLU and the buffer starts at zero).
+#pragma unroll
+                    for (int rt = 0; rt < RW; ++rt) {
+                        const int rbase = (wm * RW + rt) * 32;
+                        const int gid = sm_gid[rbase + j];
+                        int same[5];
+#pragma unroll
+                        for (int st = 0; st < 5; ++st) {
+                            const int og = __shfl_up(gid, 1 << st, 32);
+                            same[st] = (j >= (1 << st)) && og == gid;
+                        }
+#pragma unroll
+                        for (int g = 0; g < 16; ++g) {
+                            float v = acc[rt][g];
+#pragma unroll
+                            for (int st = 0; st < 5; ++st) {
+                                const float u = __shfl_up(v, 1 << st, 32);
+                                v = (same[st] && u > v) ? u : v;
+                            }
+                            acc[rt][g] = v;
+                        }
+                        const int ng = __shfl_down(gid, 1, 32);
+                        const bool tail = gid >= 0 && (j == 31 || ng != gid);
+                        if (!tail) continue;
+                        const int q0 = pass * R + rbase;                  // compact row of lane 0
+                        const bool whole = s_off[gid] >= q0 && s_off[gid + 1] <= q0 + 32;
+                        float *o = p.out + (g0 + gid) * p.ld_out + p.col_off;
+#pragma unroll
+                        for (int a = 0; a < 4; ++a) {
+                            const int ch = oc * 32 + 8 * a + 4 * h;
+                            if (whole && p.vec_out && ch + 3 < p.cout_last) {
+                                *reinterpret_cast<float4 *>(o + ch) = make_float4(acc[rt][4 * a], acc[rt][4 * a + 1], acc[rt][4 * a + 2], acc[rt][4 * a + 3]);
+                            } else {
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) {
+                                    if (ch + e >= p.cout_last) continue;
+                                    if (whole) o[ch + e] = acc[rt][4 * a + e];
+                                    else atomic_max_pos(o + ch + e, acc[rt][4 * a + e]);
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+            bias_off += p.np[l];
+            __syncthreads();
+        }
     }
 }
 
@@ -609,7 +695,9 @@ SAD_API int sad_mlp_chain_f32(const sad_mlp_args *a, sad_stream_t stream) {
     int sp_shift = 0;
     while ((1 << sp_shift) < a->S) ++sp_shift;
     p.sp_shift = sp_shift;
-    p.total_rows = (long long)a->B * a->M << sp_shift;
+    p.total_rows = (long long)a->B * a->M << sp_shift;   // plain mode: rows; VALU kernel: padded rows
+    p.total_groups = (long long)a->B * a->M;
+    const int dedup_f = sad::get_option(sad::OPT_MLP_NODEDUP) ? 1 : (sad::get_option(sad::OPT_MLP_DEDUP_F) > 0 ? sad::get_option(sad::OPT_MLP_DEDUP_F) : 8);
     int max_noc = 1, min_noc = 1 << 30;
     for (int l = 0; l < a->L; ++l) {
         p.kp[l] = g.kp[l]; p.np[l] = g.np[l]; p.off[l] = g.off[l];
@@ -663,17 +751,24 @@ SAD_API int sad_mlp_chain_f32(const sad_mlp_args *a, sad_stream_t stream) {
     int bias_total = 0;
     for (int l = 0; l < a->L; ++l) bias_total += g.np[l];
     p.bias_total = bias_total;
+    // grouped mode: a workgroup owns G groups; with ball-query padding dropped their surviving rows
+    // usually fit one pass of R rows (dedup_f = assumed ratio of padded to surviving rows)
+    auto groups_per_wg = [&](int R) {
+        long long gq = (long long)dedup_f * R / a->S;
+        return (int)(gq < 1 ? 1 : (gq > 1024 ? 1024 : gq));
+    };
     auto lds_bytes = [&](int w, int wns, int rw, int kcc) {
         int ra, rb;
         lds_rows(kcc, ra, rb);
         const size_t R = 32 * (size_t)rw * (w >> wns);
-        return ((size_t)((ra + rb) / 4) * (4 * R + 8) + R + (size_t)bias_total) * 4 + 16;
+        const size_t G = grouped ? (size_t)groups_per_wg((int)R) : 0;
+        return ((size_t)((ra + rb) / 4) * (4 * R + 8) + 2 * R + G + 1 + (size_t)bias_total) * 4 + 16;
     };
     // ---- choose the workgroup geometry -----------------------------------------------------
     // W waves, WN along output tiles; R = 32*RW*(W/WN) rows per workgroup.
     const int bkb = sad::get_option(sad::OPT_MLP_BUDGET_KB);
     const size_t BUDGET2 = (size_t)(bkb > 0 ? bkb : 78) * 1024, BUDGET1 = 156 * 1024;
-    const int rw_min = (grouped && sp_shift == 6) ? 2 : 1;  // 64-row pooling groups span 2 tiles
+    const int rw_min = 1;
     int W = 8, wn_shift = 0, RW = 1, kc = g.kp[0];
     int geom = a->geometry ? a->geometry : sad::get_option(sad::OPT_MLP_FORCE);
     if (geom) {
@@ -709,7 +804,8 @@ SAD_API int sad_mlp_chain_f32(const sad_mlp_args *a, sad_stream_t stream) {
                     if (lds_bytes(8, wns, rw, kcc) > budget) continue;
                     if (!best_rw) best_rw = rw;   // largest that fits
                     const long long R = 32LL * rw * (8 >> wns);
-                    if ((p.total_rows + R - 1) / R >= 1024 || rw == rw_min) { best_rw = rw; break; }
+                    const long long nb = grouped ? (p.total_groups * a->S / dedup_f + R - 1) / R : (p.total_rows + R - 1) / R;
+                    if (nb >= 1024 || rw == rw_min) { best_rw = rw; break; }
                 }
                 if (best_rw) { wn_shift = wns; RW = best_rw; kc = kcc; found = true; }
             }
@@ -721,7 +817,9 @@ SAD_API int sad_mlp_chain_f32(const sad_mlp_args *a, sad_stream_t stream) {
     lds_rows(kc, p.bufA_rows, p.bufB_rows);
     const size_t lds = lds_bytes(W, wn_shift, RW, kc);
     const long long R = 32LL * RW * (W >> wn_shift);
-    const long long nblocks = (p.total_rows + R - 1) / R;
+    p.G = grouped ? groups_per_wg((int)R) : 0;
+    p.nodedup = sad::get_option(sad::OPT_MLP_NODEDUP);
+    const long long nblocks = grouped ? (p.total_groups + p.G - 1) / p.G : (p.total_rows + R - 1) / R;
     SAD_REQUIRE(nblocks < (1LL << 31), "sad_mlp_chain_f32: too many workgroups");
     hipStream_t st = (hipStream_t)stream;
     if (W == 8) {

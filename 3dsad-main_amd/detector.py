@@ -131,7 +131,7 @@ class SADDetector(nn.Module):
                                        cfg.r_min, cfg.r_max, self._anchor, cand.data_ptr(),
                                        rad.data_ptr(), main.cuda_stream), "sad_candidates_f32")
         idxs = ops.ball_query_multi(cfg.cluster_scales, cfg.cluster_nsamples, cur_xyz, cand, rad)
-        cat = torch.empty((B, K, self.cluster_cat), dtype=torch.float32, device=points.device)
+        cat = torch.zeros((B, K, self.cluster_cat), dtype=torch.float32, device=points.device)
         off = 0
         for mlp, idx in zip(self.cluster_branches, idxs):
             mlp.grouped(cur_xyz, cur_feat, cand, idx, out=cat, col_off=off)

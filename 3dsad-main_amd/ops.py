@@ -288,7 +288,9 @@ class PackedMLP:
                 ) -> torch.Tensor:
         """Fused group -> MLP -> max over nsample.  xyz [B,N,3]; feat_pm point-major [B,N,C] (or
         None); new_xyz [B,M,3]; idx [B,M,S].  Writes out[:, :, col_off:col_off+C_out] of a
-        point-major [B,M,ld_out] buffer (allocated [B,M,C_out] when ``out`` is None)."""
+        point-major [B,M,ld_out] buffer (allocated [B,M,C_out] when ``out`` is None).  A caller-
+        provided ``out`` slice must be ZERO on entry (groups spanning two row tiles are combined
+        with an atomic max).  Samples that repeat a group's first index are skipped."""
         if not self.first_has_xyz:
             raise RuntimeError("this PackedMLP was packed without the xyz prefix")
         xyz = _need(xyz, "xyz", torch.float32, 3)
@@ -309,8 +311,10 @@ class PackedMLP:
             a.ld_feat = feat_pm.stride(1)
         if self.dims[0] != C + 3:
             raise ValueError(f"MLP expects {self.dims[0] - 3} feature channels, got {C}")
-        if out is None:
-            out = torch.empty((B, M, self.out_channels), dtype=torch.float32, device=xyz.device)
+        if out is None:   # the kernel max-combines into the buffer: it must start at zero
+            out = torch.zeros((B, M, self.out_channels), dtype=torch.float32, device=xyz.device)
+        if self.relu_mask != (1 << self.L) - 1:
+            raise RuntimeError("grouped chains need a ReLU after every layer (max-pool combine)")
         self._check_out(out, B * M, col_off)
         a.xyz, a.new_xyz, a.idx = xyz.data_ptr(), new_xyz.data_ptr(), idx.data_ptr()
         a.B, a.N, a.M, a.S, a.C = B, N, M, S, C

@@ -58,7 +58,7 @@ class SAModuleMSG(nn.Module):
         B, M = new_xyz.shape[0], new_xyz.shape[1]
         idxs = ops.ball_query_multi(radii if radii is not None else st.radii, st.nsamples, xyz,
                                     new_xyz, radius_pc)
-        cat = torch.empty((B, M, self.cat_channels), dtype=torch.float32, device=xyz.device)
+        cat = torch.zeros((B, M, self.cat_channels), dtype=torch.float32, device=xyz.device)
         off = 0
         for mlp, idx in zip(self.branches, idxs):
             mlp.grouped(xyz, feat_pm, new_xyz, idx, out=cat, col_off=off)

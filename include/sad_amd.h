@@ -112,7 +112,11 @@ typedef struct sad_mlp_args {
     const float *packed;          /* from sad_mlp_pack_f32 with the same L, dims, first_has_xyz */
     int relu_mask;                /* bit l set = ReLU after layer l */
     /* output: point-major rows.  grouped mode: max over the S samples of each (b,m) ->
-     * out[(b*M+m)*ld_out + col_off + o]; plain mode: out[row*ld_out + col_off + o] */
+     * out[(b*M+m)*ld_out + col_off + o]; plain mode: out[row*ld_out + col_off + o].
+     * GROUPED MODE NEEDS THE OUTPUT SLICE ZERO-INITIALISED: groups whose rows straddle two row tiles
+     * are combined with an atomic max (every layer of a grouped chain must carry a ReLU, so outputs
+     * are >= 0).  Trailing samples that repeat a group's first index (ball-query padding) are not
+     * computed at all — a duplicate row cannot change the max. */
     float *out;
     int ld_out;
     int col_off;

@@ -93,6 +93,40 @@ def test_grouped_mlp_parity(orc, sad, dev, B, N, M, S, C, mlp, r):
     _close(got, want, f"grouped C={C} S={S} mlp={mlp}")
 
 
+@pytest.mark.parametrize("S,C,mlp", [(32, 16, [32, 32, 64]), (64, 64, [64, 96, 128]), (24, 5, [20, 30]), (16, 256, [256, 512])])
+def test_grouped_mlp_arbitrary_indices(orc, sad, dev, S, C, mlp):
+    """idx need not come from ball_query: random neighbours (every group full -> several passes per
+    workgroup, groups straddling row tiles -> atomic-max combine), groups with random amounts of
+    trailing padding, duplicates in the MIDDLE of a group (must still be computed) and the
+    no-dedupe switch all give the oracle's pooled features."""
+    from sad_amd import _lib, ops, synth
+    rng = np.random.default_rng(S * 7 + C)
+    B, N, M = 2, 700, 300
+    xyz = rng.uniform(0, 1, (B, N, 3)).astype(np.float32)
+    feat = rng.normal(size=(B, N, C)).astype(np.float32)
+    new_xyz = rng.uniform(0, 1, (B, M, 3)).astype(np.float32)
+    idx = rng.integers(0, N, (B, M, S)).astype(np.int32)
+    cnt = rng.integers(1, S + 1, (B, M))
+    cnt[:, ::3] = S                                     # a third of the groups are full
+    for b in range(B):
+        for m in range(M):
+            idx[b, m, cnt[b, m]:] = idx[b, m, 0]        # trailing padding with the first index
+    idx[0, 5, 2] = idx[0, 5, 0]                         # duplicate in the middle, real rows after it
+    idx[1, 7, :] = 3                                    # one point repeated S times
+    layers = synth.make_mlp_weights([C + 3] + mlp, rng)
+    want = orc.sa_group_mlp_max(xyz, feat, new_xyz, idx, layers)
+    mlp_gpu = ops.PackedMLP(layers, True, dev)
+    args = (_t(xyz, dev), _t(feat, dev), _t(new_xyz, dev), _t(idx, dev))
+    _close(mlp_gpu.grouped(*args).cpu().numpy(), want, f"arbitrary idx S={S}")
+    for key, val in (("mlp_nodedup", 1), ("mlp_dedup_f", 1), ("mlp_dedup_f", 64)):
+        _lib.set_option(key, val)
+        try:
+            got = mlp_gpu.grouped(*args).cpu().numpy()
+        finally:
+            _lib.set_option(key, 0)
+        _close(got, want, f"{key}={val}")
+
+
 @pytest.mark.parametrize("rw", [1, 2, 4])
 def test_grouped_mlp_rows_per_wave_option(orc, sad, dev, rw):
     """Every row-tiles-per-wave variant of the kernel gives the same answer."""
