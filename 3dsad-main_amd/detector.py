@@ -21,7 +21,8 @@ from .sa_module import SAModuleMSG
 
 
 class SADDetector(nn.Module):
-    def __init__(self, cfg: DetectorConfig, weights: dict, device, overlap_fps: bool = True):
+    def __init__(self, cfg: DetectorConfig, weights: dict, device, overlap_fps: bool = True,
+                 n_fps_streams: int = 3):
         super().__init__()
         self.cfg = cfg
         self.device = torch.device(device)
@@ -47,7 +48,13 @@ class SADDetector(nn.Module):
         self._anchor = (ctypes.c_float * 3)(*cfg.anchor_car)
         self._anchors = (ctypes.c_float * 9)(*[v for a in cfg.anchors for v in a])
         self.overlap_fps = overlap_fps
-        self._side = torch.cuda.Stream(device=self.device) if overlap_fps else None
+        # Sampling streams, used round-robin by consecutive calls: one FPS chain keeps only B CUs
+        # busy (one workgroup per scene, a serial chain of M steps), so with input_ready=True the
+        # chains of several consecutive batches run side by side while the main stream works
+        # through the grouping / MLP kernels of earlier batches.
+        self._sides = ([torch.cuda.Stream(device=self.device) for _ in range(max(1, n_fps_streams))]
+                       if overlap_fps else [])
+        self._calls = 0
 
     def autotune(self, points: torch.Tensor) -> dict:
         """One synchronous forward pass during which every MLP launch times its workgroup
@@ -88,7 +95,8 @@ class SADDetector(nn.Module):
         feat = points[:, :, 3:] if D > 3 else None   # strided view [B,N,in_feat], no copy
         main = torch.cuda.current_stream()
         if self.overlap_fps:
-            side = self._side
+            side = self._sides[self._calls % len(self._sides)]
+            self._calls += 1
             if not input_ready:
                 side.wait_stream(main)
             evs = []
@@ -117,9 +125,10 @@ class SADDetector(nn.Module):
             if evs[si] is not None:
                 main.wait_event(evs[si])
             new_xyz = centroids[si]
-            cur_feat = m.group_and_pool(cur_xyz, cur_feat, new_xyz)
+            cur_feat = m.group_and_pool(cur_xyz, cur_feat, new_xyz,
+                                        keep=None if trace is None else trace.setdefault(f"sa{si + 1}", {}))
             if trace is not None:
-                trace[f"sa{si + 1}"] = dict(new_xyz=new_xyz, out=cur_feat)
+                trace[f"sa{si + 1}"].update(new_xyz=new_xyz, out=cur_feat)
             cur_xyz = new_xyz
         # ---- size-adaptive cluster layer (SPEC.md §8) ----------------------------------------
         K = cfg.n_cand

@@ -52,12 +52,15 @@ class SAModuleMSG(nn.Module):
 
     def group_and_pool(self, xyz: torch.Tensor, feat_pm: Optional[torch.Tensor],
                        new_xyz: torch.Tensor, radius_pc: Optional[torch.Tensor] = None,
-                       radii: Optional[Sequence[float]] = None) -> torch.Tensor:
+                       radii: Optional[Sequence[float]] = None, keep: Optional[dict] = None
+                       ) -> torch.Tensor:
         """ball query + fused MLP/max for every branch + aggregation -> [B,M,C'] point-major."""
         st = self.stage
         B, M = new_xyz.shape[0], new_xyz.shape[1]
         idxs = ops.ball_query_multi(radii if radii is not None else st.radii, st.nsamples, xyz,
                                     new_xyz, radius_pc)
+        if keep is not None:
+            keep["ball_idx"] = idxs
         cat = torch.zeros((B, M, self.cat_channels), dtype=torch.float32, device=xyz.device)
         off = 0
         for mlp, idx in zip(self.branches, idxs):
