@@ -23,7 +23,7 @@ vp = ctypes.c_void_p
 class MlpArgs(ctypes.Structure):
     """``struct sad_mlp_args`` (include/sad_amd.h)."""
     _fields_ = [
-        ("xyz", vp), ("new_xyz", vp), ("idx", vp), ("feat", vp),
+        ("xyz", vp), ("new_xyz", vp), ("idx", vp), ("cnt", vp), ("feat", vp),
         ("ld_feat", ctypes.c_int),
         ("B", ctypes.c_int), ("N", ctypes.c_int), ("M", ctypes.c_int), ("S", ctypes.c_int),
         ("C", ctypes.c_int),
@@ -47,11 +47,12 @@ SIGNATURES = {
     "sad_ball_query_f32": (ctypes.c_int, [vp, vp, ctypes.c_float, vp] + [ctypes.c_int] * 4 + [vp, vp]),
     "sad_ball_query_multi_f32": (ctypes.c_int, [vp, vp, ctypes.c_int, c_f32p, vp,
                                                ctypes.POINTER(ctypes.c_int), ctypes.POINTER(vp),
+                                               ctypes.POINTER(vp),
                                                ctypes.c_int, ctypes.c_int, ctypes.c_int, vp]),
     "sad_ball_query_grid_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int]),
     "sad_ball_query_grid_f32": (ctypes.c_int, [vp, vp, ctypes.c_int, c_f32p, ctypes.POINTER(ctypes.c_int),
-                                              ctypes.POINTER(vp), ctypes.c_int, ctypes.c_int, ctypes.c_int,
-                                              vp, vp]),
+                                              ctypes.POINTER(vp), ctypes.POINTER(vp),
+                                              ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp]),
     "sad_knn_f32": (ctypes.c_int, [vp, vp] + [ctypes.c_int] * 4 + [vp, vp]),
     "sad_mlp_packed_floats": (ctypes.c_size_t, [ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.c_int]),
     "sad_mlp_pack_f32": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.c_int,

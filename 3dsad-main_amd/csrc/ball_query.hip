@@ -15,6 +15,7 @@ struct BQParams {
     float radii[SAD_MAX_RADII];
     int nsample[SAD_MAX_RADII];
     int32_t *idx[SAD_MAX_RADII];
+    int32_t *cnt[SAD_MAX_RADII];   // optional: number of accepted points per centroid, capped at nsample
 };
 
 constexpr int BQ_WAVES = 4;
@@ -85,6 +86,7 @@ __global__ __launch_bounds__(BQ_WAVES * 64) void ball_query_kernel(
             const int n = cnt[c][r] < S ? cnt[c][r] : S;
             for (int s = n + lane; s < S; s += 64)
                 prm.idx[r][((size_t)b * M + (m0 + c)) * S + s] = first[c][r];
+            if (prm.cnt[r] && lane == 0) prm.cnt[r][(size_t)b * M + (m0 + c)] = n;
         }
     }
 }
@@ -154,8 +156,8 @@ int check_common(const char *fn, const void *xyz, const void *new_xyz, int B, in
 
 SAD_API int sad_ball_query_multi_f32(const float *xyz, const float *new_xyz, int n_radii,
                                      const float *radii, const float *radius_pc,
-                                     const int *nsamples, int32_t *const *idx, int B, int N, int M,
-                                     sad_stream_t stream) {
+                                     const int *nsamples, int32_t *const *idx, int32_t *const *cnt,
+                                     int B, int N, int M, sad_stream_t stream) {
     if (int e = check_common("sad_ball_query_multi_f32", xyz, new_xyz, B, N, M)) return e;
     SAD_REQUIRE(n_radii >= 1 && n_radii <= SAD_MAX_RADII, "sad_ball_query_multi_f32: n_radii=%d not in 1..%d", n_radii, SAD_MAX_RADII);
     SAD_REQUIRE(radii && nsamples && idx, "sad_ball_query_multi_f32: NULL parameter array");
@@ -166,6 +168,7 @@ SAD_API int sad_ball_query_multi_f32(const float *xyz, const float *new_xyz, int
         prm.radii[r] = radii[r];
         prm.nsample[r] = nsamples[r];
         prm.idx[r] = idx[r];
+        prm.cnt[r] = cnt ? cnt[r] : nullptr;
     }
     hipStream_t st = (hipStream_t)stream;
     switch (n_radii) {
@@ -183,7 +186,7 @@ SAD_API int sad_ball_query_f32(const float *xyz, const float *new_xyz, float rad
     const float radii[1] = {radius_pc ? 1.0f : radius};  // 1.0f * r == r exactly
     const int ns[1] = {S};
     int32_t *const outs[1] = {idx};
-    return sad_ball_query_multi_f32(xyz, new_xyz, 1, radii, radius_pc, ns, outs, B, N, M, stream);
+    return sad_ball_query_multi_f32(xyz, new_xyz, 1, radii, radius_pc, ns, outs, nullptr, B, N, M, stream);
 }
 
 SAD_API int sad_knn_f32(const float *xyz, const float *new_xyz, int B, int N, int M, int K,

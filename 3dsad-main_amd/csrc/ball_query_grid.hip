@@ -147,6 +147,7 @@ struct GQParams {
     float radii[SAD_MAX_RADII];
     int nsample[SAD_MAX_RADII];
     int32_t *idx[SAD_MAX_RADII];
+    int32_t *cnt[SAD_MAX_RADII];   // optional: accepted points per centroid, capped at nsample
 };
 
 constexpr int GQ_WAVES = 4;
@@ -251,6 +252,7 @@ __global__ __launch_bounds__(GQ_WAVES * 64) void grid_query_kernel(const float *
             int first = 0;
             if (has) first = __builtin_amdgcn_readlane(myfirst, __builtin_ctzll(has));
             for (int s = (total < S ? total : S) + lane; s < S; s += 64) out[s] = first;
+            if (prm.cnt[r] && lane == 0) prm.cnt[r][(size_t)b * M + m] = total < S ? total : S;
         }
     }
 }
@@ -273,7 +275,8 @@ SAD_API size_t sad_ball_query_grid_workspace_bytes(int B, int N) {
 
 SAD_API int sad_ball_query_grid_f32(const float *xyz, const float *new_xyz, int n_radii,
                                     const float *radii, const int *nsamples, int32_t *const *idx,
-                                    int B, int N, int M, void *workspace, sad_stream_t stream) {
+                                    int32_t *const *cnt, int B, int N, int M, void *workspace,
+                                    sad_stream_t stream) {
     SAD_REQUIRE(xyz && new_xyz && radii && nsamples && idx && workspace, "sad_ball_query_grid_f32: NULL pointer");
     SAD_REQUIRE(B >= 1 && B <= 65535 && N >= 1 && M >= 1, "sad_ball_query_grid_f32: need B,N,M >= 1");
     SAD_REQUIRE(n_radii >= 1 && n_radii <= SAD_MAX_RADII, "sad_ball_query_grid_f32: n_radii=%d not in 1..%d", n_radii, SAD_MAX_RADII);
@@ -287,6 +290,7 @@ SAD_API int sad_ball_query_grid_f32(const float *xyz, const float *new_xyz, int 
         prm.radii[r] = radii[r];
         prm.nsample[r] = nsamples[r];
         prm.idx[r] = idx[r];
+        prm.cnt[r] = cnt ? cnt[r] : nullptr;
         rmax = radii[r] > rmax ? radii[r] : rmax;
     }
     hipStream_t st = (hipStream_t)stream;

@@ -27,6 +27,7 @@ struct MlpParams {
     const float *xyz;
     const float *new_xyz;
     const int32_t *idx;
+    const int32_t *cnt;    // optional per-group row counts
     const float *feat;
     const float *packed;
     float *out;
@@ -211,17 +212,29 @@ __global__ __launch_bounds__(W * 64) void mlp_chain_kernel(const MlpParams p) {
         g0 = (long long)blockIdx.x * p.G;
         long long left = p.total_groups - g0;
         const int ng = (int)(left < p.G ? left : p.G);
-        for (int gi = wave; gi < p.G; gi += W) {           // one wave per group: lane = sample
-            int cnt = 0;
-            if (gi < ng) {
-                const int32_t *ip = p.idx + (g0 + gi) * p.S;
-                const int v = lane < p.S ? ip[lane] : 0;
-                const int first = __builtin_amdgcn_readfirstlane(v);
-                const unsigned long long diff = __ballot(lane < p.S && v != first);
-                cnt = diff ? 64 - __builtin_clzll(diff) : 1;    // last sample that differs from the first, + 1
-                if (p.nodedup) cnt = p.S;
+        if (p.cnt) {                                        // counts come from the ball query
+            for (int gi = tid; gi < p.G; gi += W * 64) {
+                int cnt = 0;
+                if (gi < ng) {
+                    cnt = p.cnt[g0 + gi];
+                    cnt = cnt < 1 ? 1 : (cnt > p.S ? p.S : cnt);
+                    if (p.nodedup) cnt = p.S;
+                }
+                s_off[gi + 1] = cnt;
             }
-            if (lane == 0) s_off[gi + 1] = cnt;
+        } else {
+            for (int gi = wave; gi < p.G; gi += W) {       // one wave per group: lane = sample
+                int cnt = 0;
+                if (gi < ng) {
+                    const int32_t *ip = p.idx + (g0 + gi) * p.S;
+                    const int v = lane < p.S ? ip[lane] : 0;
+                    const int first = __builtin_amdgcn_readfirstlane(v);
+                    const unsigned long long diff = __ballot(lane < p.S && v != first);
+                    cnt = diff ? 64 - __builtin_clzll(diff) : 1;    // last sample differing from the first, + 1
+                    if (p.nodedup) cnt = p.S;
+                }
+                if (lane == 0) s_off[gi + 1] = cnt;
+            }
         }
         if (tid == 0) s_off[0] = 0;
         __syncthreads();
@@ -688,7 +701,7 @@ SAD_API int sad_mlp_chain_f32(const sad_mlp_args *a, sad_stream_t stream) {
 
     MlpParams p{};
     const Geometry g = geometry(a->L, a->dims, grouped);
-    p.xyz = a->xyz; p.new_xyz = a->new_xyz; p.idx = a->idx; p.feat = a->feat; p.packed = a->packed;
+    p.xyz = a->xyz; p.new_xyz = a->new_xyz; p.idx = a->idx; p.cnt = a->cnt; p.feat = a->feat; p.packed = a->packed;
     p.out = a->out; p.ld_feat = a->ld_feat; p.N = a->N; p.M = a->M; p.S = a->S; p.C = a->C;
     p.grouped = grouped; p.L = a->L; p.relu_mask = a->relu_mask; p.ld_out = a->ld_out;
     p.col_off = a->col_off; p.cout_last = cout;
@@ -697,7 +710,12 @@ SAD_API int sad_mlp_chain_f32(const sad_mlp_args *a, sad_stream_t stream) {
     p.sp_shift = sp_shift;
     p.total_rows = (long long)a->B * a->M << sp_shift;   // plain mode: rows; VALU kernel: padded rows
     p.total_groups = (long long)a->B * a->M;
-    const int dedup_f = sad::get_option(sad::OPT_MLP_NODEDUP) ? 1 : (sad::get_option(sad::OPT_MLP_DEDUP_F) > 0 ? sad::get_option(sad::OPT_MLP_DEDUP_F) : 8);
+    int geom_all = a->geometry ? a->geometry : sad::get_option(sad::OPT_MLP_FORCE);
+    const int fcode = geom_all / 1000;                       // 0 = default
+    const int geom_wg = geom_all % 1000;
+    int dedup_f = sad::get_option(sad::OPT_MLP_DEDUP_F) > 0 ? sad::get_option(sad::OPT_MLP_DEDUP_F) : 8;
+    if (fcode >= 1 && fcode <= 7) dedup_f = 1 << fcode;
+    if (sad::get_option(sad::OPT_MLP_NODEDUP)) dedup_f = 1;
     int max_noc = 1, min_noc = 1 << 30;
     for (int l = 0; l < a->L; ++l) {
         p.kp[l] = g.kp[l]; p.np[l] = g.np[l]; p.off[l] = g.off[l];
@@ -716,7 +734,7 @@ SAD_API int sad_mlp_chain_f32(const sad_mlp_args *a, sad_stream_t stream) {
     }
     // ---- narrow 3-layer grouped chains run on the vector ALU (geometry 1 forces, >1 forbids) ----
     {
-        const int gsel = a->geometry ? a->geometry : sad::get_option(sad::OPT_MLP_FORCE);
+        const int gsel = geom_wg;
         const int *d = a->dims;
         const bool all_relu = (a->relu_mask & 7) == 7;
         int shape = 0;
@@ -770,7 +788,7 @@ SAD_API int sad_mlp_chain_f32(const sad_mlp_args *a, sad_stream_t stream) {
     const size_t BUDGET2 = (size_t)(bkb > 0 ? bkb : 78) * 1024, BUDGET1 = 156 * 1024;
     const int rw_min = 1;
     int W = 8, wn_shift = 0, RW = 1, kc = g.kp[0];
-    int geom = a->geometry ? a->geometry : sad::get_option(sad::OPT_MLP_FORCE);
+    int geom = geom_wg;
     if (geom) {
         const int fw = geom / 100, fwns = (geom / 10) % 10, frw = geom % 10;
         const bool ok = (fw == 4 || fw == 8) && (1 << fwns) <= fw && (frw == 1 || frw == 2 || frw == 4) && frw >= rw_min;

@@ -139,11 +139,12 @@ class SADDetector(nn.Module):
         check(lib().sad_candidates_f32(cur_xyz.data_ptr(), c.data_ptr(), B, M3, K, cfg.shift_max,
                                        cfg.r_min, cfg.r_max, self._anchor, cand.data_ptr(),
                                        rad.data_ptr(), main.cuda_stream), "sad_candidates_f32")
-        idxs = ops.ball_query_multi(cfg.cluster_scales, cfg.cluster_nsamples, cur_xyz, cand, rad)
+        idxs, cnts = ops.ball_query_multi(cfg.cluster_scales, cfg.cluster_nsamples, cur_xyz, cand, rad,
+                                          return_counts=True)
         cat = torch.zeros((B, K, self.cluster_cat), dtype=torch.float32, device=points.device)
         off = 0
-        for mlp, idx in zip(self.cluster_branches, idxs):
-            mlp.grouped(cur_xyz, cur_feat, cand, idx, out=cat, col_off=off)
+        for mlp, idx, cnt in zip(self.cluster_branches, idxs, cnts):
+            mlp.grouped(cur_xyz, cur_feat, cand, idx, out=cat, col_off=off, cnt=cnt)
             off += mlp.out_channels
         cfeat = self.cluster_agg.rows(cat)
         # ---- head + decode (SPEC.md §9) -------------------------------------------------------

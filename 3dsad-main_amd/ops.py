@@ -154,11 +154,13 @@ def ball_query(radius: Union[float, torch.Tensor], nsample: int, xyz: torch.Tens
 
 
 def ball_query_multi(radii: Sequence[float], nsamples: Sequence[int], xyz: torch.Tensor,
-                     new_xyz: torch.Tensor, radius_pc: Optional[torch.Tensor] = None
-                     ) -> List[torch.Tensor]:
+                     new_xyz: torch.Tensor, radius_pc: Optional[torch.Tensor] = None,
+                     return_counts: bool = False):
     """Several radii over the same (xyz, new_xyz): d2 is evaluated once per pair.  With
     ``radius_pc`` [B,M] the radius of branch r for centroid (b,m) is radii[r]*radius_pc[b,m]
-    (SPEC.md §8 step 5).  Returns one idx [B,M,nsamples[r]] per radius."""
+    (SPEC.md §8 step 5).  Returns one idx [B,M,nsamples[r]] per radius; with ``return_counts`` also
+    one int32 [B,M] per radius = accepted points capped at nsample (the non-padding rows of each
+    group, which lets the fused MLP skip the padding without scanning idx)."""
     xyz = _need(xyz, "xyz", torch.float32, 3)
     new_xyz = _need(new_xyz, "new_xyz", torch.float32, 3)
     B, N, _ = xyz.shape
@@ -170,6 +172,8 @@ def ball_query_multi(radii: Sequence[float], nsamples: Sequence[int], xyz: torch
     r_arr = (ctypes.c_float * n)(*[float(np.float32(r)) for r in radii])
     s_arr = (ctypes.c_int * n)(*[int(s) for s in nsamples])
     p_arr = (vp * n)(*[o.data_ptr() for o in outs])
+    cnts = [torch.empty((B, M), dtype=torch.int32, device=xyz.device) for _ in nsamples] if return_counts else None
+    c_arr = (vp * n)(*[c.data_ptr() for c in cnts]) if return_counts else None
     pc = None
     if radius_pc is not None:
         radius_pc = _need(radius_pc, "radius_pc", torch.float32, 2)
@@ -182,12 +186,13 @@ def ball_query_multi(radii: Sequence[float], nsamples: Sequence[int], xyz: torch
                          device=xyz.device)
         with _timed("ball_query", f"N{N}M{M}x{n}"):
             check(lib().sad_ball_query_grid_f32(xyz.data_ptr(), new_xyz.data_ptr(), n, r_arr, s_arr, p_arr,
-                                                B, N, M, ws.data_ptr(), _stream()), "sad_ball_query_grid_f32")
-        return outs
+                                                c_arr, B, N, M, ws.data_ptr(), _stream()),
+                  "sad_ball_query_grid_f32")
+        return (outs, cnts) if return_counts else outs
     with _timed("ball_query", f"N{N}M{M}x{n}"):
         check(lib().sad_ball_query_multi_f32(xyz.data_ptr(), new_xyz.data_ptr(), n, r_arr, pc, s_arr,
-                                             p_arr, B, N, M, _stream()), "sad_ball_query_multi_f32")
-    return outs
+                                             p_arr, c_arr, B, N, M, _stream()), "sad_ball_query_multi_f32")
+    return (outs, cnts) if return_counts else outs
 
 
 def knn_query(k: int, xyz: torch.Tensor, new_xyz: torch.Tensor) -> torch.Tensor:
@@ -242,6 +247,7 @@ class PackedMLP:
     # Geometries tried by the autotuner: W*100 + log2(WN)*10 + RW (include/sad_amd.h, sad_mlp_args).
     _CANDIDATES = [w * 100 + n * 10 + r for w in (8, 4) for n in range(4) if (1 << n) <= w
                    for r in (1, 2, 4)]
+    _F_CODES = (2, 4, 5, 6)      # grouped mode: 2^f * R / S groups per workgroup (default f = 3)
 
     def _launch(self, a: MlpArgs) -> None:
         """Enqueue the chain.  With AUTOTUNE on, the first call for a shape times every workgroup
@@ -258,7 +264,7 @@ class PackedMLP:
     def _tune(self, a: MlpArgs) -> int:
         stream = torch.cuda.current_stream()
         best, best_ms = 0, None
-        for code in [0] + self._CANDIDATES:
+        for code in self._CANDIDATES + ([1] if a.idx else []):   # 1 = VALU row-per-lane kernel (narrow chains)
             a.geometry = code
             if lib().sad_mlp_chain_f32(ctypes.byref(a), _stream()) != 0:
                 continue            # does not fit LDS / not valid for this nsample
@@ -272,6 +278,22 @@ class PackedMLP:
             ms = e0.elapsed_time(e1)
             if best_ms is None or ms < best_ms * 0.98:   # prefer earlier entries on ties
                 best, best_ms = code, ms
+        if a.idx and best != 1:   # second sweep: groups per workgroup (how much padding is expected)
+            base = best
+            for f in self._F_CODES:
+                a.geometry = base + 1000 * f
+                if lib().sad_mlp_chain_f32(ctypes.byref(a), _stream()) != 0:
+                    continue
+                stream.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(stream)
+                for _ in range(3):
+                    lib().sad_mlp_chain_f32(ctypes.byref(a), _stream())
+                e1.record(stream)
+                stream.synchronize()
+                ms = e0.elapsed_time(e1)
+                if ms < best_ms * 0.98:
+                    best, best_ms = base + 1000 * f, ms
         return best
 
     def _args(self) -> MlpArgs:
@@ -284,8 +306,8 @@ class PackedMLP:
         return a
 
     def grouped(self, xyz: torch.Tensor, feat_pm: Optional[torch.Tensor], new_xyz: torch.Tensor,
-                idx: torch.Tensor, out: Optional[torch.Tensor] = None, col_off: int = 0
-                ) -> torch.Tensor:
+                idx: torch.Tensor, out: Optional[torch.Tensor] = None, col_off: int = 0,
+                cnt: Optional[torch.Tensor] = None) -> torch.Tensor:
         """Fused group -> MLP -> max over nsample.  xyz [B,N,3]; feat_pm point-major [B,N,C] (or
         None); new_xyz [B,M,3]; idx [B,M,S].  Writes out[:, :, col_off:col_off+C_out] of a
         point-major [B,M,ld_out] buffer (allocated [B,M,C_out] when ``out`` is None).  A caller-
@@ -317,6 +339,11 @@ class PackedMLP:
             raise RuntimeError("grouped chains need a ReLU after every layer (max-pool combine)")
         self._check_out(out, B * M, col_off)
         a.xyz, a.new_xyz, a.idx = xyz.data_ptr(), new_xyz.data_ptr(), idx.data_ptr()
+        if cnt is not None:   # [B,M] int32 from ball_query_multi(return_counts=True)
+            cnt = _need(cnt, "cnt", torch.int32, 2)
+            if tuple(cnt.shape) != (B, M):
+                raise ValueError("cnt must be [B,M]")
+            a.cnt = cnt.data_ptr()
         a.B, a.N, a.M, a.S, a.C = B, N, M, S, C
         a.out, a.ld_out, a.col_off = out.data_ptr(), out.stride(-2), col_off
         self._launch(a)

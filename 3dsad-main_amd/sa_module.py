@@ -57,14 +57,14 @@ class SAModuleMSG(nn.Module):
         """ball query + fused MLP/max for every branch + aggregation -> [B,M,C'] point-major."""
         st = self.stage
         B, M = new_xyz.shape[0], new_xyz.shape[1]
-        idxs = ops.ball_query_multi(radii if radii is not None else st.radii, st.nsamples, xyz,
-                                    new_xyz, radius_pc)
+        idxs, cnts = ops.ball_query_multi(radii if radii is not None else st.radii, st.nsamples, xyz,
+                                          new_xyz, radius_pc, return_counts=True)
         if keep is not None:
             keep["ball_idx"] = idxs
         cat = torch.zeros((B, M, self.cat_channels), dtype=torch.float32, device=xyz.device)
         off = 0
-        for mlp, idx in zip(self.branches, idxs):
-            mlp.grouped(xyz, feat_pm, new_xyz, idx, out=cat, col_off=off)
+        for mlp, idx, cnt in zip(self.branches, idxs, cnts):
+            mlp.grouped(xyz, feat_pm, new_xyz, idx, out=cat, col_off=off, cnt=cnt)
             off += mlp.out_channels
         return self.agg.rows(cat) if self.agg is not None else cat
 

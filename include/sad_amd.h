@@ -69,10 +69,13 @@ int sad_ball_query_f32(const float *xyz, const float *new_xyz, float radius,
 /* Multi-radius form: d2 evaluated once per pair, SPEC.md §3 applied per radius.  radii[n_radii] and
  * nsamples[n_radii] are host arrays, idx[n_radii] a host array of device pointers (idx[r] is
  * [B,M,nsamples[r]]).  With radius_pc != NULL the radius of branch r for centroid (b,m) is
- * radii[r] * radius_pc[b,m] (one binary32 multiply; SPEC.md §8 step 5). */
+ * radii[r] * radius_pc[b,m] (one binary32 multiply; SPEC.md §8 step 5).
+ * cnt (may be NULL, entries may be NULL): host array of device pointers; cnt[r][b,m] receives the
+ * number of accepted points capped at nsamples[r] — the rows of the group that are not padding. */
 int sad_ball_query_multi_f32(const float *xyz, const float *new_xyz, int n_radii,
                              const float *radii, const float *radius_pc, const int *nsamples,
-                             int32_t *const *idx, int B, int N, int M, sad_stream_t stream);
+                             int32_t *const *idx, int32_t *const *cnt, int B, int N, int M,
+                             sad_stream_t stream);
 
 /* Same results as sad_ball_query_multi_f32 with scalar radii, computed through a per-scene uniform
  * grid (cell edge > max radius): each centroid tests only the 27 cells around it and index order is
@@ -80,8 +83,8 @@ int sad_ball_query_multi_f32(const float *xyz, const float *new_xyz, int n_radii
  * aligned device workspace (rebuilt on every call); N <= 65536. */
 size_t sad_ball_query_grid_workspace_bytes(int B, int N);
 int sad_ball_query_grid_f32(const float *xyz, const float *new_xyz, int n_radii, const float *radii,
-                            const int *nsamples, int32_t *const *idx, int B, int N, int M,
-                            void *workspace, sad_stream_t stream);
+                            const int *nsamples, int32_t *const *idx, int32_t *const *cnt, int B,
+                            int N, int M, void *workspace, sad_stream_t stream);
 
 /* SPEC.md §4.  -> idx[B,M,K] sorted by (d2, index); K <= 64, K <= N. */
 int sad_knn_f32(const float *xyz, const float *new_xyz, int B, int N, int M, int K, int32_t *idx,
@@ -101,6 +104,9 @@ typedef struct sad_mlp_args {
     const float *xyz;     /* [B,N,3]                                   (grouped mode) */
     const float *new_xyz; /* [B,M,3]                                   (grouped mode) */
     const int32_t *idx;   /* [B,M,S] or NULL                                          */
+    /* optional [B,M]: leading rows of each group that are not padding (from ball query); NULL =
+     * derived from idx as "last sample that differs from the first, + 1" */
+    const int32_t *cnt;
     /* features: grouped mode: point-major [B,N,C] with row stride ld_feat (NULL iff C == 0);
      * plain mode (idx == NULL): rows [B*M, C] with row stride ld_feat */
     const float *feat;
@@ -122,7 +128,9 @@ typedef struct sad_mlp_args {
     int col_off;
     /* workgroup geometry: 0 = built-in heuristic; else W*100 + log2(WN)*10 + RW with W in {4,8}
      * waves, WN waves along the 32-channel output tiles, RW in {1,2,4} row tiles of 32 rows per
-     * wave.  A geometry that does not fit LDS returns SAD_EUNSUPPORTED (autotuners skip it). */
+     * wave.  A geometry that does not fit LDS returns SAD_EUNSUPPORTED (autotuners skip it).
+     * + 1000*f (f = 1..7): grouped mode, a workgroup owns 2^f * R / S groups (default 8: it assumes
+     * about one row in eight survives the padding removal). */
     int geometry;
 } sad_mlp_args;
 int sad_mlp_chain_f32(const sad_mlp_args *args, sad_stream_t stream);
