@@ -237,6 +237,10 @@ __global__ __launch_bounds__(THREADS) void fps_bucket_kernel(const float *__rest
         u64 g = mine;
         if constexpr (NW == 16) {
             g = row_max_u64(g);
+        } else if constexpr (NW == 8) {
+            g = umax64(g, dpp_u64<0xB1>(g));
+            g = umax64(g, dpp_u64<0x4E>(g));
+            g = umax64(g, dpp_u64<0x141>(g));
         } else {
             g = umax64(g, dpp_u64<0xB1>(g));
             g = umax64(g, dpp_u64<0x4E>(g));
@@ -276,10 +280,23 @@ int launch_fps_bucket(const float *xyz, int B, int N, int M, int32_t *idx, void 
         else if (ppt <= 4) launch_bucket<256, 4>(xyz, perm, B, N, M, idx, st);
         else launch_bucket<256, 8>(xyz, perm, B, N, M, idx, st);
     } else {
-        const int ppt = (N + 1023) / 1024;
-        if (ppt <= 4) launch_bucket<1024, 4>(xyz, perm, B, N, M, idx, st);
-        else if (ppt <= 8) launch_bucket<1024, 8>(xyz, perm, B, N, M, idx, st);
-        else launch_bucket<1024, 16>(xyz, perm, B, N, M, idx, st);
+        // Fewer, fatter waves: the per-step chain (publish, barrier, 16-key arg-max, coordinate
+        // read) is executed by every wave, so with most waves skipping their update the step time
+        // is that chain times the waves sharing a SIMD.  fps_threads option: 1024 / 512 / 256.
+        const int th = get_option(OPT_FPS_THREADS);
+        if (th == 256 && N <= 8192) {
+            if (N <= 4096) launch_bucket<256, 16>(xyz, perm, B, N, M, idx, st);
+            else launch_bucket<256, 32>(xyz, perm, B, N, M, idx, st);
+        } else if (th == 512 || th == 256) {
+            if (N <= 4096) launch_bucket<512, 8>(xyz, perm, B, N, M, idx, st);
+            else if (N <= 8192) launch_bucket<512, 16>(xyz, perm, B, N, M, idx, st);
+            else launch_bucket<512, 32>(xyz, perm, B, N, M, idx, st);
+        } else {
+            const int ppt = (N + 1023) / 1024;
+            if (ppt <= 4) launch_bucket<1024, 4>(xyz, perm, B, N, M, idx, st);
+            else if (ppt <= 8) launch_bucket<1024, 8>(xyz, perm, B, N, M, idx, st);
+            else launch_bucket<1024, 16>(xyz, perm, B, N, M, idx, st);
+        }
     }
     return check_launch("sad_fps_f32 (bucket)");
 }

@@ -732,7 +732,7 @@ SAD_API int sad_mlp_chain_f32(const sad_mlp_args *a, sad_stream_t stream) {
     } else {
         p.cpr = 0; p.cshift = 0;
     }
-    // ---- narrow 3-layer grouped chains run on the vector ALU (geometry 1 forces, >1 forbids) ----
+    // ---- narrow 3-layer grouped chains can run on the vector ALU (geometry 1; autotune tries it) ----
     {
         const int gsel = geom_wg;
         const int *d = a->dims;
@@ -741,7 +741,7 @@ SAD_API int sad_mlp_chain_f32(const sad_mlp_args *a, sad_stream_t stream) {
         if (grouped && a->L == 3 && all_relu && d[0] == 4 && d[1] == 16 && d[2] == 16 && d[3] == 32) shape = 1;
         if (grouped && a->L == 3 && all_relu && d[0] == 4 && d[1] == 32 && d[2] == 32 && d[3] == 64) shape = 2;
         if (gsel == 1 && !shape) return sad::fail(SAD_EUNSUPPORTED, "sad_mlp_chain_f32: no VALU kernel for this chain");
-        if (shape && (gsel == 0 || gsel == 1)) {
+        if (shape && gsel == 1) {   // only on request: it computes the padding rows the tiled kernel skips
             ValuParams v{};
             v.xyz = a->xyz; v.new_xyz = a->new_xyz; v.feat = a->feat; v.idx = a->idx; v.out = a->out;
             for (int l = 0; l < 3; ++l) { v.w[l] = a->packed + g.raw_w[l]; v.b[l] = a->packed + g.raw_b[l]; }

@@ -18,8 +18,8 @@ def timeit(fn, reps=3):
 cur = xyz
 for N, M in ((16384, 4096), (4096, 1024), (1024, 512)):
     ref = None
-    for name, dpp, var in (("shfl", 0, 1), ("dpp", 1, 1), ("key", 0, 2), ("bucket", 0, 3)):
-        _lib.set_option("fps_dpp", dpp); _lib.set_option("fps_variant", var)
+    for name, dpp, var, th in (("key", 0, 2, 0), ("bucket1024", 0, 3, 1024), ("bucket512", 0, 3, 512), ("bucket256", 0, 3, 256)):
+        _lib.set_option("fps_dpp", dpp); _lib.set_option("fps_variant", var); _lib.set_option("fps_threads", th)
         t = timeit(lambda: ops.fps(cur, M))
         idx = ops.fps(cur, M)
         if ref is None: ref = idx
