@@ -142,10 +142,12 @@ class SADDetector(nn.Module):
         idxs, cnts = ops.ball_query_multi(cfg.cluster_scales, cfg.cluster_nsamples, cur_xyz, cand, rad,
                                           return_counts=True)
         cat = torch.zeros((B, K, self.cluster_cat), dtype=torch.float32, device=points.device)
-        off = 0
+        jobs, off = [], 0
         for mlp, idx, cnt in zip(self.cluster_branches, idxs, cnts):
-            mlp.grouped(cur_xyz, cur_feat, cand, idx, out=cat, col_off=off, cnt=cnt)
+            jobs.append(lambda mlp=mlp, idx=idx, cnt=cnt, off=off:
+                        mlp.grouped(cur_xyz, cur_feat, cand, idx, out=cat, col_off=off, cnt=cnt))
             off += mlp.out_channels
+        ops.run_branches(jobs)
         cfeat = self.cluster_agg.rows(cat)
         # ---- head + decode (SPEC.md §9) -------------------------------------------------------
         o = self.head.rows(cfeat)                                        # [B,K,10]

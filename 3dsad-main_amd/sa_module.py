@@ -62,10 +62,12 @@ class SAModuleMSG(nn.Module):
         if keep is not None:
             keep["ball_idx"] = idxs
         cat = torch.zeros((B, M, self.cat_channels), dtype=torch.float32, device=xyz.device)
-        off = 0
+        jobs, off = [], 0
         for mlp, idx, cnt in zip(self.branches, idxs, cnts):
-            mlp.grouped(xyz, feat_pm, new_xyz, idx, out=cat, col_off=off, cnt=cnt)
+            jobs.append(lambda mlp=mlp, idx=idx, cnt=cnt, off=off:
+                        mlp.grouped(xyz, feat_pm, new_xyz, idx, out=cat, col_off=off, cnt=cnt))
             off += mlp.out_channels
+        ops.run_branches(jobs)       # independent branches share the chip
         return self.agg.rows(cat) if self.agg is not None else cat
 
     def forward_pm(self, xyz: torch.Tensor, feat_pm: Optional[torch.Tensor]

@@ -26,6 +26,10 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# HIP multiplexes streams onto 4 hardware queues by default; this pipeline uses the main stream,
+# three sampling streams and two branch streams, and a 7 ms FPS kernel sharing a queue with MLP
+# launches would serialise them.  Must be set before the runtime initialises.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 PEAK_MFMA_F32_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: dense f32 MFMA
 PEAK_HBM_GBPS = 8000.0         # HBM3E spec
@@ -120,6 +124,7 @@ def main():
     ap.add_argument("--cpu-scenes", type=int, default=32)
     ap.add_argument("--no-launch-timing", action="store_true")
     ap.add_argument("--no-autotune", action="store_true", help="use the built-in geometry heuristic")
+    ap.add_argument("--branch-overlap", action="store_true", help="run MSG branches on helper streams")
     ap.add_argument("--opt", action="append", default=[], help="tuning knob key=value (sad_set_option)")
     args = ap.parse_args()
 
@@ -156,6 +161,7 @@ def main():
     points = torch.from_numpy(synth.make_batch(rank * B, B, cfg.n_points)).to(dev)
     torch.cuda.synchronize()
 
+    ops.BRANCH_OVERLAP = args.branch_overlap
     tuned = None if args.no_autotune else det.autotune(points)
 
     def step():

@@ -6,5 +6,7 @@ done
 python - <<'PY'
 import json
 for l in open('gpurun_out/b2.log'):
-    d=json.loads(l); print(d['config']['opts'], d['value'], d['ms_per_step'], 'mlp', d['roofline']['ms_per_step'], d['roofline']['achieved'], 'fps', d['kernels'][0]['ms_per_step'], 'bq', d['kernels'][1]['ms_per_step']); print('   ', {k:(v['ms'],v['executed_gflop'],v['tflops']) for k,v in d['mlp_launches'].items()})
+    d=json.loads(l)
+    if 'roofline' not in d: print('no-timing', d['value'], d['ms_per_step']); continue
+    print(d['config']['opts'], d['value'], d['ms_per_step'], 'mlp', d['roofline']['ms_per_step'], d['roofline']['achieved'], 'fps', d['kernels'][0]['ms_per_step'], 'bq', d['kernels'][1]['ms_per_step']); print('   ', {k:(v['ms'],v['executed_gflop'],v['tflops']) for k,v in d['mlp_launches'].items()})
 PY
