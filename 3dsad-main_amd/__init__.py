@@ -14,7 +14,7 @@ __version__ = "0.1.0"
 _LAZY = {
     "fps": "ops", "ball_query": "ops", "ball_query_multi": "ops", "knn_query": "ops",
     "group_points": "ops", "gather_points": "ops", "gather_xyz": "ops",
-    "mlp_chain": "ops", "PackedMLP": "ops",
+    "mlp_chain": "ops", "PackedMLP": "ops", "nms_bev": "ops",
     "SAModuleMSG": "sa_module", "SAModule": "sa_module", "sa_module": "sa_module",
     "SADDetector": "detector",
     "shard_range": "dist", "all_gather_boxes": "dist", "run_sharded": "dist",

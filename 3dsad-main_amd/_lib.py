@@ -61,6 +61,8 @@ SIGNATURES = {
     "sad_candidates_f32": (ctypes.c_int, [vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                          ctypes.c_float, ctypes.c_float, ctypes.c_float, c_f32p,
                                          vp, vp, vp]),
+    "sad_nms_bev_f32": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_float,
+                                      vp, vp, vp, vp]),
     "sad_decode_boxes_f32": (ctypes.c_int, [vp, vp, ctypes.c_int, ctypes.c_int, c_f32p, vp, vp]),
 }
 

@@ -1,0 +1,210 @@
+// Rotated-box NMS in bird's-eye view for gfx950 (SPEC.md §13; SURVEY.md §8(f) row 1: the step right
+// after the measured path).  No reference source exists (/root/reference/README.md:1-2).
+//
+// One workgroup per scene.  (1) rank the boxes by (score desc, index asc) with an O(K^2) counting
+// rank (K <= 512, one box per thread); (2) thread p computes row p of the suppression matrix —
+// bit q set iff IoU(rank p, rank q) > thr for q > p — with exact Sutherland-Hodgman clipping in
+// binary32 (no contraction; sin/cos by the reproducible routine of SPEC §13, so the CPU oracle and
+// this kernel make identical keep decisions); (3) one wave walks the ranking with 64-bit mask words.
+#include "common.h"
+
+namespace {
+
+constexpr int NMS_MAXK = 512;
+constexpr int NMS_WORDS = NMS_MAXK / 64;
+
+__device__ __forceinline__ void sincos_r(float th, float &s_out, float &c_out) {
+    const float n = rintf(th * 0.63661975f);
+    float r = th - n * 1.5703125f;
+    r = r - n * 4.8375129699707031e-4f;
+    r = r - n * 7.5497899548918861e-8f;
+    const int q = ((int)n) & 3;
+    const float r2 = r * r;
+    float ps = -1.9515295891e-4f;
+    ps = ps * r2; ps = ps + 8.3321608736e-3f;
+    ps = ps * r2; ps = ps + -1.6666654611e-1f;
+    float S = r * r2; S = S * ps; S = r + S;
+    float pc = 2.443315711809948e-5f;
+    pc = pc * r2; pc = pc + -1.388731625493765e-3f;
+    pc = pc * r2; pc = pc + 4.166664568298827e-2f;
+    float C = r2 * r2; C = C * pc;
+    const float h = 0.5f * r2;
+    const float one = 1.0f - h;
+    C = one + C;
+    s_out = q == 0 ? S : (q == 1 ? C : (q == 2 ? -S : -C));
+    c_out = q == 0 ? C : (q == 1 ? -S : (q == 2 ? -C : S));
+}
+
+__device__ __forceinline__ void box_corners(const float *bx, float *cx, float *cy) {
+    float s, c;
+    sincos_r(bx[6], s, c);
+    const float hl = 0.5f * bx[3], hw = 0.5f * bx[4];
+    const float dx[4] = {hl, -hl, -hl, hl}, dy[4] = {hw, hw, -hw, -hw};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        float a = c * dx[k], b = s * dy[k];
+        float t = bx[0] + a;
+        cx[k] = t - b;
+        a = s * dx[k]; b = c * dy[k];
+        t = bx[1] + a;
+        cy[k] = t + b;
+    }
+}
+
+// area of (polygon a) ∩ (convex quad b); corners counter-clockwise; vertex lists live in LDS
+// scratch vertex lists: element v of list L lives at sc[(L*10 + v) * STRIDE] (thread-interleaved LDS)
+template <int STRIDE>
+__device__ float poly_clip_area(const float *ax, const float *ay, const float *bxs, const float *bys,
+                                float *sc) {
+#define px(i) sc[(0 * 10 + (i)) * STRIDE]
+#define py(i) sc[(1 * 10 + (i)) * STRIDE]
+#define qx(i) sc[(2 * 10 + (i)) * STRIDE]
+#define qy(i) sc[(3 * 10 + (i)) * STRIDE]
+    int n = 4;
+    for (int i = 0; i < 4; ++i) { px(i) = ax[i]; py(i) = ay[i]; }
+    for (int e = 0; e < 4 && n > 0; ++e) {
+        const float q0x = bxs[e], q0y = bys[e], q1x = bxs[(e + 1) & 3], q1y = bys[(e + 1) & 3];
+        const float ex = q1x - q0x, ey = q1y - q0y;
+        int m = 0;
+        for (int i = 0; i < n; ++i) {
+            const int ip = (i + n - 1) % n;
+            float a = py(i) - q0y, b = px(i) - q0x;
+            float t1 = ex * a, t2 = ey * b;
+            const float cc = t1 - t2;
+            a = py(ip) - q0y; b = px(ip) - q0x;
+            t1 = ex * a; t2 = ey * b;
+            const float cp = t1 - t2;
+            const bool in_c = cc >= 0.0f, in_p = cp >= 0.0f;
+            if (in_c != in_p) {
+                const float den = cp - cc;
+                const float t = cp / den;
+                float d = px(i) - px(ip);
+                d = t * d;
+                qx(m) = px(ip) + d;
+                d = py(i) - py(ip);
+                d = t * d;
+                qy(m) = py(ip) + d;
+                ++m;
+            }
+            if (in_c) { qx(m) = px(i); qy(m) = py(i); ++m; }
+        }
+        n = m;
+        for (int i = 0; i < n; ++i) { px(i) = qx(i); py(i) = qy(i); }
+    }
+    if (n < 3) return 0.0f;
+    float sum = 0.0f;
+    for (int i = 0; i < n; ++i) {
+        const int j = (i + 1) % n;
+        const float t1 = px(i) * py(j), t2 = px(j) * py(i);
+        const float d = t1 - t2;
+        sum = sum + d;
+    }
+    sum = sum < 0.0f ? -sum : sum;
+    return 0.5f * sum;
+#undef px
+#undef py
+#undef qx
+#undef qy
+}
+
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void nms_bev_kernel(const float *__restrict__ boxes, int K,
+                                                          float iou_thr, float score_thr,
+                                                          int32_t *__restrict__ keep,
+                                                          int32_t *__restrict__ order,
+                                                          int32_t *__restrict__ count) {
+    __shared__ float s_cx[NMS_MAXK][4], s_cy[NMS_MAXK][4], s_area[NMS_MAXK], s_score[NMS_MAXK];
+    __shared__ int s_rank2idx[NMS_MAXK];
+    __shared__ unsigned long long s_mask[NMS_MAXK][NMS_WORDS];
+    __shared__ float s_poly[4 * 10 * THREADS];   // per-thread clipping scratch, thread-interleaved
+    __shared__ int s_n;
+    const int tid = threadIdx.x;
+    const float *bx = boxes + (size_t)blockIdx.x * K * 9;
+    int32_t *kp = keep + (size_t)blockIdx.x * K, *od = order + (size_t)blockIdx.x * K;
+
+    for (int i = tid; i < K; i += THREADS) {
+        s_score[i] = bx[i * 9 + 7];
+        kp[i] = 0;
+        od[i] = -1;
+    }
+    __syncthreads();
+    // 1. rank among the candidates (score >= threshold): score descending, index ascending
+    int nloc = 0;
+    for (int i = tid; i < K; i += THREADS) {
+        const float si = s_score[i];
+        if (si >= score_thr) {
+            int r = 0;
+            for (int j = 0; j < K; ++j) {
+                const float sj = s_score[j];
+                r += (sj >= score_thr) && (sj > si || (sj == si && j < i));
+            }
+            s_rank2idx[r] = i;
+            ++nloc;
+        }
+    }
+    if (tid == 0) s_n = 0;
+    __syncthreads();
+    atomicAdd(&s_n, nloc);
+    __syncthreads();
+    const int n = s_n;
+    // corners and areas in rank order
+    for (int p = tid; p < n; p += THREADS) {
+        const float *b = bx + (size_t)s_rank2idx[p] * 9;
+        float cx[4], cy[4];
+        box_corners(b, cx, cy);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { s_cx[p][k] = cx[k]; s_cy[p][k] = cy[k]; }
+        s_area[p] = b[3] * b[4];
+    }
+    __syncthreads();
+    // 2. suppression matrix
+    for (int p = tid; p < n; p += THREADS) {
+        unsigned long long w[NMS_WORDS];
+#pragma unroll
+        for (int k = 0; k < NMS_WORDS; ++k) w[k] = 0ull;
+        for (int q = p + 1; q < n; ++q) {
+            const float inter = poly_clip_area<THREADS>(s_cx[p], s_cy[p], s_cx[q], s_cy[q], s_poly + tid);
+            float den = s_area[p] + s_area[q];
+            den = den - inter;
+            const float iou = den > 0.0f ? inter / den : 0.0f;
+            if (iou > iou_thr) {
+#pragma unroll
+                for (int k = 0; k < NMS_WORDS; ++k)
+                    if ((q >> 6) == k) w[k] |= 1ull << (q & 63);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < NMS_WORDS; ++k) s_mask[p][k] = w[k];
+    }
+    __syncthreads();
+    // 3. walk the ranking (lanes 0..NMS_WORDS-1 of wave 0 hold one removed-word each)
+    if (tid < 64) {
+        unsigned long long removed = 0ull;
+        int nk = 0;
+        for (int p = 0; p < n; ++p) {
+            const unsigned long long word = __shfl(removed, p >> 6, 64);
+            if (!((word >> (p & 63)) & 1ull)) {            // wave-uniform
+                if (tid == 0) {
+                    const int i = s_rank2idx[p];
+                    od[nk] = i;
+                    kp[i] = 1;
+                }
+                ++nk;
+                if (tid < NMS_WORDS) removed |= s_mask[p][tid];
+            }
+        }
+        if (tid == 0) count[blockIdx.x] = nk;
+    }
+}
+
+}  // namespace
+
+SAD_API int sad_nms_bev_f32(const float *boxes, int B, int K, float iou_thr, float score_thr,
+                            int32_t *keep, int32_t *order, int32_t *count, sad_stream_t stream) {
+    SAD_REQUIRE(boxes && keep && order && count, "sad_nms_bev_f32: NULL pointer");
+    SAD_REQUIRE(B >= 1 && K >= 1, "sad_nms_bev_f32: need B,K >= 1");
+    if (K > NMS_MAXK) return sad::fail(SAD_EUNSUPPORTED, "sad_nms_bev_f32: K=%d > %d", K, NMS_MAXK);
+    hipLaunchKernelGGL((nms_bev_kernel<256>), dim3(B), dim3(256), 0, (hipStream_t)stream, boxes, K, iou_thr,
+                       score_thr, keep, order, count);
+    return sad::check_launch("sad_nms_bev_f32");
+}

@@ -143,6 +143,12 @@ int sad_candidates_f32(const float *xyz3, const float *c, int B, int M3, int K, 
 int sad_decode_boxes_f32(const float *cand, const float *o, int B, int K, const float *anchors,
                          float *boxes, sad_stream_t stream);
 
+/* SPEC.md §13.  Rotated-box NMS in bird's-eye view, one scene per workgroup.
+ * boxes[B,K,9] (x,y,z,l,w,h,yaw,score,label), K <= 512 -> keep[B,K] (0/1), order[B,K] (kept indices
+ * in rank order, -1 padded), count[B]. */
+int sad_nms_bev_f32(const float *boxes, int B, int K, float iou_thr, float score_thr, int32_t *keep,
+                    int32_t *order, int32_t *count, sad_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -204,6 +204,37 @@ def decode_boxes(cand, o, anchors):
     return boxes
 
 
+def sincos_r(theta):
+    """SPEC.md §13 reproducible sin/cos."""
+    th, pt = _f(np.ravel(theta))
+    s = np.empty_like(th)
+    c = np.empty_like(th)
+    lib().orc_sincos_r(pt, th.size, s.ctypes.data_as(_f32p), c.ctypes.data_as(_f32p))
+    return s.reshape(np.shape(theta)), c.reshape(np.shape(theta))
+
+
+def iou_bev(a, b):
+    """SPEC.md §13: rotated BEV IoU of box pairs a[i], b[i] (rows of 9 floats)."""
+    a, pa = _f(np.reshape(a, (-1, 9)))
+    b, pb = _f(np.reshape(b, (-1, 9)))
+    out = np.empty((a.shape[0],), np.float32)
+    lib().orc_iou_bev(pa, pb, a.shape[0], out.ctypes.data_as(_f32p))
+    return out
+
+
+def nms_bev(boxes, iou_thr, score_thr=0.0):
+    """SPEC.md §13.  boxes [B,K,9] -> (keep [B,K] int32, order [B,K] int32 (-1 padded), count [B])."""
+    boxes, pb = _f(boxes)
+    B, K, _ = boxes.shape
+    keep = np.empty((B, K), np.int32)
+    order = np.empty((B, K), np.int32)
+    count = np.empty((B,), np.int32)
+    lib().orc_nms_bev(pb, B, K, ctypes.c_float(float(np.float32(iou_thr))),
+                      ctypes.c_float(float(np.float32(score_thr))), keep.ctypes.data_as(_i32p),
+                      order.ctypes.data_as(_i32p), count.ctypes.data_as(_i32p))
+    return keep, order, count
+
+
 # ----------------------------------------------------------------------------------------------
 # Model-level restatement (SPEC.md §7-§9): the CPU path the GPU detector is compared with.
 # ----------------------------------------------------------------------------------------------

@@ -358,3 +358,141 @@ ORC_API void orc_decode_boxes(const float *cand, const float *o, int B, int K, c
         bx[8] = (float)label;
     }
 }
+
+/* ------------------------------------------------------------------------------------------
+ * SPEC.md §13 — rotated-box NMS in bird's-eye view.
+ * ---------------------------------------------------------------------------------------- */
+static void sincos_r(float th, float *s_out, float *c_out) {
+    float n = rintf(th * 0.63661975f);
+    float r = th - n * 1.5703125f;
+    r = r - n * 4.8375129699707031e-4f;
+    r = r - n * 7.5497899548918861e-8f;
+    int q = ((int)n) & 3;
+    float r2 = r * r;
+    float ps = -1.9515295891e-4f;
+    ps = ps * r2; ps = ps + 8.3321608736e-3f;
+    ps = ps * r2; ps = ps + -1.6666654611e-1f;
+    float S = r * r2; S = S * ps; S = r + S;
+    float pc = 2.443315711809948e-5f;
+    pc = pc * r2; pc = pc + -1.388731625493765e-3f;
+    pc = pc * r2; pc = pc + 4.166664568298827e-2f;
+    float C = r2 * r2; C = C * pc;
+    float h = 0.5f * r2;
+    float one = 1.0f - h;
+    C = one + C;
+    switch (q) {
+        case 0: *s_out = S; *c_out = C; break;
+        case 1: *s_out = C; *c_out = -S; break;
+        case 2: *s_out = -S; *c_out = -C; break;
+        default: *s_out = -C; *c_out = S; break;
+    }
+}
+
+static void box_corners(const float *bx, float *cx, float *cy) {
+    float s, c;
+    sincos_r(bx[6], &s, &c);
+    const float hl = 0.5f * bx[3], hw = 0.5f * bx[4];
+    const float dx[4] = {hl, -hl, -hl, hl}, dy[4] = {hw, hw, -hw, -hw};
+    for (int k = 0; k < 4; ++k) {
+        float a = c * dx[k], b = s * dy[k];
+        float t = bx[0] + a;
+        cx[k] = t - b;
+        a = s * dx[k]; b = c * dy[k];
+        t = bx[1] + a;
+        cy[k] = t + b;
+    }
+}
+
+static float poly_clip_area(const float *ax, const float *ay, const float *bxs, const float *bys) {
+    float px[16], py[16], qx[16], qy[16];
+    int n = 4;
+    for (int i = 0; i < 4; ++i) { px[i] = ax[i]; py[i] = ay[i]; }
+    for (int e = 0; e < 4 && n > 0; ++e) {
+        const float q0x = bxs[e], q0y = bys[e], q1x = bxs[(e + 1) & 3], q1y = bys[(e + 1) & 3];
+        const float ex = q1x - q0x, ey = q1y - q0y;
+        int m = 0;
+        for (int i = 0; i < n; ++i) {
+            const int ip = (i + n - 1) % n;
+            float a = py[i] - q0y, b = px[i] - q0x;
+            float t1 = ex * a, t2 = ey * b;
+            const float cc = t1 - t2;
+            a = py[ip] - q0y; b = px[ip] - q0x;
+            t1 = ex * a; t2 = ey * b;
+            const float cp = t1 - t2;
+            const int in_c = cc >= 0.0f, in_p = cp >= 0.0f;
+            if (in_c != in_p) {
+                const float den = cp - cc;
+                const float t = cp / den;
+                float d = px[i] - px[ip];
+                d = t * d;
+                qx[m] = px[ip] + d;
+                d = py[i] - py[ip];
+                d = t * d;
+                qy[m] = py[ip] + d;
+                ++m;
+            }
+            if (in_c) { qx[m] = px[i]; qy[m] = py[i]; ++m; }
+        }
+        n = m;
+        for (int i = 0; i < n; ++i) { px[i] = qx[i]; py[i] = qy[i]; }
+    }
+    if (n < 3) return 0.0f;
+    float sum = 0.0f;
+    for (int i = 0; i < n; ++i) {
+        const int j = (i + 1) % n;
+        const float t1 = px[i] * py[j], t2 = px[j] * py[i];
+        const float d = t1 - t2;
+        sum = sum + d;
+    }
+    sum = sum < 0.0f ? -sum : sum;
+    return 0.5f * sum;
+}
+
+static float iou_bev(const float *a, const float *b) {
+    float ax[4], ay[4], bx[4], by[4];
+    box_corners(a, ax, ay);
+    box_corners(b, bx, by);
+    const float inter = poly_clip_area(ax, ay, bx, by);
+    const float aa = a[3] * a[4], ab = b[3] * b[4];
+    float den = aa + ab;
+    den = den - inter;
+    if (!(den > 0.0f)) return 0.0f;
+    return inter / den;
+}
+
+ORC_API void orc_sincos_r(const float *th, int n, float *s, float *c) {
+    for (int i = 0; i < n; ++i) sincos_r(th[i], s + i, c + i);
+}
+
+ORC_API void orc_iou_bev(const float *a, const float *b, int n, float *out) {
+    for (int i = 0; i < n; ++i) out[i] = iou_bev(a + (size_t)i * 9, b + (size_t)i * 9);
+}
+
+ORC_API void orc_nms_bev(const float *boxes, int B, int K, float iou_thr, float score_thr,
+                         int32_t *keep, int32_t *order, int32_t *count) {
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int b = 0; b < B; ++b) {
+        const float *bx = boxes + (size_t)b * K * 9;
+        int32_t *kp = keep + (size_t)b * K, *od = order + (size_t)b * K;
+        int *rank = (int *)malloc(sizeof(int) * (size_t)K);
+        int n = 0;
+        for (int i = 0; i < K; ++i) { kp[i] = 0; od[i] = -1; if (bx[i * 9 + 7] >= score_thr) rank[n++] = i; }
+        /* insertion sort: score descending, index ascending (stable) */
+        for (int i = 1; i < n; ++i) {
+            const int v = rank[i];
+            int j = i;
+            while (j > 0 && bx[rank[j - 1] * 9 + 7] < bx[v * 9 + 7]) { rank[j] = rank[j - 1]; --j; }
+            rank[j] = v;
+        }
+        int nk = 0;
+        for (int r = 0; r < n; ++r) {
+            const int i = rank[r];
+            int ok = 1;
+            for (int k = 0; k < nk && ok; ++k)
+                if (iou_bev(bx + (size_t)od[k] * 9, bx + (size_t)i * 9) > iou_thr) ok = 0;
+            if (ok) { od[nk++] = i; kp[i] = 1; }
+        }
+        count[b] = nk;
+        free(rank);
+    }
+}

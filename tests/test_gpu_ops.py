@@ -241,3 +241,38 @@ def test_group_points_bf16(sad, dev):
     got = ops.group_points(feat, idx)
     want = torch.gather(feat[:, :, None, :].expand(-1, -1, 40, -1), 3, idx.long()[:, None].expand(-1, 8, -1, -1))
     assert torch.equal(got, want)
+
+
+# ---------------------------------------------------------------- rotated NMS (SPEC.md §13)
+@pytest.mark.parametrize("B,K,thr,sthr", [(4, 256, 0.1, 0.0), (2, 512, 0.3, 0.25), (3, 77, 0.01, 0.0), (1, 1, 0.5, 0.0)])
+def test_nms_bev_parity(orc, sad, dev, B, K, thr, sthr):
+    """Keep decisions are index work: bit-exact vs the oracle (same reproducible sin/cos, same
+    clipping arithmetic, no contraction)."""
+    from sad_amd import ops
+    from test_oracle import _random_boxes
+    bx = _random_boxes(K + B, B, K, extent=40.0 if K > 100 else 12.0)
+    if K > 10:
+        bx[0, 5, 7] = bx[0, 9, 7]                           # score tie
+        bx[-1, :, 7] = 0.5                                  # a scene where every score ties
+    keep, order, count = ops.nms_bev(_t(bx, dev), thr, sthr)
+    okeep, oorder, ocount = orc.nms_bev(bx, thr, sthr)
+    np.testing.assert_array_equal(count.cpu().numpy(), ocount)
+    np.testing.assert_array_equal(order.cpu().numpy(), oorder)
+    np.testing.assert_array_equal(keep.cpu().numpy(), okeep)
+    if K > 100:
+        assert (ocount < K).any()                           # suppression actually happened
+
+
+def test_nms_on_detector_boxes(orc, sad, dev):
+    """NMS of the boxes the TINY detector produces (the step after the measured path)."""
+    import torch
+    from sad_amd import config, ops, synth
+    from sad_amd.detector import SADDetector
+    cfg = config.TINY
+    det = SADDetector(cfg, synth.make_weights(cfg, 0), dev)
+    boxes = det(_t(synth.make_tiny_batch(0, 2, cfg.n_points), dev))
+    keep, order, count = ops.nms_bev(boxes, 0.1, 0.0)
+    torch.cuda.synchronize()
+    okeep, oorder, ocount = orc.nms_bev(boxes.cpu().numpy(), 0.1, 0.0)
+    np.testing.assert_array_equal(order.cpu().numpy(), oorder)
+    np.testing.assert_array_equal(count.cpu().numpy(), ocount)

@@ -318,3 +318,86 @@ def test_golden_tiny_detector(orc):
     np.testing.assert_array_equal(tr["cluster"]["ball_idx"][1], g["cl_idx1"])
     np.testing.assert_allclose(boxes, g["boxes"], rtol=1e-6, atol=1e-6)  # expf may differ per libm
     assert g["radius"].std() > 0.01  # the adaptive radius really varies per candidate
+
+
+# ---------------------------------------------------------------- rotated NMS (SPEC.md §13)
+def _random_boxes(seed, B, K, extent=30.0):
+    rng = np.random.default_rng(seed)
+    bx = np.zeros((B, K, 9), np.float32)
+    bx[..., 0:2] = rng.uniform(0, extent, (B, K, 2))
+    bx[..., 2] = rng.uniform(-2, 0, (B, K))
+    bx[..., 3] = rng.uniform(2.5, 5.0, (B, K))
+    bx[..., 4] = rng.uniform(1.2, 2.2, (B, K))
+    bx[..., 5] = rng.uniform(1.2, 2.0, (B, K))
+    bx[..., 6] = rng.uniform(-7, 7, (B, K))
+    bx[..., 7] = rng.uniform(0, 1, (B, K))
+    bx[..., 8] = rng.integers(0, 3, (B, K))
+    return bx
+
+
+def _iou_float64(a, b):
+    """Independent restatement: float64 corners from numpy sin/cos + Sutherland-Hodgman."""
+    def corners(q):
+        c, s = np.cos(np.float64(q[6])), np.sin(np.float64(q[6]))
+        d = np.array([[1, 1], [-1, 1], [-1, -1], [1, -1]], np.float64) * np.array([q[3], q[4]], np.float64) / 2
+        return np.stack([q[0] + c * d[:, 0] - s * d[:, 1], q[1] + s * d[:, 0] + c * d[:, 1]], 1)
+    poly, clip = corners(a), corners(b)
+    for e in range(4):
+        q0, q1 = clip[e], clip[(e + 1) % 4]
+        out = []
+        for i in range(len(poly)):
+            cur, prev = poly[i], poly[i - 1]
+            cc = (q1[0] - q0[0]) * (cur[1] - q0[1]) - (q1[1] - q0[1]) * (cur[0] - q0[0])
+            cp = (q1[0] - q0[0]) * (prev[1] - q0[1]) - (q1[1] - q0[1]) * (prev[0] - q0[0])
+            if (cc >= 0) != (cp >= 0):
+                out.append(prev + cp / (cp - cc) * (cur - prev))
+            if cc >= 0:
+                out.append(cur)
+        poly = np.array(out) if out else np.zeros((0, 2))
+        if len(poly) == 0:
+            break
+    inter = 0.0
+    if len(poly) >= 3:
+        x, y = poly[:, 0], poly[:, 1]
+        inter = 0.5 * abs(np.sum(x * np.roll(y, -1) - np.roll(x, -1) * y))
+    return inter / (a[3] * a[4] + b[3] * b[4] - inter)
+
+
+def test_sincos_r_accuracy(orc):
+    th = np.linspace(-50, 50, 20001).astype(np.float32)
+    s, c = orc.sincos_r(th)
+    assert np.abs(s - np.sin(th.astype(np.float64))).max() < 3e-7
+    assert np.abs(c - np.cos(th.astype(np.float64))).max() < 3e-7
+
+
+def test_iou_bev_vs_float64_and_known_answers(orc):
+    bx = _random_boxes(1, 1, 400, extent=12.0)[0]
+    a, b = bx[:200], bx[200:]
+    got = orc.iou_bev(a, b)
+    want = np.array([_iou_float64(p, q) for p, q in zip(a, b)])
+    assert (want > 0.05).sum() >= 15                      # the sample really contains overlaps
+    np.testing.assert_allclose(got, want, atol=2e-5)
+    unit = np.array([[0, 0, 0, 4, 2, 1, 0, 1, 0]], np.float32)
+    assert orc.iou_bev(unit, unit)[0] == 1.0
+    assert orc.iou_bev(unit, unit + np.array([10, 0, 0, 0, 0, 0, 0, 0, 0], np.float32))[0] == 0.0
+    np.testing.assert_allclose(orc.iou_bev(unit, unit + np.array([2, 0, 0, 0, 0, 0, 0, 0, 0], np.float32)), [1 / 3], rtol=1e-6)
+    rot = unit.copy()
+    rot[0, 6] = np.pi / 2
+    np.testing.assert_allclose(orc.iou_bev(unit, rot), [4 / 12], rtol=1e-5)
+
+
+def test_nms_bev_vs_python(orc):
+    bx = _random_boxes(2, 3, 120, extent=25.0)
+    bx[1, 5, 7] = bx[1, 9, 7]                               # exact score tie -> lower index first
+    keep, order, count = orc.nms_bev(bx, 0.1, 0.2)
+    for b in range(3):
+        cand = [i for i in range(120) if bx[b, i, 7] >= np.float32(0.2)]
+        cand.sort(key=lambda i: (-bx[b, i, 7], i))
+        kept = []
+        for i in cand:
+            if all(orc.iou_bev(bx[b, k], bx[b, i])[0] <= np.float32(0.1) for k in kept):
+                kept.append(i)
+        assert count[b] == len(kept) and order[b, :len(kept)].tolist() == kept
+        assert (order[b, len(kept):] == -1).all()
+        assert keep[b].sum() == len(kept) and all(keep[b, i] == 1 for i in kept)
+        assert 0 < len(kept) < len(cand)                    # something was suppressed
