@@ -22,7 +22,7 @@ from .sa_module import SAModuleMSG
 
 class SADDetector(nn.Module):
     def __init__(self, cfg: DetectorConfig, weights: dict, device, overlap_fps: bool = True,
-                 n_fps_streams: int = 3):
+                 n_fps_streams: int = 4, n_main_streams: int = 2):
         super().__init__()
         self.cfg = cfg
         self.device = torch.device(device)
@@ -55,6 +55,25 @@ class SADDetector(nn.Module):
         self._sides = ([torch.cuda.Stream(device=self.device) for _ in range(max(1, n_fps_streams))]
                        if overlap_fps else [])
         self._calls = 0
+        # submit(): consecutive batches alternate between main streams, so the tail of one batch's
+        # kernels (few workgroups left, most CUs idle) overlaps the next batch's kernels.
+        self._mains = [torch.cuda.Stream(device=self.device) for _ in range(max(1, n_main_streams))]
+        self._submits = 0
+
+    def submit(self, points: torch.Tensor, post=None):
+        """Throughput entry point: enqueue one batch on the next main stream (round-robin) and
+        return (result, done_event) without waiting.  ``points`` must already be resident and not
+        be written by queued work (same promise as ``input_ready=True``).  ``post(boxes)`` runs on
+        the same stream (e.g. the all_gather of a sharded job)."""
+        st = self._mains[self._submits % len(self._mains)]
+        self._submits += 1
+        with torch.cuda.stream(st):
+            out = self.forward(points, input_ready=True)
+            if post is not None:
+                out = post(out)
+            ev = torch.cuda.Event()
+            ev.record(st)
+        return out, ev
 
     def autotune(self, points: torch.Tensor) -> dict:
         """One synchronous forward pass during which every MLP launch times its workgroup

@@ -119,7 +119,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=32, help="scenes per GPU per step")
     ap.add_argument("--no-overlap", action="store_true", help="run FPS on the main stream")
-    ap.add_argument("--fps-streams", type=int, default=3, help="sampling streams used round-robin")
+    ap.add_argument("--fps-streams", type=int, default=4, help="sampling streams used round-robin")
+    ap.add_argument("--main-streams", type=int, default=2, help="main streams used round-robin by consecutive steps")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-scenes", type=int, default=32)
     ap.add_argument("--no-launch-timing", action="store_true")
@@ -156,7 +157,8 @@ def main():
         _lib.set_option(k, int(v))
     cfg = config.KITTI
     weights = synth.make_weights(cfg, 0)
-    det = SADDetector(cfg, weights, dev, overlap_fps=not args.no_overlap, n_fps_streams=args.fps_streams)
+    det = SADDetector(cfg, weights, dev, overlap_fps=not args.no_overlap, n_fps_streams=args.fps_streams,
+                      n_main_streams=args.main_streams)
     B = args.batch
     points = torch.from_numpy(synth.make_batch(rank * B, B, cfg.n_points)).to(dev)
     torch.cuda.synchronize()
@@ -165,8 +167,8 @@ def main():
     tuned = None if args.no_autotune else det.autotune(points)
 
     def step():
-        boxes = det(points, input_ready=True)
-        return all_gather_boxes(boxes)
+        out, _ = det.submit(points, post=all_gather_boxes)
+        return out
 
     for _ in range(args.warmup):
         out = step()
@@ -212,7 +214,7 @@ def main():
                                    "3-stage multi-radius SA backbone fp32 + size-adaptive cluster layer + box head",
                        "scenes_per_gpu": B, "global_batch": world * B, "n_points": cfg.n_points,
                        "parallelism": f"batch-sharded x{world}, one all_gather of boxes",
-                       "fps_overlap": not args.no_overlap, "fps_streams": args.fps_streams, "opts": args.opt,
+                       "fps_overlap": not args.no_overlap, "fps_streams": args.fps_streams, "main_streams": args.main_streams, "opts": args.opt,
                        "mlp_geometry": tuned if tuned is not None else "heuristic"},
         }
         if log:
