@@ -791,7 +791,7 @@ SAD_API int sad_mlp_chain_f32(const sad_mlp_args *a, sad_stream_t stream) {
     int geom = geom_wg;
     if (geom) {
         const int fw = geom / 100, fwns = (geom / 10) % 10, frw = geom % 10;
-        const bool ok = (fw == 4 || fw == 8) && (1 << fwns) <= fw && (frw == 1 || frw == 2 || frw == 4) && frw >= rw_min;
+        const bool ok = (fw == 4 || fw == 8 || fw == 16) && (1 << fwns) <= fw && (frw == 1 || frw == 2 || frw == 4) && frw >= rw_min;
         if (!ok) return sad::fail(SAD_EUNSUPPORTED, "sad_mlp_chain_f32: geometry %d is not valid here", geom);
         W = fw; wn_shift = fwns; RW = frw;
         if (lds_bytes(W, wn_shift, RW, kc) > BUDGET1) {
@@ -840,6 +840,11 @@ SAD_API int sad_mlp_chain_f32(const sad_mlp_args *a, sad_stream_t stream) {
     const long long nblocks = grouped ? (p.total_groups + p.G - 1) / p.G : (p.total_rows + R - 1) / R;
     SAD_REQUIRE(nblocks < (1LL << 31), "sad_mlp_chain_f32: too many workgroups");
     hipStream_t st = (hipStream_t)stream;
+    if (W == 16) {
+        if (RW == 1) return launch_mlp<16, 1>(p, lds, nblocks, st);
+        if (RW == 2) return launch_mlp<16, 2>(p, lds, nblocks, st);
+        return sad::fail(SAD_EUNSUPPORTED, "sad_mlp_chain_f32: 16 waves support RW 1 or 2");
+    }
     if (W == 8) {
         if (RW == 1) return launch_mlp<8, 1>(p, lds, nblocks, st);
         if (RW == 2) return launch_mlp<8, 2>(p, lds, nblocks, st);
