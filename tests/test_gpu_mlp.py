@@ -244,3 +244,35 @@ def test_detector_kitti_stagewise(orc, sad, dev):
         _close(got, onf, f"{name} features (16384-pt scene)")
         xyz, feat = onx, got      # continue from the GPU's features
     assert boxes.shape == (1, cfg.n_cand, 9) and bool(torch.isfinite(boxes).all())
+
+
+def test_random_shapes_grouped_mlp(orc, sad, dev):
+    """25 random chains (1-4 layers, odd widths, any nsample 1..64, with/without features, counts
+    from the ball query or derived from idx) vs the oracle: <= 1e-4 required, bit-exact observed."""
+    from sad_amd import ops, synth
+    rng = np.random.default_rng(77)
+    exact = 0
+    for trial in range(25):
+        B = int(rng.integers(1, 3))
+        N = int(rng.choice([300, 1000, 2500]))
+        M = int(rng.integers(5, 200))
+        S = int(rng.integers(1, 65))
+        C = int(rng.choice([0, 1, 3, 4, 16, 37, 64]))
+        L = int(rng.integers(1, 5))
+        dims = [C + 3] + [int(rng.choice([8, 16, 24, 40, 64, 100, 128])) for _ in range(L)]
+        xyz = rng.uniform(0, 2, (B, N, 3)).astype(np.float32)
+        feat = rng.normal(size=(B, N, C)).astype(np.float32) if C else None
+        new_xyz = orc.gather_xyz(xyz, orc.fps(xyz, M))
+        r = float(rng.uniform(0.1, 0.8))
+        layers = synth.make_mlp_weights(dims, rng)
+        X, Cn = _t(xyz, dev), _t(new_xyz, dev)
+        F = _t(feat, dev) if C else None
+        idxs, cnts = ops.ball_query_multi((r,), (S,), X, Cn, return_counts=True)
+        want = orc.sa_group_mlp_max(xyz, feat, new_xyz, idxs[0].cpu().numpy(), layers)
+        mlp = ops.PackedMLP(layers, True, dev)
+        got1 = mlp.grouped(X, F, Cn, idxs[0], cnt=cnts[0]).cpu().numpy()
+        got2 = mlp.grouped(X, F, Cn, idxs[0]).cpu().numpy()
+        _close(got1, want, f"trial {trial} dims={dims} S={S} (counts from ball query)")
+        assert np.array_equal(got1, got2), f"trial {trial}: counts from idx give a different result"
+        exact += int(np.array_equal(got1, want))
+    assert exact == 25, f"only {exact}/25 random chains were bit-exact"

@@ -276,3 +276,50 @@ def test_nms_on_detector_boxes(orc, sad, dev):
     okeep, oorder, ocount = orc.nms_bev(boxes.cpu().numpy(), 0.1, 0.0)
     np.testing.assert_array_equal(order.cpu().numpy(), oorder)
     np.testing.assert_array_equal(count.cpu().numpy(), ocount)
+
+
+# ---------------------------------------------------------------- randomized shapes
+def test_random_shapes_index_ops(orc, sad, dev):
+    """40 random (B, N, M, radius, nsample, k) draws through fps / ball_query / knn / gather on clustered
+    data with duplicates: every index must equal the oracle's."""
+    from sad_amd import ops
+    rng = np.random.default_rng(2024)
+    for trial in range(40):
+        B = int(rng.integers(1, 4))
+        N = int(rng.choice([17, 64, 200, 777, 1500, 2048, 2500, 5000]))
+        M = int(rng.integers(1, min(N, 400) + 1))
+        centers = rng.uniform(0, 5, (B, 8, 3))
+        which = rng.integers(0, 8, (B, N))
+        xyz = (np.take_along_axis(centers, which[..., None].repeat(3, -1), 1) +
+               rng.normal(0, rng.uniform(0.05, 0.6), (B, N, 3))).astype(np.float32)
+        if N > 30:
+            xyz[:, 20:25] = xyz[:, 3:4]                       # duplicates
+        X = _t(xyz, dev)
+        fidx = ops.fps(X, M)
+        ofidx = orc.fps(xyz, M)
+        np.testing.assert_array_equal(fidx.cpu().numpy(), ofidx, err_msg=f"fps trial {trial} N={N} M={M}")
+        new_xyz = orc.gather_xyz(xyz, ofidx)
+        np.testing.assert_array_equal(ops.gather_xyz(X, fidx).cpu().numpy(), new_xyz)
+        C = _t(new_xyz, dev)
+        S = int(rng.integers(1, 65))
+        r = float(rng.uniform(0.05, 1.5))
+        got = ops.ball_query(r, S, X, C).cpu().numpy()
+        np.testing.assert_array_equal(got, orc.ball_query(r, S, xyz, new_xyz), err_msg=f"bq trial {trial} N={N} r={r} S={S}")
+        radii = tuple(float(v) for v in rng.uniform(0.05, 1.5, 3))
+        ns = tuple(int(v) for v in rng.integers(1, 65, 3))
+        outs, cnts = ops.ball_query_multi(radii, ns, X, C, return_counts=True)
+        for o, c, rr, s in zip(outs, cnts, radii, ns):
+            want = orc.ball_query(rr, s, xyz, new_xyz)
+            np.testing.assert_array_equal(o.cpu().numpy(), want, err_msg=f"multi trial {trial} N={N} r={rr} S={s}")
+            # count = accepted points capped at nsample = 1 + last position differing from the first
+            d = want != want[..., :1]
+            wc = np.where(d.any(-1), d.shape[-1] - np.argmax(d[..., ::-1], -1), 1)
+            empty_or_one = ~d.any(-1)
+            cc = c.cpu().numpy()
+            assert ((cc == wc) | (empty_or_one & (cc <= 1))).all()
+        rad_pc = rng.uniform(0.05, 1.5, (B, M)).astype(np.float32)
+        got = ops.ball_query(_t(rad_pc, dev), S, X, C).cpu().numpy()
+        np.testing.assert_array_equal(got, orc.ball_query(rad_pc, S, xyz, new_xyz), err_msg=f"adaptive trial {trial}")
+        k = int(rng.integers(1, min(64, N) + 1))
+        np.testing.assert_array_equal(ops.knn_query(k, X, C).cpu().numpy(), orc.knn_query(k, xyz, new_xyz),
+                                      err_msg=f"knn trial {trial} N={N} k={k}")
