@@ -21,6 +21,10 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+#ifndef SAD_MLP_BDEPTH
+#define SAD_MLP_BDEPTH 2
+#endif
+
 constexpr int MAXL = SAD_MAX_LAYERS;
 
 struct MlpParams {
@@ -124,32 +128,37 @@ __device__ __forceinline__ void mma_ktile(f32x16 (&acc)[RW], const float4 *__res
     float4 a[D];
 #pragma unroll
     for (int u = 0; u < D; ++u) a[u] = lda(af, u, n4);
-    BFrag<RW> b[2] = {ldb<RW>(bp, 0, n4, kbs), ldb<RW>(bp, 1, n4, kbs)};
+    constexpr int BD = SAD_MLP_BDEPTH <= 2 || RW > 2 ? 2 : 4;   // B ring depth (LDS prefetch distance)
+    BFrag<RW> b[BD];
+#pragma unroll
+    for (int u = 0; u < BD; ++u) b[u] = ldb<RW>(bp, u, n4, kbs);
     int t = 0;
     if (n4 >= D) {
         // Opaque touch: keeps InstCombine from folding the loop PHIs of loads into "load at use".
 #pragma unroll
         for (int u = 0; u < D; ++u) asm volatile("" : "+v"(a[u].x));
 #pragma unroll
-        for (int rt = 0; rt < RW; ++rt) asm volatile("" : "+v"(b[0].v[rt].x), "+v"(b[1].v[rt].x));
+        for (int u = 0; u < BD; ++u)
+#pragma unroll
+            for (int rt = 0; rt < RW; ++rt) asm volatile("" : "+v"(b[u].v[rt].x));
         for (; t + D <= n4; t += D) {
 #pragma unroll
             for (int u = 0; u < D; ++u) {
-                mma4<RW>(acc, a[u], b[u & 1]);
+                mma4<RW>(acc, a[u], b[u % BD]);
                 a[u] = lda(af, t + D + u, n4);
-                b[u & 1] = ldb<RW>(bp, t + u + 2, n4, kbs);
+                b[u % BD] = ldb<RW>(bp, t + u + BD, n4, kbs);
                 // the refill must stay right behind the MFMAs that consumed the register (the
                 // machine scheduler otherwise clusters all refills at the loop end)
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
     }
-    const int rem = n4 - t;   // 0..D-1 k-steps left; a[0..rem) and b[0], b[1] already hold them
+    const int rem = n4 - t;   // 0..D-1 k-steps left; a[0..rem) and b[0..BD) already hold them
 #pragma unroll
     for (int u = 0; u < D - 1; ++u) {
         if (u < rem) {
-            mma4<RW>(acc, a[u], b[u & 1]);
-            if (u + 2 < rem) b[u & 1] = ldb<RW>(bp, t + u + 2, n4, kbs);
+            mma4<RW>(acc, a[u], b[u % BD]);
+            if (u + BD < rem) b[u % BD] = ldb<RW>(bp, t + u + BD, n4, kbs);
         }
     }
 }
@@ -464,32 +473,77 @@ __global__ __launch_bounds__(W * 64) void mlp_chain_kernel(const MlpParams p) {
 // nsample lanes of a group is a DPP butterfly, and there is no LDS and no barrier at all.
 struct ValuParams {
     const float *xyz, *new_xyz, *feat;
-    const int32_t *idx;
+    const int32_t *idx, *cnt;
     const float *w[3], *b[3];
     float *out;
-    long long total_rows;
-    int ld_feat, N, M, S, sp_shift, ld_out, col_off, vec_out;
+    long long total_groups;
+    int ld_feat, N, M, S, G, nodedup, ld_out, col_off, vec_out;
 };
 
+constexpr int VALU_T = 256;
+constexpr int VALU_GMAX = 2048;
+
 template <int C0, int C1, int C2, int C3>
-__global__ __launch_bounds__(256) void mlp_valu_kernel(const ValuParams p) {
-    const int lane = threadIdx.x & 63;
-    long long gr = (long long)blockIdx.x * 256 + threadIdx.x;
-    const bool live = gr < p.total_rows;
-    if (!live) gr = p.total_rows - 1;
-    const int Sp = 1 << p.sp_shift;
-    const long long bm = gr >> p.sp_shift;
-    int s = (int)(gr & (Sp - 1));
-    if (s >= p.S) s = 0;
+__global__ __launch_bounds__(VALU_T) void mlp_valu_kernel(const ValuParams p) {
+    __shared__ int s_off[VALU_GMAX + 1];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const long long g0 = (long long)blockIdx.x * p.G;
+    const long long left = p.total_groups - g0;
+    const int ng = (int)(left < p.G ? left : p.G);
+    // rows kept per group (padding rows that repeat the first index are dropped, as in the tiled kernel)
+    for (int gi = tid; gi < p.G; gi += VALU_T) {
+        int cnt = 0;
+        if (gi < ng) {
+            if (p.cnt) {
+                cnt = p.cnt[g0 + gi];
+            } else {
+                const int32_t *ip = p.idx + (g0 + gi) * p.S;
+                const int first = ip[0];
+                cnt = 1;
+                for (int s = 1; s < p.S; ++s) cnt = ip[s] != first ? s + 1 : cnt;
+            }
+            cnt = cnt < 1 ? 1 : (cnt > p.S ? p.S : cnt);
+            if (p.nodedup) cnt = p.S;
+        }
+        s_off[gi + 1] = cnt;
+    }
+    if (tid == 0) s_off[0] = 0;
+    __syncthreads();
+    if (tid < 64) {
+        int carry = 0;
+        for (int base = 0; base < p.G; base += 64) {
+            const int gi = base + lane;
+            int v = gi < p.G ? s_off[gi + 1] : 0;
+            for (int off = 1; off < 64; off <<= 1) {
+                const int u = __shfl_up(v, off, 64);
+                if (lane >= off) v += u;
+            }
+            if (gi < p.G) s_off[gi + 1] = v + carry;
+            carry += __builtin_amdgcn_readlane(v, 63);
+        }
+    }
+    __syncthreads();
+    const int T = s_off[p.G];
+    for (int q0 = 0; q0 < T; q0 += VALU_T) {
+    int q = q0 + tid;
+    const bool live = q < T;
+    if (!live) q = T - 1;
+    int glo = 0, ghi = p.G;                          // largest gi with s_off[gi] <= q
+    while (ghi - glo > 1) {
+        const int mid = (glo + ghi) >> 1;
+        if (s_off[mid] <= q) glo = mid; else ghi = mid;
+    }
+    const int gid = live ? glo : -1;
+    const long long bm = g0 + glo;
     const int b = (int)(bm / p.M);
-    const long long pt = (long long)b * p.N + p.idx[bm * p.S + s];
+    const long long pt = (long long)b * p.N + p.idx[bm * p.S + (q - s_off[glo])];
     float x[C0];
     {
-        const float *q = p.xyz + pt * 3;
+        const float *qq = p.xyz + pt * 3;
         const float *c = p.new_xyz + bm * 3;
-        x[0] = q[0] - c[0];
-        x[1] = q[1] - c[1];
-        x[2] = q[2] - c[2];
+        x[0] = qq[0] - c[0];
+        x[1] = qq[1] - c[1];
+        x[2] = qq[2] - c[2];
 #pragma unroll
         for (int k = 3; k < C0; ++k) x[k] = p.feat[pt * p.ld_feat + (k - 3)];
     }
@@ -519,46 +573,42 @@ __global__ __launch_bounds__(256) void mlp_valu_kernel(const ValuParams p) {
         for (int o = 0; o < C3; ++o) h3[o] = __builtin_fmaf(p.w[2][k * C3 + o], h2[k], h3[o]);
 #pragma unroll
     for (int o = 0; o < C3; ++o) h3[o] = __builtin_fmaxf(h3[o], 0.f);
-    // max over the nsample lanes of a group
-    if (p.sp_shift >= 1) {
+    // max-pool per group: rows of a group are consecutive lanes -> segmented max-scan over the wave;
+    // a group inside one wave of one pass is stored, otherwise combined with an atomic max
+    int same[6];
 #pragma unroll
-        for (int o = 0; o < C3; ++o) h3[o] = dpp_max<0xB1>(h3[o]);
+    for (int st = 0; st < 6; ++st) {
+        const int og = __shfl_up(gid, 1 << st, 64);
+        same[st] = (lane >= (1 << st)) && og == gid;
     }
-    if (p.sp_shift >= 2) {
 #pragma unroll
-        for (int o = 0; o < C3; ++o) h3[o] = dpp_max<0x4E>(h3[o]);
+    for (int o = 0; o < C3; ++o) {
+        float v = h3[o];
+#pragma unroll
+        for (int st = 0; st < 6; ++st) {
+            const float u = __shfl_up(v, 1 << st, 64);
+            v = (same[st] && u > v) ? u : v;
+        }
+        h3[o] = v;
     }
-    if (p.sp_shift >= 3) {
+    const int ngid = __shfl_down(gid, 1, 64);
+    const bool tail = gid >= 0 && (lane == 63 || ngid != gid);
+    if (tail) {
+        const int w0 = q0 + (tid & ~63);                 // compact row of lane 0 of this wave
+        const bool whole = s_off[gid] >= w0 && s_off[gid + 1] <= w0 + 64;
+        float *o = p.out + (g0 + gid) * p.ld_out + p.col_off;
+        if (whole && p.vec_out) {
 #pragma unroll
-        for (int o = 0; o < C3; ++o) h3[o] = dpp_max<0x141>(h3[o]);
-    }
-    if (p.sp_shift >= 4) {
+            for (int c = 0; c < C3; c += 4) *reinterpret_cast<float4 *>(o + c) = make_float4(h3[c], h3[c + 1], h3[c + 2], h3[c + 3]);
+        } else if (whole) {
 #pragma unroll
-        for (int o = 0; o < C3; ++o) h3[o] = dpp_max<0x140>(h3[o]);
-    }
-    if (p.sp_shift >= 5) {
+            for (int c = 0; c < C3; ++c) o[c] = h3[c];
+        } else {
 #pragma unroll
-        for (int o = 0; o < C3; ++o) {
-            const float u = __shfl_xor(h3[o], 16, 64);
-            h3[o] = u > h3[o] ? u : h3[o];
+            for (int c = 0; c < C3; ++c) atomic_max_pos(o + c, h3[c]);
         }
     }
-    if (p.sp_shift >= 6) {
-#pragma unroll
-        for (int o = 0; o < C3; ++o) {
-            const float u = __shfl_xor(h3[o], 32, 64);
-            h3[o] = u > h3[o] ? u : h3[o];
-        }
-    }
-    if ((lane & (Sp - 1)) != 0 || !live) return;
-    float *o = p.out + bm * p.ld_out + p.col_off;
-    if (p.vec_out) {
-#pragma unroll
-        for (int c = 0; c < C3; c += 4) *reinterpret_cast<float4 *>(o + c) = make_float4(h3[c], h3[c + 1], h3[c + 2], h3[c + 3]);
-    } else {
-#pragma unroll
-        for (int c = 0; c < C3; ++c) o[c] = h3[c];
-    }
+    }   // pass loop
 }
 
 // ---- weight packing --------------------------------------------------------------------------
@@ -743,16 +793,19 @@ SAD_API int sad_mlp_chain_f32(const sad_mlp_args *a, sad_stream_t stream) {
         if (gsel == 1 && !shape) return sad::fail(SAD_EUNSUPPORTED, "sad_mlp_chain_f32: no VALU kernel for this chain");
         if (shape && gsel == 1) {   // only on request: it computes the padding rows the tiled kernel skips
             ValuParams v{};
-            v.xyz = a->xyz; v.new_xyz = a->new_xyz; v.feat = a->feat; v.idx = a->idx; v.out = a->out;
+            v.xyz = a->xyz; v.new_xyz = a->new_xyz; v.feat = a->feat; v.idx = a->idx; v.cnt = a->cnt; v.out = a->out;
             for (int l = 0; l < 3; ++l) { v.w[l] = a->packed + g.raw_w[l]; v.b[l] = a->packed + g.raw_b[l]; }
-            v.total_rows = p.total_rows; v.ld_feat = a->ld_feat; v.N = a->N; v.M = a->M; v.S = a->S;
-            v.sp_shift = sp_shift; v.ld_out = a->ld_out; v.col_off = a->col_off; v.vec_out = p.vec_out;
-            const long long nb = (p.total_rows + 255) / 256;
+            v.total_groups = p.total_groups; v.ld_feat = a->ld_feat; v.N = a->N; v.M = a->M; v.S = a->S;
+            v.ld_out = a->ld_out; v.col_off = a->col_off; v.vec_out = p.vec_out;
+            v.nodedup = sad::get_option(sad::OPT_MLP_NODEDUP);
+            long long gq = (long long)dedup_f * VALU_T / a->S;   // groups whose surviving rows fill ~one pass
+            v.G = (int)(gq < 1 ? 1 : (gq > VALU_GMAX ? VALU_GMAX : gq));
+            const long long nb = (p.total_groups + v.G - 1) / v.G;
             SAD_REQUIRE(nb < (1LL << 31), "sad_mlp_chain_f32: too many workgroups");
             if (shape == 1)
-                hipLaunchKernelGGL((mlp_valu_kernel<4, 16, 16, 32>), dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, v);
+                hipLaunchKernelGGL((mlp_valu_kernel<4, 16, 16, 32>), dim3((unsigned)nb), dim3(VALU_T), 0, (hipStream_t)stream, v);
             else
-                hipLaunchKernelGGL((mlp_valu_kernel<4, 32, 32, 64>), dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, v);
+                hipLaunchKernelGGL((mlp_valu_kernel<4, 32, 32, 64>), dim3((unsigned)nb), dim3(VALU_T), 0, (hipStream_t)stream, v);
             return sad::check_launch("sad_mlp_chain_f32 (valu)");
         }
     }

@@ -296,7 +296,7 @@ class PackedMLP:
             ms = e0.elapsed_time(e1)
             if best_ms is None or ms < best_ms * 0.98:   # prefer earlier entries on ties
                 best, best_ms = code, ms
-        if a.idx and best != 1:   # second sweep: groups per workgroup (how much padding is expected)
+        if a.idx:   # second sweep: groups per workgroup (how much padding is expected)
             base = best
             for f in self._F_CODES:
                 a.geometry = base + 1000 * f
