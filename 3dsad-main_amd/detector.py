@@ -22,7 +22,7 @@ from .sa_module import SAModuleMSG
 
 class SADDetector(nn.Module):
     def __init__(self, cfg: DetectorConfig, weights: dict, device, overlap_fps: bool = True,
-                 n_fps_streams: int = 4, n_main_streams: int = 2):
+                 n_fps_streams: int = 4, n_main_streams: int = 2, nested_fps_shortcut: bool = True):
         super().__init__()
         self.cfg = cfg
         self.device = torch.device(device)
@@ -48,6 +48,9 @@ class SADDetector(nn.Module):
         self._anchor = (ctypes.c_float * 3)(*cfg.anchor_car)
         self._anchors = (ctypes.c_float * 9)(*[v for a in cfg.anchors for v in a])
         self.overlap_fps = overlap_fps
+        # FPS of an FPS-ordered point set is the identity prefix: stage s+1 samples the first M_{s+1}
+        # centroids of stage s (proof in _sample_stage).  Only stage 1 runs the FPS kernel.
+        self.nested_fps_shortcut = nested_fps_shortcut
         # Sampling streams, used round-robin by consecutive calls: one FPS chain keeps only B CUs
         # busy (one workgroup per scene, a serial chain of M steps), so with input_ready=True the
         # chains of several consecutive batches run side by side while the main stream works
@@ -89,12 +92,27 @@ class SADDetector(nn.Module):
         mlps += [self.cand_mlp, self.cluster_agg, self.head] + self.cluster_branches
         return {m.name: list(m._geom.values())[-1] for m in mlps if m._geom}
 
+    def _sample_stage(self, si: int, cur: torch.Tensor) -> torch.Tensor:
+        """Centroids of stage si from the previous stage's centroids (or the scene for si = 0).
+
+        Shortcut for si > 0 (exact, SPEC.md §2).  `cur` is the FPS pick sequence p_0, p_1, ... of the
+        previous stage.  Running FPS on it starts at p_0; assume its first k picks are p_0..p_{k-1}.
+        Every point's min-distance to that set is the same number in both runs (same coordinates,
+        same expression), and p_k maximised it over the WHOLE previous input, hence also over the
+        subset.  Ties: the previous run took the tied point with the lowest original index, i.e.
+        tied points appear in `cur` in index order, so "lowest position in cur" selects the same
+        point.  By induction fps(cur, M) = (0, 1, ..., M-1), so the centroids are cur[:, :M]."""
+        m = self.stages[si]
+        if si > 0 and self.nested_fps_shortcut and m.stage.npoint <= cur.shape[1]:
+            return cur[:, :m.stage.npoint].contiguous()
+        return m.sample(cur)[1]
+
     def _sample_chain(self, xyz):
         """All three stages' (new_xyz) — coordinates only."""
         out = []
         cur = xyz
-        for m in self.stages:
-            _, cur = m.sample(cur)
+        for si in range(len(self.stages)):
+            cur = self._sample_stage(si, cur)
             out.append(cur)
         return out
 
@@ -125,8 +143,8 @@ class SADDetector(nn.Module):
                 ev_xyz.record(side)
                 cur = xyz
                 centroids = []
-                for m in self.stages:
-                    _, cur = m.sample(cur)
+                for si in range(len(self.stages)):
+                    cur = self._sample_stage(si, cur)
                     centroids.append(cur)
                     ev = torch.cuda.Event()
                     ev.record(side)

@@ -276,3 +276,29 @@ def test_random_shapes_grouped_mlp(orc, sad, dev):
         assert np.array_equal(got1, got2), f"trial {trial}: counts from idx give a different result"
         exact += int(np.array_equal(got1, want))
     assert exact == 25, f"only {exact}/25 random chains were bit-exact"
+
+
+def test_nested_fps_is_identity_prefix(orc, sad, dev):
+    """The detector skips the FPS kernel for stages 2 and 3: fps(FPS-ordered points, M) must be
+    0..M-1 (SPEC.md §2: start at index 0, ties -> lowest index), on KITTI-shaped scenes and on a
+    lattice full of exact ties and duplicates; and the detector gives identical boxes either way."""
+    import torch
+    from sad_amd import config, ops, synth
+    from sad_amd.detector import SADDetector
+    xyz = np.ascontiguousarray(synth.make_batch(3, 2)[:, :, :3])
+    ax = np.arange(16, dtype=np.float32)
+    lat = np.stack(np.meshgrid(ax, ax, ax, indexing="ij"), -1).reshape(1, 4096, 3).copy()
+    lat[0, 500:600] = lat[0, 9]
+    for pts, m1, m2 in ((xyz, 4096, 1024), (lat, 2048, 700)):
+        X = _t(pts, dev)
+        first = ops.gather_xyz(X, ops.fps(X, m1))
+        second = ops.fps(first, m2).cpu().numpy()
+        np.testing.assert_array_equal(second, np.tile(np.arange(m2, dtype=np.int32), (pts.shape[0], 1)))
+        np.testing.assert_array_equal(orc.fps(first.cpu().numpy(), m2), second)
+    cfg = config.TINY
+    w = synth.make_weights(cfg, 0)
+    p = _t(synth.make_tiny_batch(5, 2, cfg.n_points), dev)
+    a = SADDetector(cfg, w, dev, nested_fps_shortcut=True)(p)
+    b = SADDetector(cfg, w, dev, nested_fps_shortcut=False)(p)
+    torch.cuda.synchronize()
+    assert torch.equal(a, b)
