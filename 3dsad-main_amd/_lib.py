@@ -23,7 +23,7 @@ vp = ctypes.c_void_p
 class MlpArgs(ctypes.Structure):
     """``struct sad_mlp_args`` (include/sad_amd.h)."""
     _fields_ = [
-        ("xyz", vp), ("new_xyz", vp), ("idx", vp), ("cnt", vp), ("feat", vp),
+        ("xyz", vp), ("new_xyz", vp), ("idx", vp), ("cnt", vp), ("workspace", vp), ("feat", vp),
         ("ld_feat", ctypes.c_int),
         ("B", ctypes.c_int), ("N", ctypes.c_int), ("M", ctypes.c_int), ("S", ctypes.c_int),
         ("C", ctypes.c_int),
@@ -57,6 +57,7 @@ SIGNATURES = {
     "sad_mlp_packed_floats": (ctypes.c_size_t, [ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.c_int]),
     "sad_mlp_pack_f32": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.c_int,
                                        ctypes.POINTER(vp), ctypes.POINTER(vp), vp, vp]),
+    "sad_mlp_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     "sad_mlp_chain_f32": (ctypes.c_int, [ctypes.POINTER(MlpArgs), vp]),
     "sad_candidates_f32": (ctypes.c_int, [vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                          ctypes.c_float, ctypes.c_float, ctypes.c_float, c_f32p,

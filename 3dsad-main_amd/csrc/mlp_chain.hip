@@ -54,6 +54,8 @@ struct MlpParams {
     int bias_total;        // sum of np[l]: biases are copied to LDS once per workgroup
     int G;                 // grouped mode: (b,m) groups per workgroup
     int nodedup;           // tuning/A-B switch: compute the padded duplicate rows too
+    int s_off_entries;     // capacity of s_off (the work-counter broadcast slot follows it)
+    int *rowtab;           // global row packing (see rowscan_kernel): hdr[4], row_start[ngroups+1], pass_first[]
     long long total_groups; // B*M
 };
 
@@ -163,6 +165,55 @@ __device__ __forceinline__ void mma_ktile(f32x16 (&acc)[RW], const float4 *__res
     }
 }
 
+// ---- global row packing ------------------------------------------------------------------------
+// With per-group counts from the ball query, one workgroup prefix-sums them over ALL groups of the
+// launch, so every pass of R rows is full and passes can be handed out dynamically (perfect balance).
+// Table (ints): hdr[0] = total rows, hdr[1] = passes, hdr[2] = next pass (work counter),
+// row_start[ngroups + 1] from offset 4, then pass_first[p] = group that contains row p*R.
+constexpr int SCAN_T = 1024;
+__global__ __launch_bounds__(SCAN_T) void rowscan_kernel(const int32_t *__restrict__ cnt, int ngroups, int S,
+                                                         int nodedup, int R, int *__restrict__ tab) {
+    __shared__ int wsum[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int *row_start = tab + 4;
+    int *pass_first = tab + 4 + ngroups + 1;
+    const int per = (ngroups + SCAN_T - 1) / SCAN_T;
+    const int g_lo = tid * per, g_hi = g_lo + per < ngroups ? g_lo + per : ngroups;
+    int sum = 0;
+    for (int g = g_lo; g < g_hi; ++g) {
+        int c = cnt[g];
+        c = c < 1 ? 1 : (c > S ? S : c);
+        sum += nodedup ? S : c;
+    }
+    int incl = sum;
+    for (int off = 1; off < 64; off <<= 1) {
+        const int v = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += v;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    int base = incl - sum;
+    for (int w = 0; w < wave; ++w) base += wsum[w];
+    int run = base;
+    for (int g = g_lo; g < g_hi; ++g) {
+        int c = cnt[g];
+        c = c < 1 ? 1 : (c > S ? S : c);
+        c = nodedup ? S : c;
+        row_start[g] = run;
+        // passes whose first row lies inside this group
+        for (int pp = (run + R - 1) / R; pp * R < run + c; ++pp) pass_first[pp] = g;
+        run += c;
+    }
+    if (tid == SCAN_T - 1) {
+        int total = 0;
+        for (int w = 0; w < 16; ++w) total += wsum[w];
+        row_start[ngroups] = total;
+        tab[0] = total;
+        tab[1] = (total + R - 1) / R;
+        tab[2] = 0;
+    }
+}
+
 // Group of the last compact row (used for the clamped rows past the end of the last pass).
 __device__ __forceinline__ int s_off_last_group(const int *s_off, int G, int T) {
     int lo = 0, hi = G;
@@ -216,8 +267,10 @@ __global__ __launch_bounds__(W * 64) void mlp_chain_kernel(const MlpParams p) {
     // G groups are numbered consecutively ("compact rows") and processed R at a time.
     long long r0 = (long long)blockIdx.x * R;
     long long g0 = 0;
-    int T = R, npass = 1;
-    if (p.grouped) {
+    int T = R, npass = 1, G = p.G;
+    const bool dyn = p.grouped && p.rowtab != nullptr;       // global packing + dynamic pass hand-out
+    int &s_pass = s_off[p.s_off_entries];   // one int past the offsets (all LDS lives in the dynamic region)
+    if (p.grouped && !dyn) {
         g0 = (long long)blockIdx.x * p.G;
         long long left = p.total_groups - g0;
         const int ng = (int)(left < p.G ? left : p.G);
@@ -266,14 +319,34 @@ __global__ __launch_bounds__(W * 64) void mlp_chain_kernel(const MlpParams p) {
     }
     const int nchunks = (p.kp[0] + p.kc - 1) / p.kc;
 
-    for (int pass = 0; pass < npass; ++pass) {
+    for (int pass_i = 0; dyn || pass_i < npass; ++pass_i) {
+        int pass = pass_i;          // static mode: pass of this workgroup's own rows
+        int qoff = pass * R;        // compact-row coordinate of row 0 of the tile in s_off's frame
+        if (dyn) {
+            // fetch the next pass of the launch; s_off becomes pass-local (row 0 of the pass = 0)
+            if (tid == 0) s_pass = atomicAdd(p.rowtab + 2, 1);
+            __syncthreads();
+            pass = s_pass;
+            const int total = p.rowtab[0];
+            if (pass >= p.rowtab[1]) break;                 // uniform
+            const int *row_start = p.rowtab + 4;
+            const int *pass_first = p.rowtab + 4 + (int)p.total_groups + 1;
+            const int gA = pass_first[pass];
+            const int gB = pass + 1 < p.rowtab[1] ? pass_first[pass + 1] : (int)p.total_groups - 1;
+            G = gB - gA + 1;                                // groups touching this pass (<= R + 1)
+            g0 = gA;
+            for (int i = tid; i <= G; i += W * 64) s_off[i] = row_start[gA + i] - pass * R;
+            T = total - pass * R < R ? total - pass * R : R;
+            qoff = 0;
+            __syncthreads();
+        }
         // ---- per-row source index ---------------------------------------------------------------
         for (int r = tid; r < R; r += W * 64) {
             if (p.grouped) {
-                int q = pass * R + r;
-                const bool valid = q < T;
+                int q = qoff + r;
+                const bool valid = dyn ? r < T : q < T;
                 if (!valid) q = T - 1;
-                int lo = 0, hi = p.G;                       // largest gi with s_off[gi] <= q
+                int lo = 0, hi = G;                         // largest gi with s_off[gi] <= q
                 while (hi - lo > 1) {
                     const int mid = (lo + hi) >> 1;
                     if (s_off[mid] <= q) lo = mid; else hi = mid;
@@ -330,7 +403,7 @@ __global__ __launch_bounds__(W * 64) void mlp_chain_kernel(const MlpParams p) {
                         if (!(round == 0 && ck == 0)) __syncthreads();  // previous readers are done
                         if (p.grouped && k0 == 0) {  // channels 0..3 = point - centroid, 0 (SPEC §6)
                             for (int r = tid; r < R; r += W * 64) {
-                                const int gi = sm_gid[r] < 0 ? s_off_last_group(s_off, p.G, T) : sm_gid[r];
+                                const int gi = sm_gid[r] < 0 ? s_off_last_group(s_off, G, T) : sm_gid[r];
                                 const float *q = p.xyz + (long long)sm_idx[r] * 3;
                                 const float *c = p.new_xyz + (g0 + gi) * 3;
                                 *reinterpret_cast<float2 *>(bufA + r * 4) = make_float2(q[0] - c[0], q[2] - c[2]);
@@ -439,7 +512,7 @@ __global__ __launch_bounds__(W * 64) void mlp_chain_kernel(const MlpParams p) {
                         const int ng = __shfl_down(gid, 1, 32);
                         const bool tail = gid >= 0 && (j == 31 || ng != gid);
                         if (!tail) continue;
-                        const int q0 = pass * R + rbase;                  // compact row of lane 0
+                        const int q0 = qoff + rbase;                      // compact row of lane 0 (s_off frame)
                         const bool whole = s_off[gid] >= q0 && s_off[gid + 1] <= q0 + 32;
                         float *o = p.out + (g0 + gid) * p.ld_out + p.col_off;
 #pragma unroll
@@ -691,8 +764,9 @@ template <int W, int RW>
 int launch_mlp(const MlpParams &p, size_t lds, long long nblocks, hipStream_t st) {
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&mlp_chain_kernel<W, RW>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&mlp_chain_kernel<W, RW>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            (void)hipGetLastError();   // do not let a refused attribute poison the launch check
         attr_set = true;
     }
     hipLaunchKernelGGL((mlp_chain_kernel<W, RW>), dim3((unsigned)nblocks), dim3(W * 64), lds, st, p);
@@ -728,6 +802,12 @@ SAD_API int sad_mlp_pack_f32(int L, const int *dims, int first_has_xyz, const fl
     return sad::check_launch("sad_mlp_pack_f32");
 }
 
+SAD_API size_t sad_mlp_workspace_bytes(int B, int M, int S) {
+    if (B < 1 || M < 1 || S < 1) return 0;
+    const size_t ng = (size_t)B * M;
+    return sizeof(int) * (4 + (ng + 1) + (ng * S / 32 + 2)) + 64;   // hdr, row_start, pass_first (R >= 32)
+}
+
 SAD_API int sad_mlp_chain_f32(const sad_mlp_args *a, sad_stream_t stream) {
     SAD_REQUIRE(a, "sad_mlp_chain_f32: NULL args");
     if (int e = check_dims("sad_mlp_chain_f32", a->L, a->dims)) return e;
@@ -761,7 +841,8 @@ SAD_API int sad_mlp_chain_f32(const sad_mlp_args *a, sad_stream_t stream) {
     p.total_rows = (long long)a->B * a->M << sp_shift;   // plain mode: rows; VALU kernel: padded rows
     p.total_groups = (long long)a->B * a->M;
     int geom_all = a->geometry ? a->geometry : sad::get_option(sad::OPT_MLP_FORCE);
-    const int fcode = geom_all / 1000;                       // 0 = default
+    const int dyn_code = (geom_all / 10000) % 10;            // 0 = heuristic, 1 = global packing, 2 = per-workgroup packing
+    const int fcode = (geom_all / 1000) % 10;                // 0 = default
     const int geom_wg = geom_all % 1000;
     int dedup_f = sad::get_option(sad::OPT_MLP_DEDUP_F) > 0 ? sad::get_option(sad::OPT_MLP_DEDUP_F) : 8;
     if (fcode >= 1 && fcode <= 7) dedup_f = 1 << fcode;
@@ -833,7 +914,8 @@ SAD_API int sad_mlp_chain_f32(const sad_mlp_args *a, sad_stream_t stream) {
         lds_rows(kcc, ra, rb);
         const size_t R = 32 * (size_t)rw * (w >> wns);
         const size_t G = grouped ? (size_t)groups_per_wg((int)R) : 0;
-        return ((size_t)((ra + rb) / 4) * (4 * R + 8) + 2 * R + G + 1 + (size_t)bias_total) * 4 + 16;
+        const size_t nso = (G > R + 1 ? G : R + 1) + 2;     // s_off entries (static G+1, dynamic <= R+2) + broadcast slot
+        return ((size_t)((ra + rb) / 4) * (4 * R + 8) + 2 * R + nso + (size_t)bias_total) * 4 + 16;
     };
     // ---- choose the workgroup geometry -----------------------------------------------------
     // W waves, WN along output tiles; R = 32*RW*(W/WN) rows per workgroup.
@@ -887,10 +969,30 @@ SAD_API int sad_mlp_chain_f32(const sad_mlp_args *a, sad_stream_t stream) {
     p.kc = kc;
     lds_rows(kc, p.bufA_rows, p.bufB_rows);
     const size_t lds = lds_bytes(W, wn_shift, RW, kc);
+    const size_t lds_final = lds;
     const long long R = 32LL * RW * (W >> wn_shift);
     p.G = grouped ? groups_per_wg((int)R) : 0;
+    p.s_off_entries = (int)((p.G > R + 1 ? p.G : R + 1) + 1);
     p.nodedup = sad::get_option(sad::OPT_MLP_NODEDUP);
-    const long long nblocks = grouped ? (p.total_groups + p.G - 1) / p.G : (p.total_rows + R - 1) / R;
+    p.rowtab = nullptr;
+    long long grid_dyn = 0;
+    long long macs_per_row = 0;
+    for (int l = 0; l < a->L; ++l) macs_per_row += (long long)g.kp[l] * g.np[l];
+    // global packing pays off when the prefix-sum workgroup is cheap (few groups) and rows are
+    // expensive (measured: cluster.b1 +7 %, sa3.b2 +3 %, every small chain slower)
+    const bool want_dyn = dyn_code == 1 || (dyn_code == 0 && p.total_groups <= 16384 && macs_per_row >= 400000);
+    if (grouped && a->cnt && a->workspace && want_dyn && !sad::get_option(sad::OPT_MLP_STATIC)) {
+        // global row packing: scan the counts once, then a persistent grid pulls full passes
+        SAD_REQUIRE((uintptr_t)a->workspace % 16 == 0, "sad_mlp_chain_f32: workspace must be 16-byte aligned");
+        SAD_REQUIRE(p.total_groups < (1LL << 30), "sad_mlp_chain_f32: too many groups");
+        p.rowtab = (int *)a->workspace;
+        hipLaunchKernelGGL(rowscan_kernel, dim3(1), dim3(SCAN_T), 0, (hipStream_t)stream, a->cnt,
+                           (int)p.total_groups, a->S, p.nodedup, (int)R, p.rowtab);
+        const long long upper = (p.total_groups * a->S + R - 1) / R;
+        const long long per_cu = lds_final > 80 * 1024 ? 1 : (lds_final > 52 * 1024 ? 2 : (lds_final > 39 * 1024 ? 3 : 4));
+        grid_dyn = upper < 256 * per_cu ? upper : 256 * per_cu;
+    }
+    const long long nblocks = grid_dyn ? grid_dyn : (grouped ? (p.total_groups + p.G - 1) / p.G : (p.total_rows + R - 1) / R);
     SAD_REQUIRE(nblocks < (1LL << 31), "sad_mlp_chain_f32: too many workgroups");
     hipStream_t st = (hipStream_t)stream;
     if (W == 16) {

@@ -107,6 +107,11 @@ typedef struct sad_mlp_args {
     /* optional [B,M]: leading rows of each group that are not padding (from ball query); NULL =
      * derived from idx as "last sample that differs from the first, + 1" */
     const int32_t *cnt;
+    /* optional, grouped mode with cnt: sad_mlp_workspace_bytes(B, M, S) bytes of 16-byte aligned
+     * device scratch.  The surviving rows of ALL groups are then packed globally (one prefix-sum
+     * workgroup) and a persistent grid pulls full passes from a work counter; without it each
+     * workgroup packs only its own groups. */
+    void *workspace;
     /* features: grouped mode: point-major [B,N,C] with row stride ld_feat (NULL iff C == 0);
      * plain mode (idx == NULL): rows [B*M, C] with row stride ld_feat */
     const float *feat;
@@ -130,9 +135,11 @@ typedef struct sad_mlp_args {
      * waves, WN waves along the 32-channel output tiles, RW in {1,2,4} row tiles of 32 rows per
      * wave.  A geometry that does not fit LDS returns SAD_EUNSUPPORTED (autotuners skip it).
      * + 1000*f (f = 1..7): grouped mode, a workgroup owns 2^f * R / S groups (default 8: it assumes
-     * about one row in eight survives the padding removal). */
+     * about one row in eight survives the padding removal).
+     * + 10000*d: d = 1 forces global row packing (needs cnt + workspace), d = 2 forbids it. */
     int geometry;
 } sad_mlp_args;
+size_t sad_mlp_workspace_bytes(int B, int M, int S);
 int sad_mlp_chain_f32(const sad_mlp_args *args, sad_stream_t stream);
 
 /* SPEC.md §8 steps 2-4.  xyz3[B,M3,3], c[B,K,6] -> cand[B,K,3], radius[B,K]; anchor[3] host. */
