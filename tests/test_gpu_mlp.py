@@ -302,3 +302,24 @@ def test_nested_fps_is_identity_prefix(orc, sad, dev):
     b = SADDetector(cfg, w, dev, nested_fps_shortcut=False)(p)
     torch.cuda.synchronize()
     assert torch.equal(a, b)
+
+
+def test_nuscenes_scale_sa_module(orc, sad, dev):
+    """BASELINE configs[4] point count (65 536 points, fp32 here): one MSG stage 65 536 -> 2 048 through
+    the large-N FPS kernel (global workspace), the grid ball query at N = 65 536 and the fused MLP,
+    against the oracle."""
+    from sad_amd import config, ops, synth
+    from sad_amd.sa_module import SAModuleMSG
+    pts = synth.make_batch(11, 1, 65536, extent=(-51.2, 51.2, -51.2, 51.2), n_boxes=120)
+    xyz = np.ascontiguousarray(pts[:, :, :3])
+    feat = np.ascontiguousarray(pts[:, :, 3:])
+    st = config.SAStage(2048, (0.4, 1.0), (16, 32), ((16, 32), (16, 16, 32)), 32)
+    rng = np.random.default_rng(4)
+    w = {"b0": synth.make_mlp_weights([4, 16, 32], rng), "b1": synth.make_mlp_weights([4, 16, 16, 32], rng),
+         "agg": synth.make_mlp_weights([64, 32], rng)}
+    mod = SAModuleMSG(1, st, dev, w)
+    nx, nf = mod.forward_pm(_t(xyz, dev), _t(feat, dev))
+    ow = {"s.b0": w["b0"], "s.b1": w["b1"], "s.agg": w["agg"]}
+    onx, onf = orc.sa_module(xyz, feat, st, ow, "s")
+    np.testing.assert_array_equal(nx.cpu().numpy(), onx)
+    _close(nf.cpu().numpy(), onf, "65536-point SA stage")
