@@ -10,7 +10,8 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-SO_PATH = os.path.join(CSRC, "libsad_amd.so")
+# SAD_AMD_LIB points at an alternative build of the same C-ABI (A/B measurements of kernel variants)
+SO_PATH = os.environ.get("SAD_AMD_LIB") or os.path.join(CSRC, "libsad_amd.so")
 
 MAX_LAYERS = 4
 MAX_RADII = 4

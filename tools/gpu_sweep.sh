@@ -1,6 +1,6 @@
 mkdir -p gpurun_out
 timeout -k 10 300 python -m pytest tests -m gpu -x -q > gpurun_out/t3.log 2>&1; echo exit=$? >> gpurun_out/t3.log; tail -3 gpurun_out/t3.log
-for o in "" "--no-launch-timing"; do
+for o in "--main-streams 1" "--no-launch-timing" "--no-launch-timing"; do
   timeout -k 10 200 python bench.py --no-cpu $o > gpurun_out/b2.tmp 2>&1; grep -E '^\{' gpurun_out/b2.tmp >> gpurun_out/b2.log || tail -5 gpurun_out/b2.tmp
 done
 python - <<'PY'
