@@ -145,11 +145,17 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path is the only path (no CPU fallback)")
+    if os.environ.get("SAD_BENCH_ONE_DEVICE"):      # rehearsal of the N>1 path on a one-GPU box
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)   # RCCL on ROCm
+        backend = os.environ.get("SAD_BENCH_BACKEND", "nccl")       # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:                                                        # rehearsal on a one-GPU box
+            dist.init_process_group(backend)
 
     from sad_amd import _lib
     for kv in args.opt:
@@ -215,7 +221,7 @@ def main():
             "ms_per_step": round(1e3 * elapsed / steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "configs[1-2]: batch 32 x 16384-pt KITTI-shaped scenes per GPU, "
+            "config": {"workload": f"configs[1-2]: batch {B} x 16384-pt KITTI-shaped scenes per GPU, "
                                    "3-stage multi-radius SA backbone fp32 + size-adaptive cluster layer + box head",
                        "scenes_per_gpu": B, "global_batch": world * B, "n_points": cfg.n_points,
                        "parallelism": f"batch-sharded x{world}, one all_gather of boxes",
