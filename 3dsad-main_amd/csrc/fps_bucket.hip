@@ -119,6 +119,29 @@ __device__ __forceinline__ u64 wave_max_u64(u64 k) {
     k = row_max_u64(k);
     return umax64(umax64(readlane_u64(k, 0), readlane_u64(k, 16)), umax64(readlane_u64(k, 32), readlane_u64(k, 48)));
 }
+// 32-bit building blocks: a 64-bit key max is done as max(high words), then max of the low words
+// among the lanes that hold that high word — two cheap v_max_u32 butterflies instead of 64-bit
+// compare/select chains.
+template <int CTRL>
+__device__ __forceinline__ unsigned dpp_max_u32(unsigned v) {
+    const unsigned o = __builtin_amdgcn_update_dpp(0u, v, CTRL, 0xF, 0xF, false);
+    return o > v ? o : v;
+}
+template <int STEPS>
+__device__ __forceinline__ unsigned row_max_u32(unsigned v) {   // max over aligned groups of 2^STEPS lanes (<= 16)
+    if constexpr (STEPS >= 1) v = dpp_max_u32<0xB1>(v);
+    if constexpr (STEPS >= 2) v = dpp_max_u32<0x4E>(v);
+    if constexpr (STEPS >= 3) v = dpp_max_u32<0x141>(v);
+    if constexpr (STEPS >= 4) v = dpp_max_u32<0x140>(v);
+    return v;
+}
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v) {  // wave-uniform result
+    v = row_max_u32<4>(v);
+    const unsigned a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 16);
+    const unsigned c = __builtin_amdgcn_readlane(v, 32), d = __builtin_amdgcn_readlane(v, 48);
+    const unsigned ab = a > b ? a : b, cd = c > d ? c : d;
+    return ab > cd ? ab : cd;
+}
 __device__ __forceinline__ float clampf(float v, float lo, float hi) {
     v = v < lo ? lo : v;
     return v > hi ? hi : v;
@@ -134,8 +157,7 @@ __global__ __launch_bounds__(THREADS) void fps_bucket_kernel(const float *__rest
     constexpr int NW = THREADS / 64;
     typedef float fvec __attribute__((ext_vector_type(PPT)));
     typedef int ivec __attribute__((ext_vector_type(PPT)));
-    __shared__ u64 s_key[2][16];
-    __shared__ float s_xyz[2][16][4];
+    __shared__ __attribute__((aligned(16))) unsigned s_rec[2][16][8];   // per wave: key lo, key hi, x, y, z
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const float *p = xyz + (size_t)blockIdx.x * N * 3;
@@ -199,14 +221,16 @@ __global__ __launch_bounds__(THREADS) void fps_bucket_kernel(const float *__rest
     u64 wkey;
     float wx, wy, wz, wmaxf;
     auto wave_best = [&]() {
-        wkey = wave_max_u64(tkey);
+        const unsigned hi = wave_max_u32((unsigned)(tkey >> 32));
+        const unsigned lo = wave_max_u32((unsigned)(tkey >> 32) == hi ? (unsigned)tkey : 0u);
+        wkey = ((u64)hi << 32) | lo;
         const unsigned long long own = __ballot(tkey == wkey);     // exactly one lane (indices are unique)
         const int ol = __builtin_ctzll(own);
         const int kk = __builtin_amdgcn_readlane(tbk, ol);
         wx = rdl_f(px[kk], ol);
         wy = rdl_f(py[kk], ol);
         wz = rdl_f(pz[kk], ol);
-        wmaxf = __builtin_bit_cast(float, (unsigned)(wkey >> 32));
+        wmaxf = __builtin_bit_cast(float, hi);
     };
     wave_best();
 
@@ -227,29 +251,27 @@ __global__ __launch_bounds__(THREADS) void fps_bucket_kernel(const float *__rest
         }
         const int buf = i & 1;
         if (lane == 0) {
-            s_key[buf][wave] = wkey;
-            s_xyz[buf][wave][0] = wx;
-            s_xyz[buf][wave][1] = wy;
-            s_xyz[buf][wave][2] = wz;
+            uint4 r0;
+            r0.x = (unsigned)wkey;
+            r0.y = (unsigned)(wkey >> 32);
+            r0.z = __builtin_bit_cast(unsigned, wx);
+            r0.w = __builtin_bit_cast(unsigned, wy);
+            *reinterpret_cast<uint4 *>(&s_rec[buf][wave][0]) = r0;
+            s_rec[buf][wave][4] = __builtin_bit_cast(unsigned, wz);
         }
         __syncthreads();
-        const u64 mine = s_key[buf][lane & (NW - 1)];
-        u64 g = mine;
-        if constexpr (NW == 16) {
-            g = row_max_u64(g);
-        } else if constexpr (NW == 8) {
-            g = umax64(g, dpp_u64<0xB1>(g));
-            g = umax64(g, dpp_u64<0x4E>(g));
-            g = umax64(g, dpp_u64<0x141>(g));
-        } else {
-            g = umax64(g, dpp_u64<0xB1>(g));
-            g = umax64(g, dpp_u64<0x4E>(g));
-        }
-        const u64 gk = readlane_u64(g, 0);
-        const int slot = __builtin_ctzll(__ballot(mine == gk)) & (NW - 1);
-        cx = rdl_f(s_xyz[buf][slot][0], 0);   // wave-uniform: keeps the skip tests on the scalar branch path
-        cy = rdl_f(s_xyz[buf][slot][1], 0);
-        cz = rdl_f(s_xyz[buf][slot][2], 0);
+        // every lane fetches one wave's record (lane & (NW-1)); the winner's coordinates then come
+        // out of the winning lane's registers — no second LDS round trip
+        const uint4 rec = *reinterpret_cast<const uint4 *>(&s_rec[buf][lane & (NW - 1)][0]);
+        const unsigned recz = s_rec[buf][lane & (NW - 1)][4];
+        constexpr int RSTEPS = NW == 16 ? 4 : (NW == 8 ? 3 : 2);
+        const unsigned ghi = __builtin_amdgcn_readlane(row_max_u32<RSTEPS>(rec.y), 0);
+        const unsigned glo = __builtin_amdgcn_readlane(row_max_u32<RSTEPS>(rec.y == ghi ? rec.x : 0u), 0);
+        const int slot = __builtin_ctzll(__ballot(rec.y == ghi && rec.x == glo));
+        cx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(rec.z, slot));
+        cy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(rec.w, slot));
+        cz = __builtin_bit_cast(float, __builtin_amdgcn_readlane(recz, slot));
+        const u64 gk = ((u64)ghi << 32) | glo;
         if (tid == 0) out[i] = (int)(~(unsigned)gk);
     }
 }
