@@ -142,6 +142,14 @@ __device__ __forceinline__ unsigned wave_max_u32(unsigned v) {  // wave-uniform 
     const unsigned ab = a > b ? a : b, cd = c > d ? c : d;
     return ab > cd ? ab : cd;
 }
+__device__ __forceinline__ unsigned wave_max_u32_bcast(unsigned v) {   // same, cross-row part by row_bcast DPP
+    v = row_max_u32<4>(v);
+    unsigned o = __builtin_amdgcn_update_dpp(v, v, 0x142, 0xA, 0xF, false);   // row_bcast:15 -> rows 1,3
+    v = o > v ? o : v;
+    o = __builtin_amdgcn_update_dpp(v, v, 0x143, 0xC, 0xF, false);            // row_bcast:31 -> rows 2,3
+    v = o > v ? o : v;
+    return __builtin_amdgcn_readlane(v, 63);
+}
 __device__ __forceinline__ float clampf(float v, float lo, float hi) {
     v = v < lo ? lo : v;
     return v > hi ? hi : v;
@@ -276,6 +284,184 @@ __global__ __launch_bounds__(THREADS) void fps_bucket_kernel(const float *__rest
     }
 }
 
+
+// ---- cell-bucket kernel ------------------------------------------------------------------------
+// Finer buckets, balanced over the waves.  A bucket is 64 consecutive points of the Z-order
+// permutation — slot k of wave w holds bucket k*NW + w, one point per lane — so spatially adjacent
+// buckets sit in DIFFERENT waves (and SIMDs), and a sampling step that disturbs a handful of
+// buckets costs each wave one or two 64-point updates instead of a whole-wave update.  Lane k
+// (< PPT <= 32) of a wave keeps bucket k's state: bounding box, exact max min-distance, and the key
+// + coordinates of the point that attains it.  The skip test of all PPT buckets is one
+// lane-parallel evaluation; its ballot is walked with scalar bit scans; slot k's registers are
+// reached by uniform register indexing (s_set_gpr_idx), so there is ONE update body and no
+// per-slot code; the wave's best is a row reduction of the bucket keys.  Few, fat waves (8 x 32
+// slots for 16 384 points) keep the part of the step every wave must execute — test, publish,
+// barrier, NW-key arg-max — short.  Same proof of exactness as above, per bucket.
+__device__ __forceinline__ unsigned wrl_dyn(unsigned old, unsigned val_uniform, int lane_uniform) {
+    // v_writelane_b32 with data and lane select both scalar: the lane select goes through M0
+    // (gfx9 allows one SGPR on the constant bus)
+    val_uniform = __builtin_amdgcn_readfirstlane(val_uniform);
+    lane_uniform = __builtin_amdgcn_readfirstlane(lane_uniform);
+    // (m0 is reserved and not tracked by the compiler; nothing in this kernel keeps a value in it)
+    asm("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(old) : "s"(val_uniform), "s"(lane_uniform));
+    return old;
+}
+__device__ __forceinline__ float wrl_dyn_f(float old, float val_uniform, int lane_uniform) {
+    return __builtin_bit_cast(float, wrl_dyn(__builtin_bit_cast(unsigned, old), __builtin_bit_cast(unsigned, val_uniform), lane_uniform));
+}
+template <int STEPS>
+__device__ __forceinline__ unsigned half_max_u32(unsigned v) {   // max over lanes 0..2^STEPS-1 (<= 32), valid in lane 0
+    if constexpr (STEPS <= 4) return row_max_u32<STEPS>(v);
+    v = row_max_u32<4>(v);
+    const unsigned o = __builtin_amdgcn_readlane(v, 16);
+    return o > v ? o : v;
+}
+
+template <int NW, int PPT>
+__global__ __launch_bounds__(NW * 64) void fps_cell_kernel(const float *__restrict__ xyz,
+                                                           const int *__restrict__ perm_in, int N,
+                                                           int M, int *__restrict__ idx_out) {
+    static_assert(PPT <= 32 && NW <= 16, "bucket state lives in lanes 0..31; one record per wave");
+    typedef float fvec __attribute__((ext_vector_type(PPT)));
+    typedef unsigned uvec __attribute__((ext_vector_type(PPT)));
+    constexpr int PSTEPS = PPT > 16 ? 5 : 4;
+    // cross-wave arg-max: every wave folds its 64-bit key (wave id in the 4 low bits) into s_gkey
+    // with one LDS atomic max; after the barrier one broadcast read gives the winner and its wave,
+    // whose coordinates are taken from that wave's record.  Three key slots rotate (the slot of step
+    // i+1 is cleared during step i), records are double-buffered.
+    __shared__ u64 s_gkey[3];
+    __shared__ __attribute__((aligned(16))) float s_wxyz[2][16][4];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const float *p = xyz + (size_t)blockIdx.x * N * 3;
+    const int *perm = perm_in + (size_t)blockIdx.x * N;
+    int *out = idx_out + (size_t)blockIdx.x * M;
+
+    fvec px, py, pz, md;
+    uvec ni;                                  // ~original index (larger = lower index, for the tie rule)
+    // bucket state, valid in lane k for bucket k; other lanes: never active, never winning
+    float blo0 = 0.f, blo1 = 0.f, blo2 = 0.f, bhi0 = 0.f, bhi1 = 0.f, bhi2 = 0.f;
+    float bx = 0.f, by = 0.f, bz = 0.f;
+    unsigned bmax = 0u, bidx = 0u;
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+        const int pos = (k * NW + wave) * 64 + lane;
+        const bool real = pos < N;
+        float x = 0.f, y = 0.f, z = 0.f;
+        unsigned n = 0x80000000u;             // padding: distance 0 and the largest index never beat a real point
+        if (real) {
+            const int j = perm[pos];
+            x = p[j * 3 + 0];
+            y = p[j * 3 + 1];
+            z = p[j * 3 + 2];
+            n = ~(unsigned)j;
+        }
+        px[k] = x; py[k] = y; pz[k] = z; ni[k] = n;
+        md[k] = real ? __builtin_inff() : 0.f;
+        float lo[3] = {real ? x : 3.0e38f, real ? y : 3.0e38f, real ? z : 3.0e38f};
+        float hi[3] = {real ? x : -3.0e38f, real ? y : -3.0e38f, real ? z : -3.0e38f};
+#pragma unroll
+        for (int d = 0; d < 3; ++d)
+            for (int off = 32; off >= 1; off >>= 1) {
+                const float a = __shfl_xor(lo[d], off, 64), b = __shfl_xor(hi[d], off, 64);
+                lo[d] = a < lo[d] ? a : lo[d];
+                hi[d] = b > hi[d] ? b : hi[d];
+            }
+        const bool any_real = __ballot(real) != 0ull;
+        if (lane == k) {
+            blo0 = lo[0]; blo1 = lo[1]; blo2 = lo[2];
+            bhi0 = hi[0]; bhi1 = hi[1]; bhi2 = hi[2];
+            bmax = any_real ? 0x7f800000u : 0u;   // +inf: the first step updates every real bucket
+            bidx = 0x80000000u;
+        }
+    }
+
+    float cx = p[0], cy = p[1], cz = p[2];
+    unsigned wk_hi = 0u, wk_lo = 0u;
+    float wx = 0.f, wy = 0.f, wz = 0.f;
+    if (tid == 0) out[0] = 0;
+    if constexpr (NW > 1) {
+        if (tid < 3) s_gkey[tid] = 0ull;
+        __syncthreads();
+    }
+    int b3 = 1;
+    for (int i = 1; i < M; ++i) {
+        // all PPT skip tests at once: lane k tests bucket k (a never-active lane has bmax = 0)
+        const float dq = sad::d2f(__builtin_amdgcn_fmed3f(cx, blo0, bhi0), __builtin_amdgcn_fmed3f(cy, blo1, bhi1),
+                                  __builtin_amdgcn_fmed3f(cz, blo2, bhi2), cx, cy, cz);
+        unsigned act = __builtin_amdgcn_readfirstlane((unsigned)__ballot(dq < __builtin_bit_cast(float, bmax)));
+        if (act) {
+            do {
+                const int k = __builtin_amdgcn_readfirstlane(__builtin_ctz(act));
+                act &= act - 1;
+                const float x = px[k], y = py[k], z = pz[k];
+                const unsigned n = ni[k];
+                const float d = sad::d2f(x, y, z, cx, cy, cz);
+                const float m = __builtin_fminf(md[k], d);
+                md[k] = m;
+                const unsigned mb = __builtin_bit_cast(unsigned, m);     // m >= +0: integer order = float order
+                const unsigned hi = wave_max_u32_bcast(mb);
+                const unsigned long long tie = __ballot(mb == hi);
+                int l = __builtin_ctzll(tie);
+                if (tie & (tie - 1)) {                                    // several lanes attain the max: lowest index wins
+                    const unsigned lo = wave_max_u32_bcast(mb == hi ? n : 0u);
+                    l = __builtin_ctzll(__ballot(mb == hi && n == lo));
+                }
+                bmax = wrl_dyn(bmax, hi, k);
+                bidx = wrl_dyn(bidx, __builtin_amdgcn_readlane(n, l), k);
+                bx = wrl_dyn_f(bx, rdl_f(x, l), k);
+                by = wrl_dyn_f(by, rdl_f(y, l), k);
+                bz = wrl_dyn_f(bz, rdl_f(z, l), k);
+            } while (act);
+            // wave best = arg-max over the bucket keys in lanes 0..PPT-1
+            wk_hi = __builtin_amdgcn_readlane(half_max_u32<PSTEPS>(bmax), 0);
+            const unsigned long long wt = __ballot(bmax == wk_hi);
+            int kb = __builtin_ctzll(wt);
+            if (wt & (wt - 1)) {                                          // equal maxima in several buckets
+                wk_lo = __builtin_amdgcn_readlane(half_max_u32<PSTEPS>(bmax == wk_hi ? bidx : 0u), 0);
+                kb = __builtin_ctzll(__ballot(bmax == wk_hi && bidx == wk_lo));
+            } else {
+                wk_lo = __builtin_amdgcn_readlane(bidx, kb);
+            }
+            wx = rdl_f(bx, kb);
+            wy = rdl_f(by, kb);
+            wz = rdl_f(bz, kb);
+        }
+        unsigned glo;
+        if constexpr (NW == 1) {
+            glo = wk_lo;
+            cx = wx; cy = wy; cz = wz;
+        } else {
+            const int buf = i & 1;
+            const int b3n = b3 == 2 ? 0 : b3 + 1;
+            if (lane == 0) {
+                const unsigned lo = ((wk_lo & 0x0fffffffu) << 4) | (unsigned)wave;   // index order kept, N < 2^28
+                atomicMax(&s_gkey[b3], ((u64)wk_hi << 32) | lo);
+                float4 r;
+                r.x = wx; r.y = wy; r.z = wz; r.w = 0.f;
+                *reinterpret_cast<float4 *>(&s_wxyz[buf][wave][0]) = r;
+                if (wave == 0) s_gkey[b3n] = 0ull;
+            }
+            __syncthreads();
+            const u64 gk = s_gkey[b3];
+            const float4 rec = *reinterpret_cast<const float4 *>(&s_wxyz[buf][lane & (NW - 1)][0]);
+            const unsigned g = __builtin_amdgcn_readfirstlane((unsigned)gk);
+            const int slot = g & 15;
+            glo = ~(0x0fffffffu - (g >> 4));
+            cx = rdl_f(rec.x, slot);
+            cy = rdl_f(rec.y, slot);
+            cz = rdl_f(rec.z, slot);
+            b3 = b3n;
+        }
+        if (tid == 0) out[i] = (int)(~glo);
+    }
+}
+
+template <int NW, int PPT>
+void launch_cell(const float *xyz, const int *perm, int B, int N, int M, int *idx, hipStream_t st) {
+    hipLaunchKernelGGL((fps_cell_kernel<NW, PPT>), dim3(B), dim3(NW * 64), 0, st, xyz, perm, N, M, idx);
+}
+
 template <int THREADS, int PPT>
 void launch_bucket(const float *xyz, const int *perm, int B, int N, int M, int *idx, hipStream_t st) {
     hipLaunchKernelGGL((fps_bucket_kernel<THREADS, PPT>), dim3(B), dim3(THREADS), 0, st, xyz, perm, N, M, idx);
@@ -296,6 +482,27 @@ int launch_fps_bucket(const float *xyz, int B, int N, int M, int32_t *idx, void 
     int *perm = (int *)workspace;
     hipLaunchKernelGGL(fps_sort_kernel, dim3(B), dim3(SORT_T), sizeof(int) * SORT_CELLS, st, xyz, N, perm);
     if (int e = check_launch("sad_fps_f32 (sort)")) return e;
+    if (get_option(OPT_FPS_VARIANT) != 3) {   // default: cell-bucket kernel (3 = wave/thread-bucket kernel)
+        // geometry = waves * 100 + slots; fps_threads option overrides (for sweeps)
+        const int nb = (N + 63) / 64;                       // buckets
+        int geo = get_option(OPT_FPS_THREADS);
+        if (geo < 100) geo = nb > 128 ? 1616 : (nb > 32 ? 816 : (nb > 16 ? 408 : 404));
+        const int nw = geo / 100, ppt = geo % 100;
+        if (nw * ppt < nb || !(nw == 1 || nw == 2 || nw == 4 || nw == 8 || nw == 16) ||
+            !(ppt == 4 || ppt == 8 || ppt == 16 || ppt == 32))
+            return fail(SAD_EINVAL, "sad_fps_f32: cell geometry %d cannot hold %d buckets", geo, nb);
+#define SAD_CELL(NW_, PPT_) case NW_ * 100 + PPT_: launch_cell<NW_, PPT_>(xyz, perm, B, N, M, idx, st); break;
+        switch (geo) {
+            SAD_CELL(16, 4) SAD_CELL(16, 8) SAD_CELL(16, 16)
+            SAD_CELL(8, 4) SAD_CELL(8, 8) SAD_CELL(8, 16) SAD_CELL(8, 32)
+            SAD_CELL(4, 4) SAD_CELL(4, 8) SAD_CELL(4, 16) SAD_CELL(4, 32)
+            SAD_CELL(2, 8) SAD_CELL(2, 16) SAD_CELL(2, 32)
+            SAD_CELL(1, 16) SAD_CELL(1, 32)
+            default: return fail(SAD_EINVAL, "sad_fps_f32: cell geometry %d not built", geo);
+        }
+#undef SAD_CELL
+        return check_launch("sad_fps_f32 (cell)");
+    }
     if (N <= 2048) {
         const int ppt = (N + 255) / 256;
         if (ppt <= 2) launch_bucket<256, 2>(xyz, perm, B, N, M, idx, st);

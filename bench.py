@@ -244,6 +244,10 @@ def main():
             iso_log, ops.LAUNCH_LOG = ops.LAUNCH_LOG, None
             iso_ms = sum(e0.elapsed_time(e1) for k, _, e0, e1 in iso_log if k == "mlp") / 5
             iso = exec_flops / (iso_ms * 1e-3) / 1e12 if iso_ms > 0 else 0.0
+            iso_name = {}
+            for k, n, e0, e1 in iso_log:
+                if k == "mlp":
+                    iso_name[n] = iso_name.get(n, 0.0) + e0.elapsed_time(e1) / 5
             res["roofline"] = {
                 "kernel": f"mlp_chain_kernel ({n_mlp} launches per step, summed)",
                 "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_MFMA_F32_TFLOPS,
@@ -277,7 +281,9 @@ def main():
                              "pair_tests_per_s": round(work["pair_tests"] * B / (bq_ms * 1e-3) / 1e12, 3)})
             res["kernels"] = kern
             res["mlp_launches"] = {n: {"ms": round(v / tsteps, 3), "executed_gflop": round(per_flops.get(n, 0) / 1e9, 1),
-                                       "tflops": round(per_flops.get(n, 0) / (v / tsteps * 1e-3) / 1e12, 1)}
+                                       "tflops": round(per_flops.get(n, 0) / (v / tsteps * 1e-3) / 1e12, 1),
+                                       "ms_single_stream": round(iso_name.get(n, 0.0), 3),
+                                       "tflops_single_stream": round(per_flops.get(n, 0) / (iso_name[n] * 1e-3) / 1e12, 1) if iso_name.get(n) else None}
                                    for (k, n), v in sorted(per_name.items()) if k == "mlp"}
         if not args.no_cpu and world == 1:
             res["cpu_baseline"] = cpu_baseline(cfg, weights, args.cpu_scenes)

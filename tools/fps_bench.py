@@ -16,10 +16,12 @@ def timeit(fn, reps=3):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps
 cur = xyz
+GEOS = {16384: (832, 1616), 4096: (416, 808, 1604, 232, 816), 1024: (404, 208, 116, 408, 804)}
 for N, M in ((16384, 4096), (4096, 1024), (1024, 512)):
     ref = None
-    for name, dpp, var, th in (("key", 0, 2, 0), ("bucket1024", 0, 3, 1024), ("bucket512", 0, 3, 512), ("bucket256", 0, 3, 256)):
-        _lib.set_option("fps_dpp", dpp); _lib.set_option("fps_variant", var); _lib.set_option("fps_threads", th)
+    variants = [("key", 2, 0), ("wavebucket", 3, 1024)] + [(f"cell{g}", 4, g) for g in GEOS[N]]
+    for name, var, th in variants:
+        _lib.set_option("fps_variant", var); _lib.set_option("fps_threads", th)
         t = timeit(lambda: ops.fps(cur, M))
         idx = ops.fps(cur, M)
         if ref is None: ref = idx
