@@ -35,6 +35,19 @@ class MlpArgs(ctypes.Structure):
     ]
 
 
+class MlpBf16Args(ctypes.Structure):
+    """``struct sad_mlp_bf16_args`` (include/sad_amd.h)."""
+    _fields_ = [
+        ("xyz", vp), ("new_xyz", vp), ("idx", vp), ("feat", vp),
+        ("feat_bf16", ctypes.c_int), ("ld_feat", ctypes.c_int),
+        ("B", ctypes.c_int), ("N", ctypes.c_int), ("M", ctypes.c_int), ("S", ctypes.c_int),
+        ("C", ctypes.c_int),
+        ("L", ctypes.c_int), ("dims", ctypes.c_int * (MAX_LAYERS + 1)),
+        ("packed", vp), ("relu_mask", ctypes.c_int),
+        ("out", vp), ("out_bf16", ctypes.c_int), ("ld_out", ctypes.c_int), ("col_off", ctypes.c_int),
+    ]
+
+
 # name -> (restype, argtypes); every symbol include/sad_amd.h declares
 SIGNATURES = {
     "sad_version": (ctypes.c_int, []),
@@ -60,6 +73,10 @@ SIGNATURES = {
                                        ctypes.POINTER(vp), ctypes.POINTER(vp), vp, vp]),
     "sad_mlp_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     "sad_mlp_chain_f32": (ctypes.c_int, [ctypes.POINTER(MlpArgs), vp]),
+    "sad_mlp_packed_bytes_bf16": (ctypes.c_size_t, [ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.c_int]),
+    "sad_mlp_pack_bf16": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.c_int,
+                                        ctypes.POINTER(vp), ctypes.POINTER(vp), vp, vp]),
+    "sad_mlp_chain_bf16": (ctypes.c_int, [ctypes.POINTER(MlpBf16Args), vp]),
     "sad_candidates_f32": (ctypes.c_int, [vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                          ctypes.c_float, ctypes.c_float, ctypes.c_float, c_f32p,
                                          vp, vp, vp]),

@@ -1,0 +1,359 @@
+// Grouped / plain point-feature MLP chain in bfloat16 on the gfx950 matrix cores (SPEC.md §14;
+// BASELINE.json configs[4] "bf16, MFMA grouped-MLP path").  No reference source exists
+// (/root/reference/README.md:1-2).
+//
+// One workgroup (4 waves) owns a tile of R rows (R = 128 / 64 / 32, the largest that fits LDS) and
+// carries it through ALL layers of the chain: activations never leave LDS between layers.
+//   * layer-0 input [feat(C) ‖ rel_xyz(3) ‖ 0-pad] is gathered straight into LDS as bf16 rows
+//     (16-byte chunks of the point-major bf16 feature array; relative coordinates are formed in
+//     binary32 and rounded once).  The weight columns are permuted at pack time to this order.
+//   * a layer is a set of 32x32 output tiles, dealt round-robin to the waves with the row block
+//     fastest, so the four waves work on the same weight tile at the same time (L1/L2 hits);
+//     v_mfma_f32_32x32x16_bf16: the activation fragment is one ds_read_b128 per lane, the weight
+//     fragment one global_load_dwordx4 per lane from a pre-packed fragment-order image.
+//   * hidden layers run as  D[cout, row] = W·Xᵀ  — a lane then holds 4 consecutive output channels
+//     of ONE row per accumulator quad, i.e. one 8-byte bf16 store into the next layer's row-major
+//     LDS image;  the last grouped layer runs as  D[row, cout] = X·Wᵀ  — a lane holds 16 rows of
+//     ONE channel, so the max-pool over a group is 15 v_max + one cross-half exchange, merged into
+//     the zero-initialised output with an integer atomic max (values are >= +0 after the ReLU).
+// Accumulation is binary32 inside the matrix core; SPEC §14 leaves its order free, so parity is a
+// stated tolerance, not bit equality.
+#include "common.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BF_T = 256;   // threads per workgroup (4 waves)
+
+struct BfParams {
+    const float *xyz, *new_xyz;
+    const int32_t *idx;        // NULL = plain mode
+    const void *feat;
+    int feat_bf16;             // element type of feat: 1 = bf16, 0 = f32
+    int ld_feat;               // row stride of feat in elements
+    int N, M, S, C;
+    long long rows;            // B*M*S (grouped) or B*M (plain)
+    int L;
+    int kp[SAD_MAX_LAYERS + 1];   // padded input width of layer l (kp[0] % 16 == 0, others % 32 == 0)
+    int cout[SAD_MAX_LAYERS];     // true output width of layer l
+    const bf16x8 *w[SAD_MAX_LAYERS];   // fragment image: [cout tile][k block][lane] x 8 bf16
+    const float *bias[SAD_MAX_LAYERS]; // padded to a multiple of 32 with zeros
+    int relu_mask;
+    void *out;
+    int out_bf16;              // plain mode only
+    int ld_out, col_off;
+    int R;                     // rows per tile
+    int bufA_elems;            // bf16 elements of LDS buffer 0 (buffer 1 follows)
+    int tiles;
+};
+
+__device__ __forceinline__ void atomic_max_pos(float *addr, float v) {
+    atomicMax(reinterpret_cast<unsigned *>(addr), __builtin_bit_cast(unsigned, v));
+}
+
+__device__ __forceinline__ __bf16 load_feat(const void *feat, int is_bf16, size_t i) {
+    return is_bf16 ? reinterpret_cast<const __bf16 *>(feat)[i] : (__bf16) reinterpret_cast<const float *>(feat)[i];
+}
+
+__global__ __launch_bounds__(BF_T) void mlp_bf16_kernel(const BfParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __bf16 *const buf0 = reinterpret_cast<__bf16 *>(smem);
+    __bf16 *const buf1 = buf0 + p.bufA_elems;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int R = p.R, NRB = R >> 5;
+    const bool grouped = p.idx != nullptr;
+    const int C = p.C;
+    const int ld0 = p.kp[0] + 8;
+    const bool vec = p.feat && (C & 7) == 0 && (p.ld_feat & 7) == 0;   // 16-byte (bf16) / 32-byte (f32) chunks
+
+    for (int tile = blockIdx.x; tile < p.tiles; tile += gridDim.x) {
+        const long long row0 = (long long)tile * R;
+        // ---- stage the layer-0 input rows ----------------------------------------------------
+        if (vec) {
+            const int C8 = C >> 3;
+            for (int e = tid; e < R * C8; e += BF_T) {
+                const int r = e / C8, c8 = e - r * C8;
+                const long long row = row0 + r;
+                bf16x8 v = {};
+                if (row < p.rows) {
+                    size_t src;
+                    if (grouped) {
+                        const long long b = row / ((long long)p.M * p.S);
+                        src = ((size_t)b * p.N + p.idx[row]) * p.ld_feat + c8 * 8;
+                    } else {
+                        src = (size_t)row * p.ld_feat + c8 * 8;
+                    }
+                    if (p.feat_bf16) {
+                        v = *reinterpret_cast<const bf16x8 *>(reinterpret_cast<const __bf16 *>(p.feat) + src);
+                    } else {
+                        const float4 a = *reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(p.feat) + src);
+                        const float4 b4 = *reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(p.feat) + src + 4);
+                        v[0] = (__bf16)a.x; v[1] = (__bf16)a.y; v[2] = (__bf16)a.z; v[3] = (__bf16)a.w;
+                        v[4] = (__bf16)b4.x; v[5] = (__bf16)b4.y; v[6] = (__bf16)b4.z; v[7] = (__bf16)b4.w;
+                    }
+                }
+                *reinterpret_cast<bf16x8 *>(buf0 + r * ld0 + c8 * 8) = v;
+            }
+        }
+        for (int r = tid; r < R; r += BF_T) {
+            const long long row = row0 + r;
+            const bool ok = row < p.rows;
+            __bf16 *x = buf0 + r * ld0;
+            size_t src = 0;
+            long long g = 0, b = 0;
+            int j = 0;
+            if (ok && grouped) {
+                g = row / p.S;
+                b = g / p.M;
+                j = p.idx[row];
+                src = ((size_t)b * p.N + j) * p.ld_feat;
+            } else if (ok) {
+                src = (size_t)row * p.ld_feat;
+            }
+            if (!vec)
+                for (int c = 0; c < C; ++c) x[c] = ok ? load_feat(p.feat, p.feat_bf16, src + c) : (__bf16)0.f;
+            int c = C;
+            if (grouped) {
+                float d0 = 0.f, d1 = 0.f, d2 = 0.f;
+                if (ok) {
+                    const float *q = p.xyz + ((size_t)b * p.N + j) * 3;
+                    const float *cen = p.new_xyz + (size_t)g * 3;
+                    d0 = q[0] - cen[0];
+                    d1 = q[1] - cen[1];
+                    d2 = q[2] - cen[2];
+                }
+                x[c] = (__bf16)d0; x[c + 1] = (__bf16)d1; x[c + 2] = (__bf16)d2;
+                c += 3;
+            }
+            for (; c < p.kp[0]; ++c) x[c] = (__bf16)0.f;
+        }
+        __syncthreads();
+
+        // ---- layers ---------------------------------------------------------------------------
+        for (int l = 0; l < p.L; ++l) {
+            const __bf16 *X = (l & 1) ? buf1 : buf0;
+            __bf16 *Y = (l & 1) ? buf0 : buf1;
+            const int ldx = p.kp[l] + 8, ldy = p.kp[l + 1] + 8;
+            const int KB = p.kp[l] >> 4;
+            const int CT = (p.cout[l] + 31) >> 5;
+            const bool last = l == p.L - 1;
+            const bool relu = (p.relu_mask >> l) & 1;
+            const bool pool = last && grouped;
+            for (int tt = wave; tt < NRB * CT; tt += BF_T / 64) {
+                const int ct = tt / NRB, rb = tt - ct * NRB;
+                const bf16x8 *wp = p.w[l] + (size_t)ct * KB * 64 + lane;
+                const __bf16 *xp = X + (rb * 32 + (lane & 31)) * ldx + (lane >> 5) * 8;
+                const float *bias = p.bias[l] + ct * 32;
+                f32x16 acc;
+                if (pool) {
+                    const float bv = bias[lane & 31];
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) acc[i] = bv;
+#pragma unroll 4
+                    for (int kb = 0; kb < KB; ++kb)
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8 *>(xp + kb * 16),
+                                                                      wp[kb * 64], acc, 0, 0, 0);
+                    // acc[i] = y[row rb*32 + 8*(i/4) + 4*(lane/32) + i%4][cout ct*32 + lane%32]
+                    const long long rbase = row0 + rb * 32;
+                    const int co = ct * 32 + (lane & 31);
+                    float *orow = reinterpret_cast<float *>(p.out) + p.col_off + co;
+                    if (rbase < p.rows) {
+                        if ((p.S & 31) == 0) {
+                            float m = 0.f;
+#pragma unroll
+                            for (int i = 0; i < 16; ++i) m = acc[i] > m ? acc[i] : m;
+                            const float o = __shfl_xor(m, 32, 64);
+                            m = o > m ? o : m;
+                            if (lane < 32 && co < p.cout[l]) atomic_max_pos(orow + (size_t)(rbase / p.S) * p.ld_out, m);
+                        } else if (p.S == 16) {
+                            float m0 = 0.f, m1 = 0.f;
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) { m0 = acc[i] > m0 ? acc[i] : m0; m1 = acc[8 + i] > m1 ? acc[8 + i] : m1; }
+                            const float o0 = __shfl_xor(m0, 32, 64), o1 = __shfl_xor(m1, 32, 64);
+                            m0 = o0 > m0 ? o0 : m0;
+                            m1 = o1 > m1 ? o1 : m1;
+                            if (lane < 32 && co < p.cout[l]) {
+                                const size_t g0 = (size_t)(rbase / 16);
+                                atomic_max_pos(orow + g0 * p.ld_out, m0);
+                                if (rbase + 16 < p.rows) atomic_max_pos(orow + (g0 + 1) * p.ld_out, m1);
+                            }
+                        } else if (co < p.cout[l]) {
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                const long long r = rbase + 8 * q + 4 * (lane >> 5);
+#pragma unroll
+                                for (int i = 0; i < 4; ++i)
+                                    if (r + i < p.rows) {
+                                        const float v = acc[4 * q + i] > 0.f ? acc[4 * q + i] : 0.f;
+                                        atomic_max_pos(orow + (size_t)((r + i) / p.S) * p.ld_out, v);
+                                    }
+                            }
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) acc[i] = bias[8 * (i >> 2) + 4 * (lane >> 5) + (i & 3)];
+#pragma unroll 4
+                    for (int kb = 0; kb < KB; ++kb)
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wp[kb * 64],
+                                                                      *reinterpret_cast<const bf16x8 *>(xp + kb * 16), acc, 0, 0, 0);
+                    // acc[i] = y[row rb*32 + lane%32][cout ct*32 + 8*(i/4) + 4*(lane/32) + i%4]
+                    if (relu)
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) acc[i] = acc[i] > 0.f ? acc[i] : 0.f;
+                    const int r = rb * 32 + (lane & 31);
+                    if (!last) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            bf16x4 v;
+                            v[0] = (__bf16)acc[4 * q]; v[1] = (__bf16)acc[4 * q + 1];
+                            v[2] = (__bf16)acc[4 * q + 2]; v[3] = (__bf16)acc[4 * q + 3];
+                            *reinterpret_cast<bf16x4 *>(Y + r * ldy + ct * 32 + 8 * q + 4 * (lane >> 5)) = v;
+                        }
+                    } else if (row0 + r < p.rows) {
+                        const size_t o = (size_t)(row0 + r) * p.ld_out + p.col_off;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                const int co = ct * 32 + 8 * q + 4 * (lane >> 5) + i;
+                                if (co < p.cout[l]) {
+                                    if (p.out_bf16) reinterpret_cast<__bf16 *>(p.out)[o + co] = (__bf16)acc[4 * q + i];
+                                    else reinterpret_cast<float *>(p.out)[o + co] = acc[4 * q + i];
+                                }
+                            }
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// W[l] f32 [cout][cin] row-major -> fragment image + padded bias.  Internal input order of layer 0
+// in grouped mode is [feat(C) ‖ xyz(3)]: internal k < C reads W column 3 + k, k = C..C+2 column k - C.
+__global__ void pack_bf16_kernel(const float *__restrict__ W, const float *__restrict__ bias, int cin, int cout,
+                                 int kp, int xyz_first, __bf16 *__restrict__ wout, float *__restrict__ bout) {
+    const int KB = kp >> 4, CT = (cout + 31) >> 5;
+    const size_t total = (size_t)CT * KB * 64 * 8;
+    for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int j = e & 7, lane = (e >> 3) & 63;
+        const size_t f = e >> 9;
+        const int kb = f % KB, ct = f / KB;
+        const int co = ct * 32 + (lane & 31);
+        const int k = kb * 16 + (lane >> 5) * 8 + j;
+        float v = 0.f;
+        if (co < cout && k < cin) {
+            int col = k;
+            if (xyz_first) col = k < cin - 3 ? k + 3 : k - (cin - 3);
+            v = W[(size_t)co * cin + col];
+        }
+        wout[e] = (__bf16)v;
+    }
+    for (int o = blockIdx.x * blockDim.x + threadIdx.x; o < CT * 32; o += gridDim.x * blockDim.x)
+        bout[o] = o < cout ? bias[o] : 0.f;
+}
+
+inline int kpad(int l, int width) { return l == 0 ? (width + 15) & ~15 : (width + 31) & ~31; }
+inline size_t align16(size_t v) { return (v + 15) & ~(size_t)15; }
+
+}  // namespace
+
+SAD_API size_t sad_mlp_packed_bytes_bf16(int L, const int *dims, int first_has_xyz) {
+    (void)first_has_xyz;
+    if (L < 1 || L > SAD_MAX_LAYERS || !dims) return 0;
+    size_t n = 0;
+    for (int l = 0; l < L; ++l) {
+        const int CT = (dims[l + 1] + 31) / 32;
+        n += align16((size_t)CT * 32 * kpad(l, dims[l]) * 2) + align16((size_t)CT * 32 * 4);
+    }
+    return n;
+}
+
+SAD_API int sad_mlp_pack_bf16(int L, const int *dims, int first_has_xyz, const float *const *W,
+                              const float *const *bias, void *packed, sad_stream_t stream) {
+    SAD_REQUIRE(L >= 1 && L <= SAD_MAX_LAYERS && dims && W && bias && packed, "sad_mlp_pack_bf16: bad argument");
+    SAD_REQUIRE((uintptr_t)packed % 16 == 0, "sad_mlp_pack_bf16: packed must be 16-byte aligned");
+    unsigned char *q = (unsigned char *)packed;
+    for (int l = 0; l < L; ++l) {
+        SAD_REQUIRE(dims[l] >= 1 && dims[l + 1] >= 1 && W[l] && bias[l], "sad_mlp_pack_bf16: bad layer %d", l);
+        SAD_REQUIRE(!(l == 0 && first_has_xyz) || dims[0] >= 3, "sad_mlp_pack_bf16: first layer needs >= 3 inputs");
+        const int CT = (dims[l + 1] + 31) / 32, kp = kpad(l, dims[l]);
+        __bf16 *wout = (__bf16 *)q;
+        q += align16((size_t)CT * 32 * kp * 2);
+        float *bout = (float *)q;
+        q += align16((size_t)CT * 32 * 4);
+        hipLaunchKernelGGL(pack_bf16_kernel, dim3(64), dim3(256), 0, (hipStream_t)stream, W[l], bias[l], dims[l],
+                           dims[l + 1], kp, (l == 0 && first_has_xyz) ? 1 : 0, wout, bout);
+    }
+    return sad::check_launch("sad_mlp_pack_bf16");
+}
+
+SAD_API int sad_mlp_chain_bf16(const sad_mlp_bf16_args *a, sad_stream_t stream) {
+    SAD_REQUIRE(a, "sad_mlp_chain_bf16: NULL args");
+    SAD_REQUIRE(a->L >= 1 && a->L <= SAD_MAX_LAYERS && a->packed && a->out, "sad_mlp_chain_bf16: bad argument");
+    SAD_REQUIRE((uintptr_t)a->packed % 16 == 0, "sad_mlp_chain_bf16: packed must be 16-byte aligned");
+    SAD_REQUIRE(a->B >= 1 && a->M >= 1 && a->C >= 0, "sad_mlp_chain_bf16: bad sizes");
+    const bool grouped = a->idx != nullptr;
+    BfParams p{};
+    if (grouped) {
+        SAD_REQUIRE(a->xyz && a->new_xyz && a->N >= 1 && a->S >= 1, "sad_mlp_chain_bf16: grouped mode needs xyz, new_xyz, N, S");
+        SAD_REQUIRE(a->dims[0] == a->C + 3, "sad_mlp_chain_bf16: dims[0]=%d != C+3=%d", a->dims[0], a->C + 3);
+        SAD_REQUIRE((a->relu_mask & ((1 << a->L) - 1)) == (1 << a->L) - 1, "sad_mlp_chain_bf16: every grouped layer needs a ReLU");
+        SAD_REQUIRE(!a->out_bf16, "sad_mlp_chain_bf16: grouped output is f32 (atomic max merge)");
+        p.rows = (long long)a->B * a->M * a->S;
+    } else {
+        SAD_REQUIRE(a->dims[0] == a->C && a->C >= 1 && a->S == 1, "sad_mlp_chain_bf16: plain mode needs dims[0] == C, S == 1");
+        p.rows = (long long)a->B * a->M;
+    }
+    SAD_REQUIRE(a->C == 0 || a->feat, "sad_mlp_chain_bf16: NULL feat");
+    if (a->feat && (a->C & 7) == 0 && (a->ld_feat & 7) == 0)
+        SAD_REQUIRE((uintptr_t)a->feat % 16 == 0, "sad_mlp_chain_bf16: feat must be 16-byte aligned");
+    p.xyz = a->xyz; p.new_xyz = a->new_xyz; p.idx = a->idx;
+    p.feat = a->feat; p.feat_bf16 = a->feat_bf16; p.ld_feat = a->ld_feat;
+    p.N = a->N; p.M = a->M; p.S = a->S; p.C = a->C;
+    p.L = a->L; p.relu_mask = a->relu_mask;
+    p.out = a->out; p.out_bf16 = a->out_bf16; p.ld_out = a->ld_out; p.col_off = a->col_off;
+    const unsigned char *q = (const unsigned char *)a->packed;
+    int ldA = 0, ldB = 0;
+    for (int l = 0; l < a->L; ++l) {
+        p.kp[l] = kpad(l, a->dims[l]);
+        p.cout[l] = a->dims[l + 1];
+        const int CT = (a->dims[l + 1] + 31) / 32;
+        p.w[l] = (const bf16x8 *)q;
+        q += align16((size_t)CT * 32 * p.kp[l] * 2);
+        p.bias[l] = (const float *)q;
+        q += align16((size_t)CT * 32 * 4);
+        int &ld = (l & 1) ? ldB : ldA;
+        ld = ld > p.kp[l] + 8 ? ld : p.kp[l] + 8;
+    }
+    p.kp[a->L] = kpad(a->L, a->dims[a->L]);
+    const size_t budget = 150 * 1024;
+    int R = 128;
+    while (R > 32 && (size_t)R * 2 * (ldA + ldB) > budget) R >>= 1;
+    const size_t lds = (size_t)R * 2 * (ldA + ldB);
+    if (lds > 160 * 1024) return sad::fail(SAD_EUNSUPPORTED, "sad_mlp_chain_bf16: layer widths need %zu bytes of LDS", lds);
+    while (R > 32 && p.rows <= R / 2) R >>= 1;
+    p.R = R;
+    p.bufA_elems = R * ldA;
+    const long long tiles = (p.rows + R - 1) / R;
+    SAD_REQUIRE(tiles < (1LL << 31), "sad_mlp_chain_bf16: too many rows");
+    p.tiles = (int)tiles;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&mlp_bf16_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            (void)hipGetLastError();
+        attr_set = true;
+    }
+    const size_t lds_now = (size_t)R * 2 * (ldA + ldB);
+    int per_cu = (int)((160 * 1024) / (lds_now > 0 ? lds_now : 1));
+    per_cu = per_cu < 1 ? 1 : (per_cu > 4 ? 4 : per_cu);
+    const int grid = (int)(tiles < 256LL * per_cu ? tiles : 256LL * per_cu);
+    hipLaunchKernelGGL(mlp_bf16_kernel, dim3(grid), dim3(BF_T), lds_now, (hipStream_t)stream, p);
+    return sad::check_launch("sad_mlp_chain_bf16");
+}

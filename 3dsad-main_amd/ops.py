@@ -421,6 +421,116 @@ class PackedMLP:
             raise ValueError("out: col_off + C_out exceeds the buffer width")
 
 
+class PackedMLPBf16:
+    """The same chain in bfloat16 on the matrix cores (SPEC.md §14, BASELINE.json configs[4]).
+
+    Weights are rounded to bf16 once and stored in MFMA fragment order; features are bf16 tensors
+    (float32 accepted and rounded on load); accumulation is float32.  Grouped output is float32
+    (pooled), plain output float32 or bfloat16.  Dense rows — ball-query padding is computed."""
+
+    def __init__(self, layers, first_has_xyz: bool, device, relu_mask: Optional[int] = None,
+                 name: str = ""):
+        self.name = name
+        if not 1 <= len(layers) <= _lib.MAX_LAYERS:
+            raise ValueError(f"1..{_lib.MAX_LAYERS} layers supported")
+        self.device = torch.device(device)
+        ws = [torch.as_tensor(w, dtype=torch.float32).to(self.device).contiguous() for w, _ in layers]
+        bs = [torch.as_tensor(b, dtype=torch.float32).to(self.device).contiguous() for _, b in layers]
+        self.dims = [ws[0].shape[1]] + [w.shape[0] for w in ws]
+        for a, b in zip(ws[:-1], ws[1:]):
+            if b.shape[1] != a.shape[0]:
+                raise ValueError("layer shapes do not chain")
+        self.L = len(ws)
+        self.first_has_xyz = bool(first_has_xyz)
+        self.relu_mask = (1 << self.L) - 1 if relu_mask is None else int(relu_mask)
+        dims_c = (ctypes.c_int * (self.L + 1))(*self.dims)
+        n = lib().sad_mlp_packed_bytes_bf16(self.L, dims_c, int(self.first_has_xyz))
+        self.packed = torch.empty((n,), dtype=torch.uint8, device=self.device)
+        w_arr = (vp * self.L)(*[w.data_ptr() for w in ws])
+        b_arr = (vp * self.L)(*[b.data_ptr() for b in bs])
+        with torch.cuda.device(self.device):
+            check(lib().sad_mlp_pack_bf16(self.L, dims_c, int(self.first_has_xyz), w_arr, b_arr,
+                                          self.packed.data_ptr(), _stream()), "sad_mlp_pack_bf16")
+            torch.cuda.current_stream().synchronize()
+        self.out_channels = self.dims[-1]
+
+    def _args(self) -> _lib.MlpBf16Args:
+        a = _lib.MlpBf16Args()
+        a.L = self.L
+        for i, d in enumerate(self.dims):
+            a.dims[i] = d
+        a.packed = self.packed.data_ptr()
+        a.relu_mask = self.relu_mask
+        return a
+
+    @staticmethod
+    def _feat(t: torch.Tensor, name: str):
+        if not t.is_cuda or t.dtype not in (torch.bfloat16, torch.float32):
+            raise TypeError(f"{name}: expected a GPU bfloat16 or float32 tensor")
+        return 1 if t.dtype == torch.bfloat16 else 0
+
+    def grouped(self, xyz: torch.Tensor, feat_pm: Optional[torch.Tensor], new_xyz: torch.Tensor,
+                idx: torch.Tensor, out: Optional[torch.Tensor] = None, col_off: int = 0) -> torch.Tensor:
+        """xyz [B,N,3] f32; feat_pm point-major [B,N,C] bf16/f32 (or None); new_xyz [B,M,3]; idx
+        [B,M,S] -> out[:, :, col_off:col_off+C_out] of a ZERO-initialised float32 [B,M,ld] buffer."""
+        if not self.first_has_xyz:
+            raise RuntimeError("this PackedMLPBf16 was packed without the xyz prefix")
+        xyz = _need(xyz, "xyz", torch.float32, 3)
+        new_xyz = _need(new_xyz, "new_xyz", torch.float32, 3)
+        idx = _need(idx, "idx", torch.int32, 3)
+        B, N, _ = xyz.shape
+        _, M, S = idx.shape
+        a = self._args()
+        C = 0
+        if feat_pm is not None:
+            a.feat_bf16 = self._feat(feat_pm, "feat_pm")
+            if feat_pm.dim() != 3:
+                raise ValueError("feat_pm: expected [B,N,C]")
+            if feat_pm.stride(2) != 1 or feat_pm.stride(0) != N * feat_pm.stride(1):
+                feat_pm = feat_pm.contiguous()
+            C = feat_pm.shape[2]
+            a.feat, a.ld_feat = feat_pm.data_ptr(), feat_pm.stride(1)
+        if self.dims[0] != C + 3:
+            raise ValueError(f"MLP expects {self.dims[0] - 3} feature channels, got {C}")
+        if out is None:
+            out = torch.zeros((B, M, self.out_channels), dtype=torch.float32, device=xyz.device)
+        if out.dtype != torch.float32 or not out.is_contiguous() or col_off + self.out_channels > out.shape[-1]:
+            raise ValueError("out: expected a contiguous float32 [B,M,ld_out] buffer wide enough")
+        a.xyz, a.new_xyz, a.idx = xyz.data_ptr(), new_xyz.data_ptr(), idx.data_ptr()
+        a.B, a.N, a.M, a.S, a.C = B, N, M, S, C
+        a.out, a.out_bf16, a.ld_out, a.col_off = out.data_ptr(), 0, out.stride(-2), col_off
+        with _timed("mlp_bf16", self.name):
+            check(lib().sad_mlp_chain_bf16(ctypes.byref(a), _stream()), "sad_mlp_chain_bf16")
+        return out
+
+    def rows(self, x: torch.Tensor, out: Optional[torch.Tensor] = None, col_off: int = 0,
+             out_dtype=torch.float32) -> torch.Tensor:
+        """Plain rows.  x [..., C] bf16/f32 (last-dim stride 1) -> [..., C_out] f32 or bf16."""
+        if self.first_has_xyz:
+            raise RuntimeError("this PackedMLPBf16 was packed with the xyz prefix")
+        a = self._args()
+        a.feat_bf16 = self._feat(x, "x")
+        C = x.shape[-1]
+        if C != self.dims[0]:
+            raise ValueError(f"MLP expects {self.dims[0]} channels, got {C}")
+        x2 = x.reshape(-1, C)
+        if x2.stride(1) != 1:
+            x2 = x2.contiguous()
+        R = x2.shape[0]
+        if out is None:
+            out = torch.empty(tuple(x.shape[:-1]) + (self.out_channels,), dtype=out_dtype, device=x.device)
+        if out.dtype not in (torch.float32, torch.bfloat16) or not out.is_contiguous() \
+                or out.numel() // out.shape[-1] != R or col_off + self.out_channels > out.shape[-1]:
+            raise ValueError("out: expected a contiguous f32/bf16 [rows, ld_out] buffer wide enough")
+        a.feat, a.ld_feat = x2.data_ptr(), x2.stride(0)
+        a.B, a.N, a.M, a.S, a.C = 1, 0, R, 1, C
+        a.out, a.out_bf16 = out.data_ptr(), int(out.dtype == torch.bfloat16)
+        a.ld_out, a.col_off = out.stride(-2), col_off
+        with _timed("mlp_bf16", self.name):
+            check(lib().sad_mlp_chain_bf16(ctypes.byref(a), _stream()), "sad_mlp_chain_bf16")
+        return out
+
+
 _BRANCH_STREAMS = {}
 
 

@@ -142,6 +142,34 @@ typedef struct sad_mlp_args {
 size_t sad_mlp_workspace_bytes(int B, int M, int S);
 int sad_mlp_chain_f32(const sad_mlp_args *args, sad_stream_t stream);
 
+/* SPEC.md §14 — the same chain in bfloat16 on the matrix cores (BASELINE.json configs[4]).
+ * Weights are rounded to bf16 and laid out in MFMA fragment order by sad_mlp_pack_bf16 (W/bias as
+ * for sad_mlp_pack_f32; `packed` needs sad_mlp_packed_bytes_bf16() bytes, 16-byte aligned).
+ * Fields as in sad_mlp_args, except: feat is bf16 (feat_bf16 = 1) or f32 (0, rounded on load) with
+ * ld_feat in ELEMENTS; grouped output is f32 and must be zero on entry (atomic max merge); plain
+ * output is f32 or bf16 (out_bf16).  Dense rows: padding rows are computed, not skipped. */
+size_t sad_mlp_packed_bytes_bf16(int L, const int *dims, int first_has_xyz);
+int sad_mlp_pack_bf16(int L, const int *dims, int first_has_xyz, const float *const *W,
+                      const float *const *bias, void *packed, sad_stream_t stream);
+typedef struct sad_mlp_bf16_args {
+    const float *xyz;     /* [B,N,3] f32                               (grouped mode) */
+    const float *new_xyz; /* [B,M,3] f32                               (grouped mode) */
+    const int32_t *idx;   /* [B,M,S] or NULL (plain mode)                             */
+    const void *feat;     /* grouped: point-major [B,N,C]; plain: rows [B*M, C]        */
+    int feat_bf16;
+    int ld_feat;
+    int B, N, M, S, C;
+    int L;
+    int dims[SAD_MAX_LAYERS + 1];
+    const void *packed;
+    int relu_mask;
+    void *out;
+    int out_bf16;
+    int ld_out;
+    int col_off;
+} sad_mlp_bf16_args;
+int sad_mlp_chain_bf16(const sad_mlp_bf16_args *args, sad_stream_t stream);
+
 /* SPEC.md §8 steps 2-4.  xyz3[B,M3,3], c[B,K,6] -> cand[B,K,3], radius[B,K]; anchor[3] host. */
 int sad_candidates_f32(const float *xyz3, const float *c, int B, int M3, int K, float shift_max,
                        float r_min, float r_max, const float *anchor, float *cand, float *radius,

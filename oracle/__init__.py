@@ -178,6 +178,43 @@ def sa_group_mlp_max(xyz, feat_pm, new_xyz, idx, layers, out=None, col_off=0):
     return out
 
 
+def bf16_round(x):
+    """SPEC.md §14: round-to-nearest-even binary32 -> bfloat16, returned as binary32 values."""
+    u = np.ascontiguousarray(x, dtype=np.float32).view(np.uint32).astype(np.uint64)
+    u = (u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000
+    return u.astype(np.uint32).view(np.float32).reshape(np.shape(x))
+
+
+def mlp_rows_bf16(x, layers, relu_mask=None):
+    """SPEC.md §14 on rows x[R, C_in] (binary32 values, rounded to bf16 here).  layers: [(W, b)].
+    Products of bf16 values are exact in binary64; the sum is rounded once to binary32."""
+    L = len(layers)
+    if relu_mask is None:
+        relu_mask = (1 << L) - 1
+    y = np.asarray(x, dtype=np.float32)
+    for l, (W, b) in enumerate(layers):
+        xb = bf16_round(y).astype(np.float64)
+        Wb = bf16_round(np.asarray(W, dtype=np.float32)).astype(np.float64)
+        y = (xb @ Wb.T + np.asarray(b, dtype=np.float64)).astype(np.float32)
+        if (relu_mask >> l) & 1:
+            y = np.maximum(y, 0.0)
+    return y
+
+
+def sa_group_mlp_max_bf16(xyz, feat_pm, new_xyz, idx, layers):
+    """SPEC.md §14 grouped chain: xyz[B,N,3] f32, feat_pm[B,N,C] (bf16-representable f32) or None,
+    new_xyz[B,M,3], idx[B,M,S] -> pooled [B,M,C_out] f32."""
+    B, M, S = idx.shape
+    out = np.empty((B, M, layers[-1][0].shape[0]), np.float32)
+    for b in range(B):
+        j = idx[b].reshape(-1)
+        rel = (xyz[b][j] - np.repeat(new_xyz[b], S, axis=0)).astype(np.float32)
+        rows = rel if feat_pm is None else np.concatenate([rel, feat_pm[b][j]], axis=1)
+        y = mlp_rows_bf16(rows, layers)
+        out[b] = y.reshape(M, S, -1).max(axis=1)
+    return out
+
+
 def candidates(xyz3, c, shift_max, r_min, r_max, anchor):
     """SPEC.md §8 steps 2-4.  xyz3 [B,M3,3], c [B,K,6] -> (cand [B,K,3], radius [B,K])."""
     xyz3, px = _f(xyz3)

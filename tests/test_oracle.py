@@ -401,3 +401,22 @@ def test_nms_bev_vs_python(orc):
         assert (order[b, len(kept):] == -1).all()
         assert keep[b].sum() == len(kept) and all(keep[b, i] == 1 for i in kept)
         assert 0 < len(kept) < len(cand)                    # something was suppressed
+
+
+def test_bf16_oracle_rounding_and_chain(orc):
+    """SPEC.md §14: bf16_round is round-to-nearest-even (checked against torch's conversion), and the
+    bf16 chain equals a float64 matmul of the rounded operands."""
+    import torch
+    rng = np.random.default_rng(14)
+    x = (rng.standard_normal(20000) * np.exp(rng.uniform(-20, 20, 20000))).astype(np.float32)
+    x[:4] = [0.0, -0.0, 1.00390625, 1.01171875]          # ties: 1 + 2^-8 -> even (1.0), 1 + 3*2^-8 -> 1.015625
+    got = orc.bf16_round(x)
+    want = torch.from_numpy(x).bfloat16().float().numpy()
+    assert np.array_equal(got, want)
+    assert got[2] == 1.0 and got[3] == 1.015625
+    W = rng.standard_normal((5, 7)).astype(np.float32)
+    b = rng.standard_normal(5).astype(np.float32)
+    rows = rng.standard_normal((11, 7)).astype(np.float32)
+    y = orc.mlp_rows_bf16(rows, [(W, b)], relu_mask=0)
+    ref = orc.bf16_round(rows).astype(np.float64) @ orc.bf16_round(W).astype(np.float64).T + b
+    assert np.allclose(y, ref, rtol=1e-6, atol=1e-6)
