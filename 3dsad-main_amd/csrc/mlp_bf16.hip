@@ -58,6 +58,190 @@ __device__ __forceinline__ __bf16 load_feat(const void *feat, int is_bf16, size_
     return is_bf16 ? reinterpret_cast<const __bf16 *>(feat)[i] : (__bf16) reinterpret_cast<const float *>(feat)[i];
 }
 
+// All output tiles of layer l for one row tile, in work units of RW row blocks x CW channel tiles
+// dealt round-robin to the waves (an operand fragment then feeds RW or CW MFMAs).  An odd last
+// block / tile is clamped onto its neighbour and its result dropped.  POOL: last layer of a grouped
+// chain (D[row, cout] = X·Wᵀ, max over the group); else D[cout, row] = W·Xᵀ.
+template <int RW, int CW, bool POOL>
+__device__ __forceinline__ void run_units(const BfParams &p, int l, const __bf16 *X, __bf16 *Y, long long row0,
+                                          int wave, int lane, int NRB) {
+    const int ldx = p.kp[l] + 8, ldy = p.kp[l + 1] + 8;
+    const int KB = p.kp[l] >> 4;
+    const int CT = (p.cout[l] + 31) >> 5;
+    const bool last = l == p.L - 1;
+    const bool relu = (p.relu_mask >> l) & 1;
+    const int NRP = (NRB + RW - 1) / RW, NCP = (CT + CW - 1) / CW;
+    for (int tt = wave; tt < NRP * NCP; tt += BF_T / 64) {
+        const int cp = tt / NRP, rp = tt - cp * NRP;
+        int rb[RW], ct[CW];
+        const bf16x8 *wp[CW];
+        const __bf16 *xp[RW];
+#pragma unroll
+        for (int r = 0; r < RW; ++r) {
+            rb[r] = rp * RW + r < NRB ? rp * RW + r : rp * RW;
+            xp[r] = X + (rb[r] * 32 + (lane & 31)) * ldx + (lane >> 5) * 8;
+        }
+#pragma unroll
+        for (int c = 0; c < CW; ++c) {
+            ct[c] = cp * CW + c < CT ? cp * CW + c : cp * CW;
+            wp[c] = p.w[l] + (size_t)ct[c] * KB * 64 + lane;
+        }
+        f32x16 acc[RW][CW];
+#pragma unroll
+        for (int c = 0; c < CW; ++c)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float bv = POOL ? p.bias[l][ct[c] * 32 + (lane & 31)]
+                                      : p.bias[l][ct[c] * 32 + 8 * (i >> 2) + 4 * (lane >> 5) + (i & 3)];
+#pragma unroll
+                for (int r = 0; r < RW; ++r) acc[r][c][i] = bv;
+            }
+        // k loop: weight fragments run WD k-blocks ahead in a register ring (L2 latency), activation
+        // fragments one k-block ahead (LDS latency)
+        constexpr int WD = 4;
+        bf16x8 wr[WD][CW], x[RW];
+#pragma unroll
+        for (int d = 0; d < WD; ++d)
+#pragma unroll
+            for (int c = 0; c < CW; ++c) wr[d][c] = wp[c][(d < KB ? d : KB - 1) * 64];
+#pragma unroll
+        for (int r = 0; r < RW; ++r) x[r] = *reinterpret_cast<const bf16x8 *>(xp[r]);
+        for (int kb0 = 0; kb0 < KB; kb0 += WD) {
+#pragma unroll
+            for (int d = 0; d < WD; ++d) {
+                const int kb = kb0 + d;
+                if (kb < KB) {
+                    const int kn = kb + 1 < KB ? kb + 1 : kb;
+                    bf16x8 nx[RW];
+#pragma unroll
+                    for (int r = 0; r < RW; ++r) nx[r] = *reinterpret_cast<const bf16x8 *>(xp[r] + kn * 16);
+#pragma unroll
+                    for (int c = 0; c < CW; ++c)
+#pragma unroll
+                        for (int r = 0; r < RW; ++r)
+                            acc[r][c] = POOL ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(x[r], wr[d][c], acc[r][c], 0, 0, 0)
+                                             : __builtin_amdgcn_mfma_f32_32x32x16_bf16(wr[d][c], x[r], acc[r][c], 0, 0, 0);
+                    const int kw = kb + WD < KB ? kb + WD : KB - 1;
+#pragma unroll
+                    for (int c = 0; c < CW; ++c) wr[d][c] = wp[c][kw * 64];
+#pragma unroll
+                    for (int r = 0; r < RW; ++r) x[r] = nx[r];
+                }
+            }
+        }
+        if constexpr (POOL) {
+            // acc[r][c][i] = y[row rb*32 + 8*(i/4) + 4*(lane/32) + i%4][cout ct*32 + lane%32]
+            const int S = p.S;
+#pragma unroll
+            for (int c = 0; c < CW; ++c) {
+                if (c > 0 && cp * CW + c >= CT) continue;
+                const int co = ct[c] * 32 + (lane & 31);
+                const bool cok = co < p.cout[l];
+                float *orow = reinterpret_cast<float *>(p.out) + p.col_off + co;
+                if ((S & 31) == 0) {
+                    float m[RW];
+#pragma unroll
+                    for (int r = 0; r < RW; ++r) {
+                        float v = 0.f;
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) v = acc[r][c][i] > v ? acc[r][c][i] : v;
+                        const float o = __shfl_xor(v, 32, 64);
+                        m[r] = o > v ? o : v;
+                    }
+                    if (lane < 32 && cok) {
+                        const long long rbase = row0 + rb[0] * 32;
+                        if (rbase < p.rows) {
+                            if (S == 32) {          // a block is a whole group: plain stores
+#pragma unroll
+                                for (int r = 0; r < RW; ++r)
+                                    if ((r == 0 || rp * RW + r < NRB) && rbase + r * 32 < p.rows)
+                                        orow[(size_t)((rbase + r * 32) / 32) * p.ld_out] = m[r];
+                            } else if (S == 64 && RW == 2 && rp * RW + 1 < NRB) {   // the unit is a whole group
+                                orow[(size_t)(rbase / 64) * p.ld_out] = m[0] > m[RW - 1] ? m[0] : m[RW - 1];
+                            } else {
+#pragma unroll
+                                for (int r = 0; r < RW; ++r)
+                                    if ((r == 0 || rp * RW + r < NRB) && rbase + r * 32 < p.rows)
+                                        atomic_max_pos(orow + (size_t)((rbase + r * 32) / S) * p.ld_out, m[r]);
+                            }
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < RW; ++r) {
+                        if (r > 0 && rp * RW + r >= NRB) continue;
+                        const long long rbase = row0 + rb[r] * 32;
+                        if (rbase >= p.rows) continue;
+                        const f32x16 &av = acc[r][c];
+                        if (S == 16) {
+                            float m0 = 0.f, m1 = 0.f;
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) { m0 = av[i] > m0 ? av[i] : m0; m1 = av[8 + i] > m1 ? av[8 + i] : m1; }
+                            const float o0 = __shfl_xor(m0, 32, 64), o1 = __shfl_xor(m1, 32, 64);
+                            m0 = o0 > m0 ? o0 : m0;
+                            m1 = o1 > m1 ? o1 : m1;
+                            if (lane < 32 && cok) {
+                                const size_t g0 = (size_t)(rbase / 16);
+                                orow[g0 * p.ld_out] = m0;
+                                if (rbase + 16 < p.rows) orow[(g0 + 1) * p.ld_out] = m1;
+                            }
+                        } else if (cok) {
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                const long long rr = rbase + 8 * q + 4 * (lane >> 5);
+#pragma unroll
+                                for (int i = 0; i < 4; ++i)
+                                    if (rr + i < p.rows) {
+                                        const float v = av[4 * q + i] > 0.f ? av[4 * q + i] : 0.f;
+                                        atomic_max_pos(orow + (size_t)((rr + i) / S) * p.ld_out, v);
+                                    }
+                            }
+                        }
+                    }
+                }
+            }
+        } else {
+            // acc[r][c][i] = y[row rb*32 + lane%32][cout ct*32 + 8*(i/4) + 4*(lane/32) + i%4]
+#pragma unroll
+            for (int r = 0; r < RW; ++r) {
+                if (r > 0 && rp * RW + r >= NRB) continue;
+                const int row = rb[r] * 32 + (lane & 31);
+#pragma unroll
+                for (int c = 0; c < CW; ++c) {
+                    if (c > 0 && cp * CW + c >= CT) continue;
+                    const f32x16 &av = acc[r][c];
+                    if (!last) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            bf16x4 v;
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                const float t = av[4 * q + i];
+                                v[i] = (__bf16)(relu && !(t > 0.f) ? 0.f : t);
+                            }
+                            *reinterpret_cast<bf16x4 *>(Y + row * ldy + ct[c] * 32 + 8 * q + 4 * (lane >> 5)) = v;
+                        }
+                    } else if (row0 + row < p.rows) {
+                        const size_t o = (size_t)(row0 + row) * p.ld_out + p.col_off;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                const int co = ct[c] * 32 + 8 * q + 4 * (lane >> 5) + i;
+                                float t = av[4 * q + i];
+                                t = relu && !(t > 0.f) ? 0.f : t;
+                                if (co < p.cout[l]) {
+                                    if (p.out_bf16) reinterpret_cast<__bf16 *>(p.out)[o + co] = (__bf16)t;
+                                    else reinterpret_cast<float *>(p.out)[o + co] = t;
+                                }
+                            }
+                    }
+                }
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(BF_T) void mlp_bf16_kernel(const BfParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __bf16 *const buf0 = reinterpret_cast<__bf16 *>(smem);
@@ -114,22 +298,29 @@ __global__ __launch_bounds__(BF_T) void mlp_bf16_kernel(const BfParams p) {
             } else if (ok) {
                 src = (size_t)row * p.ld_feat;
             }
-            if (!vec)
-                for (int c = 0; c < C; ++c) x[c] = ok ? load_feat(p.feat, p.feat_bf16, src + c) : (__bf16)0.f;
-            int c = C;
-            if (grouped) {
-                float d0 = 0.f, d1 = 0.f, d2 = 0.f;
-                if (ok) {
-                    const float *q = p.xyz + ((size_t)b * p.N + j) * 3;
-                    const float *cen = p.new_xyz + (size_t)g * 3;
-                    d0 = q[0] - cen[0];
-                    d1 = q[1] - cen[1];
-                    d2 = q[2] - cen[2];
-                }
-                x[c] = (__bf16)d0; x[c + 1] = (__bf16)d1; x[c + 2] = (__bf16)d2;
-                c += 3;
+            float d[3] = {0.f, 0.f, 0.f};
+            if (ok && grouped) {
+                const float *q = p.xyz + ((size_t)b * p.N + j) * 3;
+                const float *cen = p.new_xyz + (size_t)g * 3;
+                d[0] = q[0] - cen[0];
+                d[1] = q[1] - cen[1];
+                d[2] = q[2] - cen[2];
             }
-            for (; c < p.kp[0]; ++c) x[c] = (__bf16)0.f;
+            // everything the vector gather did not write: (features,) relative coordinates, zero pad —
+            // assembled in registers, one 16-byte store per 8 channels
+            const int cx = grouped ? C : p.kp[0];          // first channel of the coordinates (none in plain mode)
+            for (int c8 = vec ? C >> 3 : 0; c8 < p.kp[0] >> 3; ++c8) {
+                bf16x8 v;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int c = c8 * 8 + i;
+                    float t = 0.f;
+                    if (c < C) t = ok ? (float)load_feat(p.feat, p.feat_bf16, src + c) : 0.f;
+                    else if (c >= cx && c < cx + 3) t = d[c - cx];
+                    v[i] = (__bf16)t;
+                }
+                *reinterpret_cast<bf16x8 *>(x + c8 * 8) = v;
+            }
         }
         __syncthreads();
 
@@ -137,97 +328,21 @@ __global__ __launch_bounds__(BF_T) void mlp_bf16_kernel(const BfParams p) {
         for (int l = 0; l < p.L; ++l) {
             const __bf16 *X = (l & 1) ? buf1 : buf0;
             __bf16 *Y = (l & 1) ? buf0 : buf1;
-            const int ldx = p.kp[l] + 8, ldy = p.kp[l + 1] + 8;
-            const int KB = p.kp[l] >> 4;
             const int CT = (p.cout[l] + 31) >> 5;
-            const bool last = l == p.L - 1;
-            const bool relu = (p.relu_mask >> l) & 1;
-            const bool pool = last && grouped;
-            for (int tt = wave; tt < NRB * CT; tt += BF_T / 64) {
-                const int ct = tt / NRB, rb = tt - ct * NRB;
-                const bf16x8 *wp = p.w[l] + (size_t)ct * KB * 64 + lane;
-                const __bf16 *xp = X + (rb * 32 + (lane & 31)) * ldx + (lane >> 5) * 8;
-                const float *bias = p.bias[l] + ct * 32;
-                f32x16 acc;
-                if (pool) {
-                    const float bv = bias[lane & 31];
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) acc[i] = bv;
-#pragma unroll 4
-                    for (int kb = 0; kb < KB; ++kb)
-                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8 *>(xp + kb * 16),
-                                                                      wp[kb * 64], acc, 0, 0, 0);
-                    // acc[i] = y[row rb*32 + 8*(i/4) + 4*(lane/32) + i%4][cout ct*32 + lane%32]
-                    const long long rbase = row0 + rb * 32;
-                    const int co = ct * 32 + (lane & 31);
-                    float *orow = reinterpret_cast<float *>(p.out) + p.col_off + co;
-                    if (rbase < p.rows) {
-                        if ((p.S & 31) == 0) {
-                            float m = 0.f;
-#pragma unroll
-                            for (int i = 0; i < 16; ++i) m = acc[i] > m ? acc[i] : m;
-                            const float o = __shfl_xor(m, 32, 64);
-                            m = o > m ? o : m;
-                            if (lane < 32 && co < p.cout[l]) atomic_max_pos(orow + (size_t)(rbase / p.S) * p.ld_out, m);
-                        } else if (p.S == 16) {
-                            float m0 = 0.f, m1 = 0.f;
-#pragma unroll
-                            for (int i = 0; i < 8; ++i) { m0 = acc[i] > m0 ? acc[i] : m0; m1 = acc[8 + i] > m1 ? acc[8 + i] : m1; }
-                            const float o0 = __shfl_xor(m0, 32, 64), o1 = __shfl_xor(m1, 32, 64);
-                            m0 = o0 > m0 ? o0 : m0;
-                            m1 = o1 > m1 ? o1 : m1;
-                            if (lane < 32 && co < p.cout[l]) {
-                                const size_t g0 = (size_t)(rbase / 16);
-                                atomic_max_pos(orow + g0 * p.ld_out, m0);
-                                if (rbase + 16 < p.rows) atomic_max_pos(orow + (g0 + 1) * p.ld_out, m1);
-                            }
-                        } else if (co < p.cout[l]) {
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) {
-                                const long long r = rbase + 8 * q + 4 * (lane >> 5);
-#pragma unroll
-                                for (int i = 0; i < 4; ++i)
-                                    if (r + i < p.rows) {
-                                        const float v = acc[4 * q + i] > 0.f ? acc[4 * q + i] : 0.f;
-                                        atomic_max_pos(orow + (size_t)((r + i) / p.S) * p.ld_out, v);
-                                    }
-                            }
-                        }
-                    }
-                } else {
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) acc[i] = bias[8 * (i >> 2) + 4 * (lane >> 5) + (i & 3)];
-#pragma unroll 4
-                    for (int kb = 0; kb < KB; ++kb)
-                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wp[kb * 64],
-                                                                      *reinterpret_cast<const bf16x8 *>(xp + kb * 16), acc, 0, 0, 0);
-                    // acc[i] = y[row rb*32 + lane%32][cout ct*32 + 8*(i/4) + 4*(lane/32) + i%4]
-                    if (relu)
-#pragma unroll
-                        for (int i = 0; i < 16; ++i) acc[i] = acc[i] > 0.f ? acc[i] : 0.f;
-                    const int r = rb * 32 + (lane & 31);
-                    if (!last) {
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            bf16x4 v;
-                            v[0] = (__bf16)acc[4 * q]; v[1] = (__bf16)acc[4 * q + 1];
-                            v[2] = (__bf16)acc[4 * q + 2]; v[3] = (__bf16)acc[4 * q + 3];
-                            *reinterpret_cast<bf16x4 *>(Y + r * ldy + ct * 32 + 8 * q + 4 * (lane >> 5)) = v;
-                        }
-                    } else if (row0 + r < p.rows) {
-                        const size_t o = (size_t)(row0 + r) * p.ld_out + p.col_off;
-#pragma unroll
-                        for (int q = 0; q < 4; ++q)
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) {
-                                const int co = ct * 32 + 8 * q + 4 * (lane >> 5) + i;
-                                if (co < p.cout[l]) {
-                                    if (p.out_bf16) reinterpret_cast<__bf16 *>(p.out)[o + co] = (__bf16)acc[4 * q + i];
-                                    else reinterpret_cast<float *>(p.out)[o + co] = acc[4 * q + i];
-                                }
-                            }
-                    }
-                }
+            const bool pool = l == p.L - 1 && grouped;
+            const int T = NRB * CT;
+            const int RWs = (NRB >= 2 && T >= 8) ? 2 : 1;
+            const int CWs = (CT >= 2 && (T >= 16 || (T >= 8 && NRB < 2))) ? 2 : 1;
+            if (pool) {
+                if (RWs == 2 && CWs == 2) run_units<2, 2, true>(p, l, X, Y, row0, wave, lane, NRB);
+                else if (RWs == 2) run_units<2, 1, true>(p, l, X, Y, row0, wave, lane, NRB);
+                else if (CWs == 2) run_units<1, 2, true>(p, l, X, Y, row0, wave, lane, NRB);
+                else run_units<1, 1, true>(p, l, X, Y, row0, wave, lane, NRB);
+            } else {
+                if (RWs == 2 && CWs == 2) run_units<2, 2, false>(p, l, X, Y, row0, wave, lane, NRB);
+                else if (RWs == 2) run_units<2, 1, false>(p, l, X, Y, row0, wave, lane, NRB);
+                else if (CWs == 2) run_units<1, 2, false>(p, l, X, Y, row0, wave, lane, NRB);
+                else run_units<1, 1, false>(p, l, X, Y, row0, wave, lane, NRB);
             }
             __syncthreads();
         }

@@ -22,8 +22,15 @@ from .sa_module import SAModuleMSG
 
 class SADDetector(nn.Module):
     def __init__(self, cfg: DetectorConfig, weights: dict, device, overlap_fps: bool = True,
-                 n_fps_streams: int = 4, n_main_streams: int = 2, nested_fps_shortcut: bool = True):
+                 n_fps_streams: int = 4, n_main_streams: int = 2, nested_fps_shortcut: bool = True,
+                 dtype: str = "f32"):
+        """``dtype="bf16"``: every MLP runs on the bf16 matrix-core path (SPEC.md §14, BASELINE.json
+        configs[4]); sampling, ball query and box decode are unchanged."""
         super().__init__()
+        if dtype not in ("f32", "bf16"):
+            raise ValueError("dtype must be 'f32' or 'bf16'")
+        self.dtype = dtype
+        mlp_cls = ops.PackedMLP if dtype == "f32" else ops.PackedMLPBf16
         self.cfg = cfg
         self.device = torch.device(device)
         c = cfg.in_feat
@@ -32,18 +39,18 @@ class SADDetector(nn.Module):
             w = {f"b{i}": weights[f"sa{si + 1}.b{i}"] for i in range(len(st.mlps))}
             if st.agg:
                 w["agg"] = weights[f"sa{si + 1}.agg"]
-            m = SAModuleMSG(c, st, self.device, w, name=f"sa{si + 1}")
+            m = SAModuleMSG(c, st, self.device, w, name=f"sa{si + 1}", dtype=dtype)
             self.stages.append(m)
             c = m.out_channels
-        self.cand_mlp = ops.PackedMLP(weights["cand"], False, self.device,
+        self.cand_mlp = mlp_cls(weights["cand"], False, self.device,
                                       relu_mask=(1 << (len(weights["cand"]) - 1)) - 1, name="cand")
-        self.cluster_branches = [ops.PackedMLP(weights[f"cluster.b{i}"], True, self.device,
+        self.cluster_branches = [mlp_cls(weights[f"cluster.b{i}"], True, self.device,
                                                name=f"cluster.b{i}")
                                  for i in range(len(cfg.cluster_mlps))]
         self.cluster_cat = sum(m[-1] for m in cfg.cluster_mlps)
-        self.cluster_agg = ops.PackedMLP(weights["cluster.agg"], False, self.device,
+        self.cluster_agg = mlp_cls(weights["cluster.agg"], False, self.device,
                                          name="cluster.agg")
-        self.head = ops.PackedMLP(weights["head"], False, self.device,
+        self.head = mlp_cls(weights["head"], False, self.device,
                                   relu_mask=(1 << (len(weights["head"]) - 1)) - 1, name="head")
         self._anchor = (ctypes.c_float * 3)(*cfg.anchor_car)
         self._anchors = (ctypes.c_float * 9)(*[v for a in cfg.anchors for v in a])

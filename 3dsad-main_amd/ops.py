@@ -446,6 +446,7 @@ class PackedMLPBf16:
         dims_c = (ctypes.c_int * (self.L + 1))(*self.dims)
         n = lib().sad_mlp_packed_bytes_bf16(self.L, dims_c, int(self.first_has_xyz))
         self.packed = torch.empty((n,), dtype=torch.uint8, device=self.device)
+        self._geom = {}      # no geometry autotuning on this path (kept for SADDetector.autotune)
         w_arr = (vp * self.L)(*[w.data_ptr() for w in ws])
         b_arr = (vp * self.L)(*[b.data_ptr() for b in bs])
         with torch.cuda.device(self.device):
@@ -470,9 +471,11 @@ class PackedMLPBf16:
         return 1 if t.dtype == torch.bfloat16 else 0
 
     def grouped(self, xyz: torch.Tensor, feat_pm: Optional[torch.Tensor], new_xyz: torch.Tensor,
-                idx: torch.Tensor, out: Optional[torch.Tensor] = None, col_off: int = 0) -> torch.Tensor:
+                idx: torch.Tensor, out: Optional[torch.Tensor] = None, col_off: int = 0,
+                cnt: Optional[torch.Tensor] = None) -> torch.Tensor:
         """xyz [B,N,3] f32; feat_pm point-major [B,N,C] bf16/f32 (or None); new_xyz [B,M,3]; idx
-        [B,M,S] -> out[:, :, col_off:col_off+C_out] of a ZERO-initialised float32 [B,M,ld] buffer."""
+        [B,M,S] -> out[:, :, col_off:col_off+C_out] of a ZERO-initialised float32 [B,M,ld] buffer.
+        ``cnt`` is accepted for signature parity with PackedMLP and ignored (rows are dense)."""
         if not self.first_has_xyz:
             raise RuntimeError("this PackedMLPBf16 was packed without the xyz prefix")
         xyz = _need(xyz, "xyz", torch.float32, 3)
@@ -499,7 +502,7 @@ class PackedMLPBf16:
         a.xyz, a.new_xyz, a.idx = xyz.data_ptr(), new_xyz.data_ptr(), idx.data_ptr()
         a.B, a.N, a.M, a.S, a.C = B, N, M, S, C
         a.out, a.out_bf16, a.ld_out, a.col_off = out.data_ptr(), 0, out.stride(-2), col_off
-        with _timed("mlp_bf16", self.name):
+        with _timed("mlp", self.name):
             check(lib().sad_mlp_chain_bf16(ctypes.byref(a), _stream()), "sad_mlp_chain_bf16")
         return out
 
@@ -526,7 +529,7 @@ class PackedMLPBf16:
         a.B, a.N, a.M, a.S, a.C = 1, 0, R, 1, C
         a.out, a.out_bf16 = out.data_ptr(), int(out.dtype == torch.bfloat16)
         a.ld_out, a.col_off = out.stride(-2), col_off
-        with _timed("mlp_bf16", self.name):
+        with _timed("mlp", self.name):
             check(lib().sad_mlp_chain_bf16(ctypes.byref(a), _stream()), "sad_mlp_chain_bf16")
         return out
 

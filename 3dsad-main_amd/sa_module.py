@@ -27,8 +27,14 @@ class SAModuleMSG(nn.Module):
     as numpy arrays (BatchNorm folded); seeded Kaiming-uniform weights are drawn when omitted."""
 
     def __init__(self, in_channels: int, stage: SAStage, device, weights: Optional[dict] = None,
-                 seed: int = 0, name: str = "sa"):
+                 seed: int = 0, name: str = "sa", dtype: str = "f32"):
+        """``dtype``: "f32" (SPEC.md §6, bit-exact fmaf chains) or "bf16" (SPEC.md §14: bf16 MFMA
+        MLPs, float32 accumulation, bf16 stage outputs; index operators unchanged)."""
         super().__init__()
+        if dtype not in ("f32", "bf16"):
+            raise ValueError("dtype must be 'f32' or 'bf16'")
+        self.dtype = dtype
+        mlp_cls = ops.PackedMLP if dtype == "f32" else ops.PackedMLPBf16
         self.stage = stage
         self.in_channels = in_channels
         self.device = torch.device(device)
@@ -38,10 +44,10 @@ class SAModuleMSG(nn.Module):
                        for i, m in enumerate(stage.mlps)}
             if stage.agg:
                 weights["agg"] = make_mlp_weights([sum(m[-1] for m in stage.mlps), stage.agg], rng)
-        self.branches = [ops.PackedMLP(weights[f"b{i}"], True, self.device, name=f"{name}.b{i}")
+        self.branches = [mlp_cls(weights[f"b{i}"], True, self.device, name=f"{name}.b{i}")
                          for i in range(len(stage.mlps))]
         self.cat_channels = sum(m[-1] for m in stage.mlps)
-        self.agg = (ops.PackedMLP(weights["agg"], False, self.device, name=f"{name}.agg")
+        self.agg = (mlp_cls(weights["agg"], False, self.device, name=f"{name}.agg")
                     if stage.agg else None)
         self.out_channels = stage.agg if stage.agg else self.cat_channels
 
@@ -68,7 +74,11 @@ class SAModuleMSG(nn.Module):
                         mlp.grouped(xyz, feat_pm, new_xyz, idx, out=cat, col_off=off, cnt=cnt))
             off += mlp.out_channels
         ops.run_branches(jobs)       # independent branches share the chip
-        return self.agg.rows(cat) if self.agg is not None else cat
+        if self.agg is None:
+            return cat
+        if self.dtype == "bf16":     # a stage output that feeds another stage is stored as bf16 (SPEC §14)
+            return self.agg.rows(cat, out_dtype=torch.bfloat16)
+        return self.agg.rows(cat)
 
     def forward_pm(self, xyz: torch.Tensor, feat_pm: Optional[torch.Tensor]
                    ) -> Tuple[torch.Tensor, torch.Tensor]:

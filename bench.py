@@ -32,6 +32,7 @@ sys.path.insert(0, ROOT)
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 PEAK_MFMA_F32_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: dense f32 MFMA
+PEAK_MFMA_BF16_TFLOPS = 2500.0 # same guide: dense bf16 MFMA (not the 2:1-sparsity headline)
 PEAK_HBM_GBPS = 8000.0         # HBM3E spec
 
 
@@ -65,7 +66,7 @@ def cpu_baseline(cfg, weights, scenes: int, repeats: int = 2):
                       f"(C + OpenMP, {cores} threads), best of {repeats}; the upstream reference has no CPU path"}
 
 
-def executed_flops(det, points, cfg):
+def executed_flops(det, points, cfg, dense=False):
     """Flops the MLP kernels execute on this batch: per grouped launch only the leading rows of each
     group up to the last sample that differs from the first (the kernel's own rule); plain launches
     (aggregation, candidate MLP, head) execute every row."""
@@ -85,6 +86,8 @@ def executed_flops(det, points, cfg):
         return 2 * sum(a * b for a, b in zip(d[:-1], d[1:]))
 
     def rows_of(idx):
+        if dense:                 # the bf16 path computes every row of every group
+            return idx.numel()
         diff = idx != idx[..., :1]
         pos = torch.arange(1, idx.shape[-1] + 1, device=idx.device)
         return int(torch.clamp((diff * pos).amax(-1), min=1).sum().item())
@@ -126,6 +129,9 @@ def main():
     ap.add_argument("--no-launch-timing", action="store_true")
     ap.add_argument("--no-autotune", action="store_true", help="use the built-in geometry heuristic")
     ap.add_argument("--branch-overlap", action="store_true", help="run MSG branches on helper streams")
+    ap.add_argument("--dtype", choices=("f32", "bf16"), default="f32",
+                    help="bf16 = SPEC.md 14 mode (configs[4]): MLPs on the bf16 matrix cores, dense rows; "
+                         "the headline metric is the f32 default")
     ap.add_argument("--opt", action="append", default=[], help="tuning knob key=value (sad_set_option)")
     args = ap.parse_args()
 
@@ -164,7 +170,8 @@ def main():
     cfg = config.KITTI
     weights = synth.make_weights(cfg, 0)
     det = SADDetector(cfg, weights, dev, overlap_fps=not args.no_overlap, n_fps_streams=args.fps_streams,
-                      n_main_streams=args.main_streams)
+                      n_main_streams=args.main_streams, dtype=args.dtype)
+    PEAK = PEAK_MFMA_F32_TFLOPS if args.dtype == "f32" else PEAK_MFMA_BF16_TFLOPS
     B = args.batch
     points = torch.from_numpy(synth.make_batch(rank * B, B, cfg.n_points)).to(dev)
     torch.cuda.synchronize()
@@ -220,9 +227,9 @@ def main():
             "n_gpus": world, "steps": steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"configs[1-2]: batch {B} x 16384-pt KITTI-shaped scenes per GPU, "
-                                   "3-stage multi-radius SA backbone fp32 + size-adaptive cluster layer + box head",
+                                   f"3-stage multi-radius SA backbone {'fp32' if args.dtype == 'f32' else 'bf16 (SPEC 14)'} + size-adaptive cluster layer + box head",
                        "scenes_per_gpu": B, "global_batch": world * B, "n_points": cfg.n_points,
                        "parallelism": f"batch-sharded x{world}, one all_gather of boxes",
                        "fps_overlap": not args.no_overlap, "fps_streams": args.fps_streams, "main_streams": args.main_streams, "opts": args.opt,
@@ -232,7 +239,7 @@ def main():
             tsteps = max(1, timed_steps)
             mlp_ms = per_kind.get("mlp", 0.0) / tsteps
             flops = work["mlp_flops"] * B                      # dense definition (SPEC.md §6)
-            exec_flops, row_frac, per_flops = executed_flops(det, points, cfg)
+            exec_flops, row_frac, per_flops = executed_flops(det, points, cfg, dense=args.dtype != "f32")
             ach = exec_flops / (mlp_ms * 1e-3) / 1e12 if mlp_ms > 0 else 0.0
             n_mlp = sum(1 for k, _, _, _ in log if k == "mlp") // tsteps
             # the same launches without a sibling main stream (kernel durations are then not stretched
@@ -249,9 +256,9 @@ def main():
                 if k == "mlp":
                     iso_name[n] = iso_name.get(n, 0.0) + e0.elapsed_time(e1) / 5
             res["roofline"] = {
-                "kernel": f"mlp_chain_kernel ({n_mlp} launches per step, summed)",
-                "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_MFMA_F32_TFLOPS,
-                "unit": "TFLOP/s", "frac": round(ach / PEAK_MFMA_F32_TFLOPS, 4), "traffic": None,
+                "kernel": f"{'mlp_chain_kernel' if args.dtype == 'f32' else 'mlp_bf16_kernel'} ({n_mlp} launches per step, summed)",
+                "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK,
+                "unit": "TFLOP/s", "frac": round(ach / PEAK, 4), "traffic": None,
                 "flop_per_step": exec_flops, "ms_per_step": round(mlp_ms, 3), "sampled_steps": tsteps,
                 "note": "durations are HIP-event intervals on the launching stream inside the timed region, where "
                         "two main streams run consecutive batches side by side (kernels share the chip, so "
@@ -259,7 +266,7 @@ def main():
                         "group's first neighbour (ball-query padding) are skipped exactly (a duplicate "
                         "row cannot change the max-pool), so executed < dense",
                 "single_main_stream": {"ms_per_step": round(iso_ms, 3), "achieved": round(iso, 2),
-                                       "frac": round(iso / PEAK_MFMA_F32_TFLOPS, 4),
+                                       "frac": round(iso / PEAK, 4),
                                        "note": "same launches, consecutive batches NOT overlapped on a second main stream"},
                 "dense_flop_per_step": flops, "executed_row_fraction": round(row_frac, 4),
                 "dense_equivalent_tflops": round(flops / (mlp_ms * 1e-3) / 1e12, 2) if mlp_ms > 0 else 0.0}

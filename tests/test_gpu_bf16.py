@@ -108,3 +108,69 @@ def test_nuscenes_stage_bf16(orc, sad, dev):
     got = ops.PackedMLPBf16(layers, True, dev).grouped(xt, _t(feat, dev).bfloat16(), new_xyz, idx).cpu().numpy()
     want = orc.sa_group_mlp_max_bf16(xyz, feat, new_xyz.cpu().numpy(), idx.cpu().numpy(), layers)
     _close(got, want, "nuScenes-shaped SA1 branch")
+
+
+def _stage_oracle(orc, xyz, feat, new_xyz, idxs, weights, name, agg):
+    """One SA / cluster stage of SPEC §14 from given inputs: branches -> concat -> aggregation."""
+    cat = np.concatenate([orc.sa_group_mlp_max_bf16(xyz, feat, new_xyz, idx, weights[f"{name}.b{i}"])
+                          for i, idx in enumerate(idxs)], axis=2)
+    B, M, C = cat.shape
+    out = orc.mlp_rows_bf16(cat.reshape(B * M, C), weights[f"{name}.agg"]).reshape(B, M, -1)
+    return cat, out
+
+
+@pytest.mark.parametrize("cfg_name,batch", [("TINY", 2), ("KITTI", 1)])
+def test_detector_bf16_stagewise(orc, sad, dev, cfg_name, batch):
+    """The whole path with dtype="bf16", each stage checked against the §14 oracle fed with the
+    GPU's own upstream tensors (teacher forcing: a bf16 rounding flip must not be allowed to move
+    a later index decision and then be counted as an error).  Index operators are checked
+    bit-exactly on those same inputs."""
+    import torch
+    from sad_amd import config, synth
+    from sad_amd.detector import SADDetector
+    cfg = getattr(config, cfg_name)
+    w = synth.make_weights(cfg, 0)
+    pts = synth.make_tiny_batch(0, batch, cfg.n_points) if cfg_name == "TINY" else synth.make_batch(0, batch)
+    det = SADDetector(cfg, w, dev, dtype="bf16")
+    tr = {}
+    boxes = det(_t(pts, dev), tr)
+    torch.cuda.synchronize()
+    xyz = np.ascontiguousarray(pts[:, :, :3])
+    feat = np.ascontiguousarray(pts[:, :, 3:])
+    for si, st in enumerate(cfg.stages):
+        name = f"sa{si + 1}"
+        t = tr[name]
+        new_xyz = t["new_xyz"].cpu().numpy()
+        np.testing.assert_array_equal(new_xyz, orc.gather_xyz(xyz, orc.fps(xyz, st.npoint)))
+        idxs = [i.cpu().numpy() for i in t["ball_idx"]]
+        for r, s, got in zip(st.radii, st.nsamples, idxs):
+            np.testing.assert_array_equal(got, orc.ball_query(r, s, xyz, new_xyz))
+        _, want = _stage_oracle(orc, xyz, orc.bf16_round(feat), new_xyz, idxs, w, name, st.agg)
+        assert t["out"].dtype == torch.bfloat16
+        got = t["out"].float().cpu().numpy()
+        _close(got, orc.bf16_round(want), f"{cfg_name} {name} bf16 features")
+        xyz, feat = new_xyz, got
+    c = tr["cluster"]
+    K = cfg.n_cand
+    want_c = orc.mlp_rows_bf16(feat[:, :K].reshape(-1, feat.shape[2]), w["cand"],
+                               relu_mask=(1 << (len(w["cand"]) - 1)) - 1).reshape(batch, K, -1)
+    gc = c["c"].cpu().numpy()
+    _close(gc, want_c, "candidate MLP")
+    cand, rad = orc.candidates(xyz, gc, cfg.shift_max, cfg.r_min, cfg.r_max, cfg.anchor_car)
+    np.testing.assert_array_equal(c["cand"].cpu().numpy(), cand)
+    np.testing.assert_array_equal(c["radius"].cpu().numpy(), rad)
+    idxs = [i.cpu().numpy() for i in c["ball_idx"]]
+    for sc, s, got in zip(cfg.cluster_scales, cfg.cluster_nsamples, idxs):
+        np.testing.assert_array_equal(got, orc.ball_query((np.float32(sc) * rad).astype(np.float32), s, xyz, cand))
+    want_cat, want_cf = _stage_oracle(orc, xyz, feat, cand, idxs, w, "cluster", True)
+    _close(c["cat"].cpu().numpy(), want_cat, "cluster pooled")
+    gcf = c["cfeat"].float().cpu().numpy()
+    _close(gcf, want_cf, "cluster features")
+    want_h = orc.mlp_rows_bf16(gcf.reshape(batch * K, -1), w["head"],
+                               relu_mask=(1 << (len(w["head"]) - 1)) - 1).reshape(batch, K, -1)
+    gh = c["head"].cpu().numpy()
+    _close(gh, want_h, "head")
+    want_b = orc.decode_boxes(cand, gh, [v for a in cfg.anchors for v in a])
+    b = boxes.cpu().numpy()
+    np.testing.assert_array_equal(b[..., 8], want_b[..., 8])
+    assert np.abs(b - want_b).max() <= 1e-4 * (1 + np.abs(want_b).max())
