@@ -293,7 +293,9 @@ void launch_reg(const float *xyz, int B, int N, int M, int *idx, hipStream_t st,
 // permutation of the bucketed kernel (optional: without it the plain register kernel runs).
 SAD_API size_t sad_fps_workspace_bytes(int B, int N) {
     if (B <= 0 || N < 2048) return 0;
-    return (size_t)B * (size_t)N * sizeof(float);
+    size_t n = (size_t)B * (size_t)N * sizeof(float);
+    if (N > 16384 && N <= 65536) n = ((n + 15) & ~(size_t)15) + (size_t)B * 65536 * 16;   // + sorted float4 records
+    return n;
 }
 
 SAD_API int sad_fps_f32(const float *xyz, int B, int N, int M, int32_t *idx, void *workspace,
@@ -303,6 +305,11 @@ SAD_API int sad_fps_f32(const float *xyz, int B, int N, int M, int32_t *idx, voi
     SAD_REQUIRE((size_t)N * 3 < (1u << 31), "sad_fps_f32: N too large");
     hipStream_t st = (hipStream_t)stream;
     const bool dpp = sad::get_option(sad::OPT_FPS_DPP) != 0;
+    const int variant0 = sad::get_option(sad::OPT_FPS_VARIANT);
+    if (N > 16384 && N <= 65536 && workspace && (variant0 == 0 || variant0 >= 3)) {
+        SAD_REQUIRE((uintptr_t)workspace % 16 == 0, "sad_fps_f32: workspace must be 16-byte aligned");
+        return sad::launch_fps_cellg(xyz, B, N, M, idx, workspace, st);
+    }
     if (N > 16384) {
         SAD_REQUIRE(workspace, "sad_fps_f32: N=%d > 16384 needs sad_fps_workspace_bytes() of workspace", N);
         hipLaunchKernelGGL(fps_big_kernel, dim3(B), dim3(1024), 0, st, xyz, N, M, (float *)workspace, idx);

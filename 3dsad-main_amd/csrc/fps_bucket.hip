@@ -462,6 +462,149 @@ void launch_cell(const float *xyz, const int *perm, int B, int N, int M, int *id
     hipLaunchKernelGGL((fps_cell_kernel<NW, PPT>), dim3(B), dim3(NW * 64), 0, st, xyz, perm, N, M, idx);
 }
 
+// ---- cell-bucket kernel for 16 384 < N <= 65 536 -------------------------------------------------
+// Same algorithm, but a scene no longer fits the register file of one CU: only the running
+// min-distances (64 per lane, two 32-wide register-indexed vectors) and the 64 bucket states per wave
+// stay in registers; a bucket's coordinates and (~index) come from a Z-order-sorted float4 record
+// array in the workspace (1 MB per scene, L2 / Infinity-Cache resident) — ONE coalesced 16-byte load
+// per lane, issued only for the handful of buckets a step disturbs.
+__global__ __launch_bounds__(256) void fps_records_kernel(const float *__restrict__ xyz, const int *__restrict__ perm_in,
+                                                          int N, int NP, float4 *__restrict__ rec_out) {
+    const float *p = xyz + (size_t)blockIdx.y * N * 3;
+    const int *perm = perm_in + (size_t)blockIdx.y * N;
+    float4 *rec = rec_out + (size_t)blockIdx.y * NP;
+    for (int pos = blockIdx.x * blockDim.x + threadIdx.x; pos < NP; pos += gridDim.x * blockDim.x) {
+        float4 r = {0.f, 0.f, 0.f, __builtin_bit_cast(float, 0x80000000u)};   // padding record
+        if (pos < N) {
+            const int j = perm[pos];
+            r.x = p[j * 3 + 0];
+            r.y = p[j * 3 + 1];
+            r.z = p[j * 3 + 2];
+            r.w = __builtin_bit_cast(float, ~(unsigned)j);
+        }
+        rec[pos] = r;
+    }
+}
+
+__global__ __launch_bounds__(1024) void fps_cellg_kernel(const float4 *__restrict__ rec_in, int N, int NP, int M,
+                                                         int *__restrict__ idx_out) {
+    constexpr int NW = 16, PPT = 64;
+    typedef float fvec32 __attribute__((ext_vector_type(32)));
+    __shared__ u64 s_gkey[3];
+    __shared__ __attribute__((aligned(16))) float s_wxyz[2][16][4];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const float4 *rec = rec_in + (size_t)blockIdx.x * NP;
+    int *out = idx_out + (size_t)blockIdx.x * M;
+
+    fvec32 md0, md1;       // min-distance of point `lane` of slot k: md0[k] (k < 32) / md1[k - 32]
+    float blo0 = 0.f, blo1 = 0.f, blo2 = 0.f, bhi0 = 0.f, bhi1 = 0.f, bhi2 = 0.f;
+    float bx = 0.f, by = 0.f, bz = 0.f;
+    unsigned bmax = 0u, bidx = 0x80000000u;
+#pragma unroll 1
+    for (int k = 0; k < PPT; ++k) {
+        const int pos = (k * NW + wave) * 64 + lane;       // < NP by construction
+        const bool real = pos < N;
+        const float4 r = rec[pos];
+        if (k < 32) md0[k] = real ? __builtin_inff() : 0.f; else md1[k - 32] = real ? __builtin_inff() : 0.f;
+        float lo[3] = {real ? r.x : 3.0e38f, real ? r.y : 3.0e38f, real ? r.z : 3.0e38f};
+        float hi[3] = {real ? r.x : -3.0e38f, real ? r.y : -3.0e38f, real ? r.z : -3.0e38f};
+#pragma unroll
+        for (int d = 0; d < 3; ++d)
+            for (int off = 32; off >= 1; off >>= 1) {
+                const float a = __shfl_xor(lo[d], off, 64), b = __shfl_xor(hi[d], off, 64);
+                lo[d] = a < lo[d] ? a : lo[d];
+                hi[d] = b > hi[d] ? b : hi[d];
+            }
+        const bool any_real = __ballot(real) != 0ull;
+        if (lane == k) {
+            blo0 = lo[0]; blo1 = lo[1]; blo2 = lo[2];
+            bhi0 = hi[0]; bhi1 = hi[1]; bhi2 = hi[2];
+            bmax = any_real ? 0x7f800000u : 0u;
+        }
+    }
+    float cx, cy, cz;
+    {   // the first sample is original index 0: find its record (one lane of one wave owns it)
+        if (tid < 3) s_gkey[tid] = 0ull;
+        __syncthreads();
+        for (int k = 0; k < PPT; ++k) {
+            const float4 r = rec[(k * NW + wave) * 64 + lane];
+            if (__builtin_bit_cast(unsigned, r.w) == 0xffffffffu) {
+                s_wxyz[0][0][0] = r.x; s_wxyz[0][0][1] = r.y; s_wxyz[0][0][2] = r.z;
+            }
+        }
+        __syncthreads();
+        cx = s_wxyz[0][0][0]; cy = s_wxyz[0][0][1]; cz = s_wxyz[0][0][2];
+        __syncthreads();
+    }
+    unsigned wk_hi = 0u, wk_lo = 0u;
+    float wx = 0.f, wy = 0.f, wz = 0.f;
+    if (tid == 0) out[0] = 0;
+    int b3 = 1;
+    for (int i = 1; i < M; ++i) {
+        const float dq = sad::d2f(__builtin_amdgcn_fmed3f(cx, blo0, bhi0), __builtin_amdgcn_fmed3f(cy, blo1, bhi1),
+                                  __builtin_amdgcn_fmed3f(cz, blo2, bhi2), cx, cy, cz);
+        unsigned long long act = __ballot(dq < __builtin_bit_cast(float, bmax));
+        if (act) {
+            do {
+                const int k = __builtin_amdgcn_readfirstlane(__builtin_ctzll(act));
+                act &= act - 1;
+                const float4 r = rec[(k * NW + wave) * 64 + lane];
+                const unsigned n = __builtin_bit_cast(unsigned, r.w);
+                const float d = sad::d2f(r.x, r.y, r.z, cx, cy, cz);
+                float m;
+                if (k < 32) { m = __builtin_fminf(md0[k], d); md0[k] = m; }
+                else { m = __builtin_fminf(md1[k - 32], d); md1[k - 32] = m; }
+                const unsigned mb = __builtin_bit_cast(unsigned, m);
+                const unsigned hi = wave_max_u32_bcast(mb);
+                const unsigned long long tie = __ballot(mb == hi);
+                int l = __builtin_ctzll(tie);
+                if (tie & (tie - 1)) {
+                    const unsigned lo = wave_max_u32_bcast(mb == hi ? n : 0u);
+                    l = __builtin_ctzll(__ballot(mb == hi && n == lo));
+                }
+                bmax = wrl_dyn(bmax, hi, k);
+                bidx = wrl_dyn(bidx, __builtin_amdgcn_readlane(n, l), k);
+                bx = wrl_dyn_f(bx, rdl_f(r.x, l), k);
+                by = wrl_dyn_f(by, rdl_f(r.y, l), k);
+                bz = wrl_dyn_f(bz, rdl_f(r.z, l), k);
+            } while (act);
+            wk_hi = wave_max_u32_bcast(bmax);
+            const unsigned long long wt = __ballot(bmax == wk_hi);
+            int kb = __builtin_ctzll(wt);
+            if (wt & (wt - 1)) {
+                wk_lo = wave_max_u32_bcast(bmax == wk_hi ? bidx : 0u);
+                kb = __builtin_ctzll(__ballot(bmax == wk_hi && bidx == wk_lo));
+            } else {
+                wk_lo = __builtin_amdgcn_readlane(bidx, kb);
+            }
+            wx = rdl_f(bx, kb);
+            wy = rdl_f(by, kb);
+            wz = rdl_f(bz, kb);
+        }
+        const int buf = i & 1;
+        const int b3n = b3 == 2 ? 0 : b3 + 1;
+        if (lane == 0) {
+            const unsigned lo = ((wk_lo & 0x0fffffffu) << 4) | (unsigned)wave;
+            atomicMax(&s_gkey[b3], ((u64)wk_hi << 32) | lo);
+            float4 r;
+            r.x = wx; r.y = wy; r.z = wz; r.w = 0.f;
+            *reinterpret_cast<float4 *>(&s_wxyz[buf][wave][0]) = r;
+            if (wave == 0) s_gkey[b3n] = 0ull;
+        }
+        __syncthreads();
+        const u64 gk = s_gkey[b3];
+        const float4 wr = *reinterpret_cast<const float4 *>(&s_wxyz[buf][lane & (NW - 1)][0]);
+        const unsigned g = __builtin_amdgcn_readfirstlane((unsigned)gk);
+        const int slot = g & 15;
+        cx = rdl_f(wr.x, slot);
+        cy = rdl_f(wr.y, slot);
+        cz = rdl_f(wr.z, slot);
+        b3 = b3n;
+        if (tid == 0) out[i] = (int)(0x0fffffffu - (g >> 4));
+    }
+}
+
 template <int THREADS, int PPT>
 void launch_bucket(const float *xyz, const int *perm, int B, int N, int M, int *idx, hipStream_t st) {
     hipLaunchKernelGGL((fps_bucket_kernel<THREADS, PPT>), dim3(B), dim3(THREADS), 0, st, xyz, perm, N, M, idx);
@@ -470,6 +613,24 @@ void launch_bucket(const float *xyz, const int *perm, int B, int N, int M, int *
 }  // namespace
 
 namespace sad {
+
+// 16 384 < N <= 65 536: workspace = perm[B*N] ints, then B * 65 536 float4 records (16-byte aligned).
+int launch_fps_cellg(const float *xyz, int B, int N, int M, int32_t *idx, void *workspace, hipStream_t st) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&fps_sort_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        attr_set = true;
+    }
+    constexpr int NP = 65536;
+    int *perm = (int *)workspace;
+    const size_t off = (((size_t)B * N * sizeof(int)) + 15) & ~(size_t)15;
+    float4 *rec = (float4 *)((unsigned char *)workspace + off);
+    hipLaunchKernelGGL(fps_sort_kernel, dim3(B), dim3(SORT_T), sizeof(int) * SORT_CELLS, st, xyz, N, perm);
+    hipLaunchKernelGGL(fps_records_kernel, dim3(64, B), dim3(256), 0, st, xyz, perm, N, NP, rec);
+    hipLaunchKernelGGL(fps_cellg_kernel, dim3(B), dim3(1024), 0, st, rec, N, NP, M, idx);
+    return check_launch("sad_fps_f32 (cell, global records)");
+}
 
 // Called by sad_fps_f32 when a workspace (B*N ints) is available and N <= 16384.
 int launch_fps_bucket(const float *xyz, int B, int N, int M, int32_t *idx, void *workspace, hipStream_t st) {

@@ -44,8 +44,10 @@ const char *sad_last_error(void);
 /* Tuning knobs for A/B measurements ("fps_dpp" 0/1, "mlp_rw" 0/1/2/4 (0 = auto)); returns SAD_EINVAL for an unknown key. */
 int sad_set_option(const char *key, int value);
 
-/* SPEC.md §2.  xyz[B,N,3] -> idx[B,M].  N <= 16384 runs register-resident and needs no workspace;
- * larger N needs sad_fps_workspace_bytes(B,N) bytes of device workspace. */
+/* SPEC.md §2.  xyz[B,N,3] -> idx[B,M].  N < 2048 needs no workspace; otherwise pass
+ * sad_fps_workspace_bytes(B,N) bytes of 16-byte aligned device workspace (Z-order permutation for
+ * the bucketed kernels; + sorted point records for 16384 < N <= 65536).  Without a workspace,
+ * N <= 16384 falls back to the plain register-resident scan. */
 size_t sad_fps_workspace_bytes(int B, int N);
 int sad_fps_f32(const float *xyz, int B, int N, int M, int32_t *idx, void *workspace,
                 sad_stream_t stream);

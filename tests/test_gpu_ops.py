@@ -31,12 +31,12 @@ def _rand_xyz(seed, B, N, scale=1.0):
 @pytest.mark.parametrize("B,N,M", [(2, 64, 16), (3, 257, 100), (2, 1024, 256), (2, 2048, 512),
                                    (2, 3000, 700), (2, 4096, 1024), (1, 8192, 512), (2, 16384, 1024),
                                    (1, 5, 5), (1, 1, 1)])
-@pytest.mark.parametrize("variant", ["shfl", "dpp", "key", "bucket"])
+@pytest.mark.parametrize("variant", ["shfl", "dpp", "key", "bucket", "cell"])
 def test_fps_parity(orc, sad, dev, B, N, M, variant):
     """Every FPS kernel variant (selected with sad_set_option) gives the oracle's indices."""
     from sad_amd import _lib, ops
     _lib.set_option("fps_dpp", 1 if variant == "dpp" else 0)
-    _lib.set_option("fps_variant", {"shfl": 1, "dpp": 1, "key": 2, "bucket": 3}[variant])
+    _lib.set_option("fps_variant", {"shfl": 1, "dpp": 1, "key": 2, "bucket": 3, "cell": 4}[variant])
     try:
         xyz = _rand_xyz(100 + N, B, N)
         got = ops.fps(_t(xyz, dev), M).cpu().numpy()
@@ -46,13 +46,29 @@ def test_fps_parity(orc, sad, dev, B, N, M, variant):
     np.testing.assert_array_equal(got, orc.fps(xyz, M))
 
 
-def test_fps_big_n_workspace_path(orc, sad, dev):
+@pytest.mark.parametrize("N,M", [(20000, 300), (40000, 1500), (65536, 2048), (70000, 200)])
+def test_fps_big_n_workspace_path(orc, sad, dev, N, M):
+    """16384 < N <= 65536: cell buckets over sorted global records (BASELINE configs[4] size);
+    above that the plain global-workspace kernel."""
     from sad_amd import ops
-    xyz = _rand_xyz(7, 1, 20000)
-    np.testing.assert_array_equal(ops.fps(_t(xyz, dev), 300).cpu().numpy(), orc.fps(xyz, 300))
+    xyz = _rand_xyz(7 + N, 2, N, scale=50.0)
+    np.testing.assert_array_equal(ops.fps(_t(xyz, dev), M).cpu().numpy(), orc.fps(xyz, M))
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3])
+def test_fps_big_n_ties_and_duplicates(orc, sad, dev):
+    """32^3 lattice (exact distance ties everywhere) + a block of duplicated points at N = 32768 and
+    a degenerate z extent: the record kernel must break every tie towards the lowest index."""
+    from sad_amd import ops
+    ax = np.arange(32, dtype=np.float32)
+    grid = np.stack(np.meshgrid(ax, ax, ax, indexing="ij"), -1).reshape(1, 32768, 3).copy()
+    grid[0, 5000:5300] = grid[0, 11]
+    np.testing.assert_array_equal(ops.fps(_t(grid, dev), 1200).cpu().numpy(), orc.fps(grid, 1200))
+    flat = grid.copy()
+    flat[:, :, 2] = -1.5
+    np.testing.assert_array_equal(ops.fps(_t(flat, dev), 700).cpu().numpy(), orc.fps(flat, 700))
+
+
+@pytest.mark.parametrize("variant", [1, 2, 3, 4])
 def test_fps_edge_cases(orc, sad, dev, variant):
     from sad_amd import _lib, ops
     _lib.set_option("fps_variant", variant)
