@@ -55,6 +55,10 @@ SIGNATURES = {
     "sad_set_option": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_int]),
     "sad_fps_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int]),
     "sad_fps_f32": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp, vp]),
+    "sad_ffps_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int]),
+    "sad_pairdist_f32": (ctypes.c_int, [vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                       ctypes.c_float, vp, vp]),
+    "sad_ffps_f32": (ctypes.c_int, [vp, vp] + [ctypes.c_int] * 5 + [ctypes.c_float, vp, vp, vp]),
     "sad_gather_xyz_f32": (ctypes.c_int, [vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp]),
     "sad_gather_points": (ctypes.c_int, [vp, vp] + [ctypes.c_int] * 5 + [vp, vp]),
     "sad_group_points": (ctypes.c_int, [vp, vp] + [ctypes.c_int] * 6 + [vp, vp]),

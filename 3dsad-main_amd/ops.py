@@ -86,6 +86,34 @@ def fps(xyz: torch.Tensor, npoint: int) -> torch.Tensor:
     return idx
 
 
+def ffps(xyz: torch.Tensor, feat_pm: torch.Tensor, npoint: int, w_xyz: float = 1.0) -> torch.Tensor:
+    """Feature-distance FPS (SPEC.md §15).  xyz [B,N,3] f32, feat_pm [B,N,C] f32 point-major ->
+    idx [B,npoint] int32.  Allocates the B*N*N distance matrix the two-phase kernel needs."""
+    xyz = _need(xyz, "xyz", torch.float32, 3)
+    feat_pm = _need(feat_pm, "feat_pm", torch.float32, 3)
+    B, N, _ = xyz.shape
+    if feat_pm.shape[0] != B or feat_pm.shape[1] != N:
+        raise ValueError("feat_pm must be [B,N,C]")
+    if feat_pm.stride(2) != 1 or feat_pm.stride(0) != N * feat_pm.stride(1):
+        feat_pm = feat_pm.contiguous()
+    if not 1 <= npoint <= N:
+        raise ValueError(f"npoint={npoint} must be in 1..N={N}")
+    idx = torch.empty((B, npoint), dtype=torch.int32, device=xyz.device)
+    ws = torch.empty((lib().sad_ffps_workspace_bytes(B, N),), dtype=torch.uint8, device=xyz.device)
+    with _timed("fps", f"F{N}"):
+        check(lib().sad_ffps_f32(xyz.data_ptr(), feat_pm.data_ptr(), feat_pm.stride(1), B, N,
+                                 feat_pm.shape[2], npoint, float(w_xyz), idx.data_ptr(), ws.data_ptr(),
+                                 _stream()), "sad_ffps_f32")
+    return idx
+
+
+def dfps_ffps(xyz: torch.Tensor, feat_pm: torch.Tensor, npoint: int, w_xyz: float = 1.0) -> torch.Tensor:
+    """Fused D+F sampling (SPEC.md §15): npoint//2 picks by distance FPS, the rest by F-FPS."""
+    half = npoint // 2
+    parts = ([fps(xyz, half)] if half else []) + [ffps(xyz, feat_pm, npoint - half, w_xyz)]
+    return torch.cat(parts, dim=1)
+
+
 def gather_xyz(xyz: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
     """xyz [B,N,3], idx [B,M] -> [B,M,3] (SPEC.md §5)."""
     xyz = _need(xyz, "xyz", torch.float32, 3)

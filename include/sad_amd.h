@@ -52,6 +52,17 @@ size_t sad_fps_workspace_bytes(int B, int N);
 int sad_fps_f32(const float *xyz, int B, int N, int M, int32_t *idx, void *workspace,
                 sad_stream_t stream);
 
+/* SPEC.md §15.  Feature-distance FPS: xyz[B,N,3], feat point-major [B,N,C]
+ * with row stride ld_feat (floats) -> idx[B,M]; N <= 16384.  Two phases on the given stream: all
+ * N x N distances in the exact §15 order (sad_pairdist_f32, parallel over the chip) into
+ * `workspace` (sad_ffps_workspace_bytes(B,N) = B*N*N*4 bytes), then the serial sampling chain
+ * reading one matrix row per step. */
+size_t sad_ffps_workspace_bytes(int B, int N);
+int sad_pairdist_f32(const float *xyz, const float *feat, int ld_feat, int B, int N, int C,
+                     float w_xyz, float *dmat, sad_stream_t stream);
+int sad_ffps_f32(const float *xyz, const float *feat, int ld_feat, int B, int N, int C, int M,
+                 float w_xyz, int32_t *idx, void *workspace, sad_stream_t stream);
+
 /* SPEC.md §5.  gather_xyz: xyz[B,N,3], idx[B,M] -> out[B,M,3].
  * gather_points: src[B,C,N], idx[B,M] -> out[B,C,M]; elem_size 2 or 4 bytes.
  * group_points:  feat[B,C,N], idx[B,M,S] -> out[B,C,M,S]; elem_size 2 or 4 bytes. */

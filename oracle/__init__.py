@@ -59,6 +59,17 @@ def fps(xyz, npoint):
     return idx
 
 
+def ffps(xyz, feat_pm, npoint, w_xyz=1.0):
+    """SPEC.md §15.  xyz [B,N,3], feat_pm [B,N,C] -> idx [B,npoint] (feature-distance FPS)."""
+    xyz, px = _f(xyz)
+    feat_pm, pf = _f(feat_pm)
+    B, N, _ = xyz.shape
+    C = feat_pm.shape[2]
+    idx = np.empty((B, npoint), np.int32)
+    lib().orc_ffps(px, pf, B, N, C, npoint, ctypes.c_float(w_xyz), idx.ctypes.data_as(_i32p))
+    return idx
+
+
 def ball_query(radius, nsample, xyz, new_xyz):
     """SPEC.md §3.  radius: python float or [B,M] array (adaptive).  -> idx [B,M,nsample]."""
     xyz, px = _f(xyz)

@@ -58,6 +58,42 @@ ORC_API void orc_fps(const float *xyz, int B, int N, int M, int32_t *idx) {
     }
 }
 
+/* SPEC.md §15 — feature-distance FPS; feat point-major [B,N,C] */
+static inline float dff(const float *p, const float *q, const float *fp, const float *fq, int C, float w) {
+    float d = d2f(p, q) * w;
+    for (int c = 0; c < C; ++c) {
+        float t = fp[c] - fq[c];
+        float tt = t * t;
+        d = d + tt;
+    }
+    return d;
+}
+ORC_API void orc_ffps(const float *xyz, const float *feat, int B, int N, int C, int M, float w_xyz, int32_t *idx) {
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int b = 0; b < B; ++b) {
+        const float *p = xyz + (size_t)b * N * 3;
+        const float *f = feat + (size_t)b * N * C;
+        int32_t *o = idx + (size_t)b * M;
+        float *mind = (float *)malloc(sizeof(float) * (size_t)N);
+        for (int j = 0; j < N; ++j) mind[j] = INFINITY;
+        int last = 0;
+        o[0] = 0;
+        for (int i = 1; i < M; ++i) {
+            float best = -1.0f;
+            int besti = 0;
+            for (int j = 0; j < N; ++j) {
+                float d = dff(p + (size_t)j * 3, p + (size_t)last * 3, f + (size_t)j * C, f + (size_t)last * C, C, w_xyz);
+                float m = mind[j] < d ? mind[j] : d;
+                mind[j] = m;
+                if (m > best) { best = m; besti = j; }
+            }
+            last = besti;
+            o[i] = last;
+        }
+        free(mind);
+    }
+}
+
 /* SPEC.md §3 — ball query; radius_pc == NULL → scalar radius, else per-centroid radius[B,M] */
 ORC_API void orc_ball_query(const float *xyz, const float *new_xyz, int B, int N, int M, int S,
                             float radius, const float *radius_pc, int32_t *idx) {

@@ -53,7 +53,10 @@ def test_host_side_argument_errors(sad):
     assert L.sad_set_option(b"no_such_option", 1) == -1
     assert L.sad_fps_workspace_bytes(2, 1024) == 0
     assert L.sad_fps_workspace_bytes(2, 16384) == 2 * 16384 * 4   # Z-order permutation (bucketed kernel)
-    assert L.sad_fps_workspace_bytes(2, 65536) == 2 * 65536 * 4
+    assert L.sad_fps_workspace_bytes(2, 65536) == 2 * 65536 * 4 + 2 * 65536 * 16   # permutation + sorted float4 records
+    assert L.sad_fps_workspace_bytes(2, 100000) == 2 * 100000 * 4             # plain min-distance workspace
+    assert L.sad_ffps_workspace_bytes(2, 1000) == 2 * 1000 * 1000 * 4
+    assert L.sad_ffps_f32(p, p, 4, 1, 8, 4, 9, 1.0, p, p, None) == -1        # M > N
     dims = (ctypes.c_int * 4)(259, 256, 512, 1024)
     n = L.sad_mlp_packed_floats(3, dims, 1)
     kp = [264, 256, 512]

@@ -339,3 +339,38 @@ def test_random_shapes_index_ops(orc, sad, dev):
         k = int(rng.integers(1, min(64, N) + 1))
         np.testing.assert_array_equal(ops.knn_query(k, X, C).cpu().numpy(), orc.knn_query(k, xyz, new_xyz),
                                       err_msg=f"knn trial {trial} N={N} k={k}")
+
+
+# ---------------------------------------------------------------- F-FPS (SPEC.md §15)
+@pytest.mark.parametrize("B,N,C,M,w", [(2, 300, 5, 40, 1.0), (1, 1000, 64, 200, 0.5), (2, 2048, 32, 256, 1.0),
+                                       (1, 4096, 128, 512, 1.0), (1, 777, 3, 777, 0.0), (2, 130, 1, 20, 2.0)])
+def test_ffps_parity(orc, sad, dev, B, N, C, M, w):
+    """Feature-distance FPS: bit-exact indices vs the oracle (same metric, same evaluation order)."""
+    from sad_amd import ops
+    rng = np.random.default_rng(N + C)
+    xyz = _rand_xyz(300 + N, B, N, scale=4.0)
+    feat = rng.standard_normal((B, N, C)).astype(np.float32)
+    got = ops.ffps(_t(xyz, dev), _t(feat, dev), M, w).cpu().numpy()
+    np.testing.assert_array_equal(got, orc.ffps(xyz, feat, M, w))
+
+
+def test_ffps_degenerate_and_fused(orc, sad, dev):
+    """Zero features + w=1 reduce F-FPS to plain FPS; duplicated feature rows tie to the lowest
+    index; the fused D+F sampler is the concatenation of its halves; a strided feature view works."""
+    import torch
+    from sad_amd import ops
+    rng = np.random.default_rng(15)
+    xyz = _rand_xyz(15, 2, 600)
+    zeros = np.zeros((2, 600, 4), np.float32)
+    np.testing.assert_array_equal(ops.ffps(_t(xyz, dev), _t(zeros, dev), 100).cpu().numpy(), orc.fps(xyz, 100))
+    feat = rng.standard_normal((2, 600, 6)).astype(np.float32)
+    feat[:, 100:200] = feat[:, 7:8]                      # exact duplicates in feature space
+    same_xyz = np.repeat(xyz[:, :1], 600, axis=1)        # and identical coordinates: pure ties
+    np.testing.assert_array_equal(ops.ffps(_t(same_xyz, dev), _t(feat, dev), 550).cpu().numpy(),
+                                  orc.ffps(same_xyz, feat, 550))
+    got = ops.dfps_ffps(_t(xyz, dev), _t(feat, dev), 65).cpu().numpy()
+    np.testing.assert_array_equal(got[:, :32], orc.fps(xyz, 32))
+    np.testing.assert_array_equal(got[:, 32:], orc.ffps(xyz, feat, 33))
+    wide = torch.zeros(2, 600, 10, device=dev)
+    wide[:, :, 2:8] = _t(feat, dev)
+    np.testing.assert_array_equal(ops.ffps(_t(xyz, dev), wide[:, :, 2:8], 50).cpu().numpy(), orc.ffps(xyz, feat, 50))

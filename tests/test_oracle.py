@@ -420,3 +420,26 @@ def test_bf16_oracle_rounding_and_chain(orc):
     y = orc.mlp_rows_bf16(rows, [(W, b)], relu_mask=0)
     ref = orc.bf16_round(rows).astype(np.float64) @ orc.bf16_round(W).astype(np.float64).T + b
     assert np.allclose(y, ref, rtol=1e-6, atol=1e-6)
+
+
+def test_ffps_oracle_reduces_to_fps_and_is_greedy(orc):
+    """SPEC.md §15: zero features with w_xyz = 1 give plain FPS; with features every pick maximises
+    the min metric distance to the earlier picks (recomputed in numpy, same evaluation order)."""
+    rng = np.random.default_rng(151)
+    xyz = rng.random((2, 200, 3), dtype=np.float32)
+    np.testing.assert_array_equal(orc.ffps(xyz, np.zeros((2, 200, 3), np.float32), 50), orc.fps(xyz, 50))
+    feat = rng.standard_normal((2, 200, 4)).astype(np.float32)
+    idx = orc.ffps(xyz, feat, 30, 0.5)
+
+    def metric(b, q):
+        d = xyz[b] - xyz[b][q]
+        d2 = ((d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2]) * np.float32(0.5)
+        for c in range(4):
+            t = feat[b][:, c] - feat[b][q, c]
+            d2 = d2 + t * t
+        return d2
+    for b in range(2):
+        mind = np.full(200, np.inf, np.float32)
+        for i in range(1, 30):
+            mind = np.minimum(mind, metric(b, idx[b, i - 1]))
+            assert int(np.argmax(mind)) == idx[b, i]
