@@ -62,6 +62,9 @@ SIGNATURES = {
     "sad_gather_xyz_f32": (ctypes.c_int, [vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp]),
     "sad_gather_points": (ctypes.c_int, [vp, vp] + [ctypes.c_int] * 5 + [vp, vp]),
     "sad_group_points": (ctypes.c_int, [vp, vp] + [ctypes.c_int] * 6 + [vp, vp]),
+    "sad_group_points_grad_f32": (ctypes.c_int, [vp, vp] + [ctypes.c_int] * 5 + [vp, vp]),
+    "sad_max_pool_s_f32": (ctypes.c_int, [vp] + [ctypes.c_int] * 4 + [vp, vp, vp]),
+    "sad_max_pool_s_grad_f32": (ctypes.c_int, [vp, vp] + [ctypes.c_int] * 4 + [vp, vp]),
     "sad_ball_query_f32": (ctypes.c_int, [vp, vp, ctypes.c_float, vp] + [ctypes.c_int] * 4 + [vp, vp]),
     "sad_ball_query_multi_f32": (ctypes.c_int, [vp, vp, ctypes.c_int, c_f32p, vp,
                                                ctypes.POINTER(ctypes.c_int), ctypes.POINTER(vp),

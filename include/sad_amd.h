@@ -73,6 +73,18 @@ int sad_gather_points(const void *src, const int32_t *idx, int B, int C, int N, 
 int sad_group_points(const void *feat, const int32_t *idx, int B, int C, int N, int M, int S,
                      int elem_size, void *out, sad_stream_t stream);
 
+/* SPEC.md §16: backward of the unfused operators.
+ * group_points_grad: grad_out[B,C,M,S], idx[B,M,S] -> grad_feat[B,C,N] += scatter-add (float
+ * atomics; grad_feat must be zero, or hold a gradient to accumulate into, on entry); S = 1 is
+ * gather_points_grad.  max_pool_s: x[B,C,M,S] -> out[B,C,M], arg[B,C,M] (ties -> lowest s);
+ * max_pool_s_grad: grad_out[B,C,M], arg -> grad_x[B,C,M,S]. */
+int sad_group_points_grad_f32(const float *grad_out, const int32_t *idx, int B, int C, int N, int M,
+                              int S, float *grad_feat, sad_stream_t stream);
+int sad_max_pool_s_f32(const float *x, int B, int C, int M, int S, float *out, int32_t *arg,
+                       sad_stream_t stream);
+int sad_max_pool_s_grad_f32(const float *grad_out, const int32_t *arg, int B, int C, int M, int S,
+                            float *grad_x, sad_stream_t stream);
+
 /* SPEC.md §3.  xyz[B,N,3], new_xyz[B,M,3] -> idx[B,M,S], 1 <= S <= 64.
  * radius_pc == NULL: scalar `radius`; else per-centroid radius_pc[B,M] (adaptive) and `radius`
  * is ignored. */
