@@ -42,6 +42,51 @@ __global__ __launch_bounds__(256) void group_kernel(const T *__restrict__ feat,
     }
 }
 
+// LDS-staged variant: a workgroup copies the source rows of CHL channels of one scene (CHL*N
+// elements <= 128 KB) into LDS once — coalesced — and then serves the random per-neighbour reads
+// from LDS instead of L1/L2; the (m,s) axis stays the lane axis, 16-byte index loads and 16-byte
+// grouped stores.  Several workgroups split the (m,s) range of one (scene, channel block).
+template <typename T>
+__global__ __launch_bounds__(1024) void group_lds_kernel(const T *__restrict__ feat, const int32_t *__restrict__ idx,
+                                                         int C, int N, int MS, int CHL, int per_split,
+                                                         T *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T *s = reinterpret_cast<T *>(smem_raw);
+    const int b = blockIdx.z, c0 = blockIdx.y * CHL;
+    const int nch = C - c0 < CHL ? C - c0 : CHL;
+    const T *src = feat + ((size_t)b * C + c0) * N;
+    const int total = nch * N;
+    constexpr int EV = 16 / sizeof(T);
+    if ((total % EV) == 0 && ((uintptr_t)src % 16) == 0) {
+        for (int e = threadIdx.x; e < total / EV; e += 1024)
+            reinterpret_cast<uint4 *>(s)[e] = reinterpret_cast<const uint4 *>(src)[e];
+    } else {
+        for (int e = threadIdx.x; e < total; e += 1024) s[e] = src[e];
+    }
+    __syncthreads();
+    const int t0 = blockIdx.x * per_split;
+    const int t1 = t0 + per_split < MS ? t0 + per_split : MS;
+    for (int t = t0 + threadIdx.x * 4; t < t1; t += 1024 * 4) {
+        const int4 v = *reinterpret_cast<const int4 *>(idx + (size_t)b * MS + t);
+        for (int cc = 0; cc < nch; ++cc) {
+            const T *row = s + cc * N;
+            T *dst = out + ((size_t)b * C + c0 + cc) * MS + t;
+            if constexpr (sizeof(T) == 4) {
+                typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+                u32x4 o;
+                o.x = row[v.x]; o.y = row[v.y]; o.z = row[v.z]; o.w = row[v.w];
+                __builtin_nontemporal_store(o, reinterpret_cast<u32x4 *>(dst));   // streamed once, never re-read here
+            } else {
+                typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                u32x2 o;
+                o.x = (unsigned)row[v.x] | ((unsigned)row[v.y] << 16);
+                o.y = (unsigned)row[v.z] | ((unsigned)row[v.w] << 16);
+                __builtin_nontemporal_store(o, reinterpret_cast<u32x2 *>(dst));
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void gather_xyz_kernel(const float *__restrict__ xyz,
                                                          const int32_t *__restrict__ idx, int N,
                                                          int M, float *__restrict__ out) {
@@ -57,6 +102,35 @@ template <typename T>
 int launch_group(const void *feat, const int32_t *idx, int B, int C, int N, long long MS, void *out,
                  hipStream_t st) {
     const bool vec = (MS % 4 == 0) && (((uintptr_t)idx | (uintptr_t)out) % 16 == 0);
+    // LDS-staged path: worth it when every source element is gathered several times
+    const size_t slab_budget = 32 * 1024;   // two workgroups per CU: one stages while the other gathers
+    int chl = (int)(slab_budget / ((size_t)N * sizeof(T)));
+    chl = chl > 8 ? 8 : chl;
+    if (vec && chl >= 1 && MS >= 4 * (long long)N && MS >= 8192 && sad::get_option(sad::OPT_GROUP_VARIANT) != 1) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(&group_lds_kernel<uint32_t>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+                hipFuncSetAttribute(reinterpret_cast<const void *>(&group_lds_kernel<uint16_t>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+                (void)hipGetLastError();
+            attr_set = true;
+        }
+        if (chl > C) chl = C;
+        const int cblocks = (C + chl - 1) / chl;
+        // enough workgroups for ~4 per CU, each with at least 4096 outputs per channel
+        long long splits = (1024LL + (long long)B * cblocks - 1) / ((long long)B * cblocks);
+        const long long max_splits = (MS + 4095) / 4096;
+        splits = splits < 1 ? 1 : (splits > max_splits ? max_splits : splits);
+        long long per_split = ((MS + splits - 1) / splits + 4095) / 4096 * 4096;
+        splits = (MS + per_split - 1) / per_split;
+        if (cblocks <= 65535 && splits <= 65535) {
+            hipLaunchKernelGGL((group_lds_kernel<T>), dim3((unsigned)splits, cblocks, B), dim3(1024),
+                               (size_t)chl * N * sizeof(T), st, (const T *)feat, idx, C, N, (int)MS, chl, (int)per_split,
+                               (T *)out);
+            return sad::check_launch("sad_group_points (lds)");
+        }
+    }
     const int per = vec ? 4 : 1;
     dim3 grid((unsigned)((MS + 256LL * per - 1) / (256LL * per)), (C + CH - 1) / CH, B);
     if (vec)

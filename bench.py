@@ -290,6 +290,26 @@ def main():
                              "bound": "hbm", "achieved": round(gbps, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
                              "frac": round(gbps / PEAK_HBM_GBPS, 5),
                              "pair_tests_per_s": round(work["pair_tests"] * B / (bq_ms * 1e-3) / 1e12, 3)})
+            # the unfused group_points operator (not on the fused path; part of the drop-in surface):
+            # an HBM-bound gather, timed here on the SA2 branch shape with its own HIP events
+            gC, gN, gM, gS = 64, 4096, 1024, 32
+            gfeat = torch.randn(B, gC, gN, device=dev)
+            gidx = torch.randint(0, gN, (B, gM, gS), device=dev, dtype=torch.int32)
+            ops.group_points(gfeat, gidx)
+            torch.cuda.synchronize()
+            ge0, ge1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ge0.record()
+            for _ in range(10):
+                ops.group_points(gfeat, gidx)
+            ge1.record()
+            torch.cuda.synchronize()
+            g_ms = ge0.elapsed_time(ge1) / 10
+            g_bytes = B * (gM * gS * 4 + gC * gM * gS * 4 + gC * gN * 4)     # idx + grouped out + source once
+            kern.append({"kernel": "group_lds_kernel (unfused group_points, SA2 branch shape, outside the timed region)",
+                         "ms_per_launch": round(g_ms, 4), "bound": "hbm",
+                         "achieved": round(g_bytes / (g_ms * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+                         "frac": round(g_bytes / (g_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4),
+                         "algorithmic_bytes": g_bytes})
             res["kernels"] = kern
             res["mlp_launches"] = {n: {"ms": round(v / tsteps, 3), "executed_gflop": round(per_flops.get(n, 0) / 1e9, 1),
                                        "tflops": round(per_flops.get(n, 0) / (v / tsteps * 1e-3) / 1e12, 1),

@@ -234,7 +234,8 @@ def test_knn_parity(orc, sad, dev, B, N, M, K):
 
 # ---------------------------------------------------------------- group / gather
 @pytest.mark.parametrize("dtype", ["float32", "float16"])
-@pytest.mark.parametrize("B,C,N,M,S", [(2, 5, 77, 9, 4), (2, 67, 4096, 1024, 32), (1, 3, 100, 7, 3)])
+@pytest.mark.parametrize("B,C,N,M,S", [(2, 5, 77, 9, 4), (2, 67, 4096, 1024, 32), (1, 3, 100, 7, 3),
+                                       (1, 5, 16384, 4096, 16), (2, 9, 1000, 300, 32)])
 def test_group_gather_parity(orc, sad, dev, dtype, B, C, N, M, S):
     from sad_amd import ops
     rng = np.random.default_rng(400 + N)
@@ -247,6 +248,23 @@ def test_group_gather_parity(orc, sad, dev, dtype, B, C, N, M, S):
                                   orc.gather_points(feat, i2))
     xyz = rng.normal(size=(B, N, 3)).astype(np.float32)
     np.testing.assert_array_equal(ops.gather_xyz(_t(xyz, dev), _t(i2, dev)).cpu().numpy(), orc.gather_xyz(xyz, i2))
+
+
+def test_group_points_lds_and_l2_paths_agree(sad, dev):
+    """The LDS-staged kernel (default for big groups) and the L2-gather kernel give the same bytes."""
+    import torch
+    from sad_amd import _lib, ops
+    feat = torch.randn(3, 21, 2048, device=dev)
+    idx = torch.randint(0, 2048, (3, 512, 32), device=dev, dtype=torch.int32)
+    a = ops.group_points(feat, idx)
+    _lib.set_option("group_variant", 1)
+    try:
+        b = ops.group_points(feat, idx)
+    finally:
+        _lib.set_option("group_variant", 0)
+    assert torch.equal(a, b)
+    want = torch.gather(feat[:, :, None, :].expand(-1, -1, 512, -1), 3, idx.long()[:, None].expand(-1, 21, -1, -1))
+    assert torch.equal(a, want)
 
 
 def test_group_points_bf16(sad, dev):
