@@ -48,6 +48,12 @@ struct BfParams {
     int R;                     // rows per tile
     int bufA_elems;            // bf16 elements of LDS buffer 0 (buffer 1 follows)
     int tiles;
+    // packed mode (cnt given): only the leading cnt[g] rows of every group are computed (a row that
+    // repeats the group's first neighbour cannot change the max).  rowtab from sad::launch_rowscan:
+    // hdr[4] = {total rows, tiles, -, -}, row_start[ngroups + 1], tile_first[tiles]
+    const int *rowtab;
+    int ngroups;
+    int meta_off;              // byte offset of the per-tile row maps (s_srow[R], s_grp[R]) in LDS
 };
 
 __device__ __forceinline__ void atomic_max_pos(float *addr, float v) {
@@ -64,7 +70,7 @@ __device__ __forceinline__ __bf16 load_feat(const void *feat, int is_bf16, size_
 // chain (D[row, cout] = X·Wᵀ, max over the group); else D[cout, row] = W·Xᵀ.
 template <int RW, int CW, bool POOL>
 __device__ __forceinline__ void run_units(const BfParams &p, int l, const __bf16 *X, __bf16 *Y, long long row0,
-                                          int wave, int lane, int NRB) {
+                                          int wave, int lane, int NRB, const int *s_grp) {
     const int ldx = p.kp[l] + 8, ldy = p.kp[l + 1] + 8;
     const int KB = p.kp[l] >> 4;
     const int CT = (p.cout[l] + 31) >> 5;
@@ -132,6 +138,41 @@ __device__ __forceinline__ void run_units(const BfParams &p, int l, const __bf16
         if constexpr (POOL) {
             // acc[r][c][i] = y[row rb*32 + 8*(i/4) + 4*(lane/32) + i%4][cout ct*32 + lane%32]
             const int S = p.S;
+            if (p.rowtab) {
+                // packed rows: a group is a run of consecutive tile rows with arbitrary boundaries.
+                // Each lane walks its 4 runs of 4 consecutive rows; a run inside one group is one atomic.
+#pragma unroll
+                for (int c = 0; c < CW; ++c) {
+                    if (c > 0 && cp * CW + c >= CT) continue;
+                    const int co = ct[c] * 32 + (lane & 31);
+                    if (co >= p.cout[l]) continue;
+                    float *orow = reinterpret_cast<float *>(p.out) + p.col_off + co;
+#pragma unroll
+                    for (int r = 0; r < RW; ++r) {
+                        if (r > 0 && rp * RW + r >= NRB) continue;
+                        const f32x16 &av = acc[r][c];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const int4 gq = *reinterpret_cast<const int4 *>(s_grp + rb[r] * 32 + 8 * q + 4 * (lane >> 5));
+                            const float v0 = av[4 * q], v1 = av[4 * q + 1], v2 = av[4 * q + 2], v3 = av[4 * q + 3];
+                            if (gq.x == gq.w) {           // (covers the all-invalid run: -1 == -1)
+                                if (gq.x >= 0) {
+                                    float m = v0 > v1 ? v0 : v1;
+                                    const float m2 = v2 > v3 ? v2 : v3;
+                                    m = m > m2 ? m : m2;
+                                    atomic_max_pos(orow + (size_t)gq.x * p.ld_out, m > 0.f ? m : 0.f);
+                                }
+                            } else {
+                                if (gq.x >= 0) atomic_max_pos(orow + (size_t)gq.x * p.ld_out, v0 > 0.f ? v0 : 0.f);
+                                if (gq.y >= 0) atomic_max_pos(orow + (size_t)gq.y * p.ld_out, v1 > 0.f ? v1 : 0.f);
+                                if (gq.z >= 0) atomic_max_pos(orow + (size_t)gq.z * p.ld_out, v2 > 0.f ? v2 : 0.f);
+                                if (gq.w >= 0) atomic_max_pos(orow + (size_t)gq.w * p.ld_out, v3 > 0.f ? v3 : 0.f);
+                            }
+                        }
+                    }
+                }
+                continue;
+            }
 #pragma unroll
             for (int c = 0; c < CW; ++c) {
                 if (c > 0 && cp * CW + c >= CT) continue;
@@ -254,19 +295,73 @@ __global__ __launch_bounds__(BF_T) void mlp_bf16_kernel(const BfParams p) {
     const int ld0 = p.kp[0] + 8;
     const bool vec = p.feat && (C & 7) == 0 && (p.ld_feat & 7) == 0;   // 16-byte (bf16) / 32-byte (f32) chunks
 
-    for (int tile = blockIdx.x; tile < p.tiles; tile += gridDim.x) {
+    int *const s_srow = reinterpret_cast<int *>(smem + p.meta_off);   // dense row (b*M + m)*S + s of tile row r, -1 = none
+    int *const s_grp = s_srow + R;                                    // its group b*M + m, -1 = none
+    int *const s_rs = s_grp + R;                                      // packed mode: row_start of the tile's groups (R + 1)
+    const bool packed = p.rowtab != nullptr;
+    const int ntiles = packed ? p.rowtab[1] : p.tiles;
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const long long row0 = (long long)tile * R;
+        // ---- which dense row does tile row r stand for? ---------------------------------------
+        if (packed) {
+            const int *row_start = p.rowtab + 4;
+            const int lo = row_start[p.ngroups + 1 + tile];          // tile_first[tile]
+            const int total = p.rowtab[0];
+            for (int i = tid; i <= R; i += BF_T) s_rs[i] = lo + i <= p.ngroups ? row_start[lo + i] : 0x7fffffff;
+            for (int i = tid; i < R; i += BF_T) s_grp[i] = 0;       // head marks
+            __syncthreads();
+            for (int i = tid + 1; i <= R; i += BF_T) {               // group lo + i starts at tile row s_rs[i] - row0
+                const long long pos = (long long)s_rs[i] - row0;
+                if (pos >= 0 && pos < R && lo + i < p.ngroups) s_grp[pos] = i;
+            }
+            __syncthreads();
+            // inclusive prefix max of the head marks = index (relative to lo) of the group of each row;
+            // every wave scans both 64-row halves itself (no carry exchange)
+            int carry = 0, mine = 0;
+            for (int h = 0; h * 64 < R; ++h) {
+                int v = s_grp[h * 64 + lane];
+                v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, false));   // row_shr:1
+                v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, false));   // row_shr:2
+                v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, false));   // row_shr:4
+                v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, false));   // row_shr:8
+                v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false));   // row_bcast:15
+                v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false));   // row_bcast:31
+                v = max(v, carry);
+                if (h == (tid >> 6)) mine = v;
+                carry = __builtin_amdgcn_readlane(v, 63);
+            }
+            __syncthreads();
+            if (tid < R) {
+                const long long pr = row0 + tid;
+                int g = -1, srow = -1;
+                if (pr < total) {
+                    g = lo + mine;
+                    srow = g * p.S + (int)(pr - s_rs[mine]);
+                }
+                s_grp[tid] = g;
+                s_srow[tid] = srow;
+            }
+        } else {
+            for (int r = tid; r < R; r += BF_T) {
+                const long long row = row0 + r;
+                const bool ok = row < p.rows;
+                s_srow[r] = ok ? (int)row : -1;
+                s_grp[r] = ok ? (int)(grouped ? row / p.S : row) : -1;
+            }
+        }
+        __syncthreads();
         // ---- stage the layer-0 input rows ----------------------------------------------------
         if (vec) {
             const int C8 = C >> 3;
             for (int e = tid; e < R * C8; e += BF_T) {
                 const int r = e / C8, c8 = e - r * C8;
-                const long long row = row0 + r;
+                const int row = s_srow[r];
                 bf16x8 v = {};
-                if (row < p.rows) {
+                if (row >= 0) {
                     size_t src;
                     if (grouped) {
-                        const long long b = row / ((long long)p.M * p.S);
+                        const int b = s_grp[r] / p.M;
                         src = ((size_t)b * p.N + p.idx[row]) * p.ld_feat + c8 * 8;
                     } else {
                         src = (size_t)row * p.ld_feat + c8 * 8;
@@ -284,14 +379,14 @@ __global__ __launch_bounds__(BF_T) void mlp_bf16_kernel(const BfParams p) {
             }
         }
         for (int r = tid; r < R; r += BF_T) {
-            const long long row = row0 + r;
-            const bool ok = row < p.rows;
+            const int row = s_srow[r];
+            const bool ok = row >= 0;
             __bf16 *x = buf0 + r * ld0;
             size_t src = 0;
             long long g = 0, b = 0;
             int j = 0;
             if (ok && grouped) {
-                g = row / p.S;
+                g = s_grp[r];
                 b = g / p.M;
                 j = p.idx[row];
                 src = ((size_t)b * p.N + j) * p.ld_feat;
@@ -334,15 +429,15 @@ __global__ __launch_bounds__(BF_T) void mlp_bf16_kernel(const BfParams p) {
             const int RWs = (NRB >= 2 && T >= 8) ? 2 : 1;
             const int CWs = (CT >= 2 && (T >= 16 || (T >= 8 && NRB < 2))) ? 2 : 1;
             if (pool) {
-                if (RWs == 2 && CWs == 2) run_units<2, 2, true>(p, l, X, Y, row0, wave, lane, NRB);
-                else if (RWs == 2) run_units<2, 1, true>(p, l, X, Y, row0, wave, lane, NRB);
-                else if (CWs == 2) run_units<1, 2, true>(p, l, X, Y, row0, wave, lane, NRB);
-                else run_units<1, 1, true>(p, l, X, Y, row0, wave, lane, NRB);
+                if (RWs == 2 && CWs == 2) run_units<2, 2, true>(p, l, X, Y, row0, wave, lane, NRB, s_grp);
+                else if (RWs == 2) run_units<2, 1, true>(p, l, X, Y, row0, wave, lane, NRB, s_grp);
+                else if (CWs == 2) run_units<1, 2, true>(p, l, X, Y, row0, wave, lane, NRB, s_grp);
+                else run_units<1, 1, true>(p, l, X, Y, row0, wave, lane, NRB, s_grp);
             } else {
-                if (RWs == 2 && CWs == 2) run_units<2, 2, false>(p, l, X, Y, row0, wave, lane, NRB);
-                else if (RWs == 2) run_units<2, 1, false>(p, l, X, Y, row0, wave, lane, NRB);
-                else if (CWs == 2) run_units<1, 2, false>(p, l, X, Y, row0, wave, lane, NRB);
-                else run_units<1, 1, false>(p, l, X, Y, row0, wave, lane, NRB);
+                if (RWs == 2 && CWs == 2) run_units<2, 2, false>(p, l, X, Y, row0, wave, lane, NRB, s_grp);
+                else if (RWs == 2) run_units<2, 1, false>(p, l, X, Y, row0, wave, lane, NRB, s_grp);
+                else if (CWs == 2) run_units<1, 2, false>(p, l, X, Y, row0, wave, lane, NRB, s_grp);
+                else run_units<1, 1, false>(p, l, X, Y, row0, wave, lane, NRB, s_grp);
             }
             __syncthreads();
         }
@@ -433,6 +528,12 @@ SAD_API int sad_mlp_chain_bf16(const sad_mlp_bf16_args *a, sad_stream_t stream) 
     p.N = a->N; p.M = a->M; p.S = a->S; p.C = a->C;
     p.L = a->L; p.relu_mask = a->relu_mask;
     p.out = a->out; p.out_bf16 = a->out_bf16; p.ld_out = a->ld_out; p.col_off = a->col_off;
+    const bool packed = grouped && a->cnt && a->workspace;
+    if (packed) {
+        SAD_REQUIRE((uintptr_t)a->workspace % 16 == 0, "sad_mlp_chain_bf16: workspace must be 16-byte aligned");
+        SAD_REQUIRE((long long)a->B * a->M < (1LL << 30) && p.rows < (1LL << 31), "sad_mlp_chain_bf16: too many groups");
+        p.ngroups = a->B * a->M;
+    }
     const unsigned char *q = (const unsigned char *)a->packed;
     int ldA = 0, ldB = 0;
     for (int l = 0; l < a->L; ++l) {
@@ -449,13 +550,18 @@ SAD_API int sad_mlp_chain_bf16(const sad_mlp_bf16_args *a, sad_stream_t stream) 
     p.kp[a->L] = kpad(a->L, a->dims[a->L]);
     const size_t budget = 150 * 1024;
     int R = 128;
-    while (R > 32 && (size_t)R * 2 * (ldA + ldB) > budget) R >>= 1;
-    const size_t lds = (size_t)R * 2 * (ldA + ldB);
-    if (lds > 160 * 1024) return sad::fail(SAD_EUNSUPPORTED, "sad_mlp_chain_bf16: layer widths need %zu bytes of LDS", lds);
+    auto lds_of = [&](int r) { return (((size_t)r * 2 * (ldA + ldB) + 15) & ~(size_t)15) + (size_t)(3 * r + 4) * sizeof(int); };
+    while (R > 32 && lds_of(R) > budget) R >>= 1;
+    if (lds_of(R) > 160 * 1024) return sad::fail(SAD_EUNSUPPORTED, "sad_mlp_chain_bf16: layer widths need %zu bytes of LDS", lds_of(R));
     while (R > 32 && p.rows <= R / 2) R >>= 1;
     p.R = R;
     p.bufA_elems = R * ldA;
-    const long long tiles = (p.rows + R - 1) / R;
+    p.meta_off = (int)(((size_t)R * 2 * (ldA + ldB) + 15) & ~(size_t)15);
+    const long long tiles = (p.rows + R - 1) / R;       // packed mode: an upper bound, the kernel reads the real count
+    if (packed) {
+        p.rowtab = (const int *)a->workspace;
+        if (int e = sad::launch_rowscan(a->cnt, p.ngroups, a->S, R, (int *)a->workspace, (hipStream_t)stream)) return e;
+    }
     SAD_REQUIRE(tiles < (1LL << 31), "sad_mlp_chain_bf16: too many rows");
     p.tiles = (int)tiles;
     static bool attr_set = false;
@@ -465,7 +571,7 @@ SAD_API int sad_mlp_chain_bf16(const sad_mlp_bf16_args *a, sad_stream_t stream) 
             (void)hipGetLastError();
         attr_set = true;
     }
-    const size_t lds_now = (size_t)R * 2 * (ldA + ldB);
+    const size_t lds_now = lds_of(R);
     int per_cu = (int)((160 * 1024) / (lds_now > 0 ? lds_now : 1));
     per_cu = per_cu < 1 ? 1 : (per_cu > 4 ? 4 : per_cu);
     const int grid = (int)(tiles < 256LL * per_cu ? tiles : 256LL * per_cu);

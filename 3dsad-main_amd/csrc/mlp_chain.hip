@@ -214,6 +214,80 @@ __global__ __launch_bounds__(SCAN_T) void rowscan_kernel(const int32_t *__restri
     }
 }
 
+// The same table with two parallel launches (used above 4096 groups, where one workgroup walking
+// 128 groups per thread costs 50-100 us): block sums, then every block adds the sums of the blocks
+// before it to its own in-block scan.
+__global__ __launch_bounds__(SCAN_T) void rowscan_sums_kernel(const int32_t *__restrict__ cnt, int ngroups, int S,
+                                                              int nodedup, int *__restrict__ blk_sum) {
+    __shared__ int wsum[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = blockIdx.x * SCAN_T + tid;
+    int c = 0;
+    if (g < ngroups) {
+        c = cnt[g];
+        c = c < 1 ? 1 : (c > S ? S : c);
+        c = nodedup ? S : c;
+    }
+    for (int off = 32; off >= 1; off >>= 1) c += __shfl_xor(c, off, 64);
+    if (lane == 0) wsum[wave] = c;
+    __syncthreads();
+    if (tid == 0) {
+        int t = 0;
+        for (int w = 0; w < 16; ++w) t += wsum[w];
+        blk_sum[blockIdx.x] = t;
+    }
+}
+
+__global__ __launch_bounds__(SCAN_T) void rowscan_write_kernel(const int32_t *__restrict__ cnt, int ngroups, int S,
+                                                               int nodedup, int R, const int *__restrict__ blk_sum,
+                                                               int *__restrict__ tab) {
+    __shared__ int wsum[16];
+    __shared__ int s_base;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int *row_start = tab + 4;
+    int *pass_first = tab + 4 + ngroups + 1;
+    int part = 0;
+    for (int b = tid; b < (int)blockIdx.x; b += SCAN_T) part += blk_sum[b];
+    for (int off = 32; off >= 1; off >>= 1) part += __shfl_xor(part, off, 64);
+    if (lane == 0) wsum[wave] = part;
+    __syncthreads();
+    if (tid == 0) {
+        int t = 0;
+        for (int w = 0; w < 16; ++w) t += wsum[w];
+        s_base = t;
+    }
+    __syncthreads();
+    const int base = s_base;
+    const int g = blockIdx.x * SCAN_T + tid;
+    int c = 0;
+    if (g < ngroups) {
+        c = cnt[g];
+        c = c < 1 ? 1 : (c > S ? S : c);
+        c = nodedup ? S : c;
+    }
+    int incl = c;
+    for (int off = 1; off < 64; off <<= 1) {
+        const int v = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += v;
+    }
+    __syncthreads();
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    int run = base + incl - c;
+    for (int w = 0; w < wave; ++w) run += wsum[w];
+    if (g < ngroups) {
+        row_start[g] = run;
+        for (int pp = (run + R - 1) / R; pp * R < run + c; ++pp) pass_first[pp] = g;
+        if (g == ngroups - 1) {
+            const int total = run + c;
+            row_start[ngroups] = total;
+            tab[0] = total;
+            tab[1] = (total + R - 1) / R;
+            tab[2] = 0;
+        }
+    }
+}
+
 // Group of the last compact row (used for the clamped rows past the end of the last pass).
 __device__ __forceinline__ int s_off_last_group(const int *s_off, int G, int T) {
     int lo = 0, hi = G;
@@ -802,10 +876,28 @@ SAD_API int sad_mlp_pack_f32(int L, const int *dims, int first_has_xyz, const fl
     return sad::check_launch("sad_mlp_pack_f32");
 }
 
+namespace sad {
+// Prefix-sums the per-group row counts into the table described at rowscan_kernel (shared with the
+// bf16 chain, csrc/mlp_bf16.hip).
+int launch_rowscan(const int32_t *cnt, int ngroups, int S, int R, int *tab, hipStream_t st, int nodedup) {
+    if (ngroups <= 4096) {
+        hipLaunchKernelGGL(rowscan_kernel, dim3(1), dim3(SCAN_T), 0, st, cnt, ngroups, S, nodedup, R, tab);
+    } else {
+        // block sums live behind the table (sad_mlp_workspace_bytes reserves them)
+        const int nblk = (ngroups + SCAN_T - 1) / SCAN_T;
+        int *blk_sum = tab + 4 + (ngroups + 1) + ((long long)ngroups * S / 32 + 2);
+        hipLaunchKernelGGL(rowscan_sums_kernel, dim3(nblk), dim3(SCAN_T), 0, st, cnt, ngroups, S, nodedup, blk_sum);
+        hipLaunchKernelGGL(rowscan_write_kernel, dim3(nblk), dim3(SCAN_T), 0, st, cnt, ngroups, S, nodedup, R, blk_sum, tab);
+    }
+    return check_launch("rowscan");
+}
+}  // namespace sad
+
 SAD_API size_t sad_mlp_workspace_bytes(int B, int M, int S) {
     if (B < 1 || M < 1 || S < 1) return 0;
     const size_t ng = (size_t)B * M;
-    return sizeof(int) * (4 + (ng + 1) + (ng * S / 32 + 2)) + 64;   // hdr, row_start, pass_first (R >= 32)
+    // hdr, row_start, pass_first (R >= 32), block sums of the two-launch scan
+    return sizeof(int) * (4 + (ng + 1) + (ng * S / 32 + 2) + (ng / 1024 + 2)) + 64;
 }
 
 SAD_API int sad_mlp_chain_f32(const sad_mlp_args *a, sad_stream_t stream) {
@@ -986,8 +1078,7 @@ SAD_API int sad_mlp_chain_f32(const sad_mlp_args *a, sad_stream_t stream) {
         SAD_REQUIRE((uintptr_t)a->workspace % 16 == 0, "sad_mlp_chain_f32: workspace must be 16-byte aligned");
         SAD_REQUIRE(p.total_groups < (1LL << 30), "sad_mlp_chain_f32: too many groups");
         p.rowtab = (int *)a->workspace;
-        hipLaunchKernelGGL(rowscan_kernel, dim3(1), dim3(SCAN_T), 0, (hipStream_t)stream, a->cnt,
-                           (int)p.total_groups, a->S, p.nodedup, (int)R, p.rowtab);
+        if (int e = sad::launch_rowscan(a->cnt, (int)p.total_groups, a->S, (int)R, p.rowtab, (hipStream_t)stream, p.nodedup)) return e;
         const long long upper = (p.total_groups * a->S + R - 1) / R;
         const long long per_cu = lds_final > 80 * 1024 ? 1 : (lds_final > 52 * 1024 ? 2 : (lds_final > 39 * 1024 ? 3 : 4));
         grid_dyn = upper < 256 * per_cu ? upper : 256 * per_cu;

@@ -503,7 +503,8 @@ class PackedMLPBf16:
                 cnt: Optional[torch.Tensor] = None) -> torch.Tensor:
         """xyz [B,N,3] f32; feat_pm point-major [B,N,C] bf16/f32 (or None); new_xyz [B,M,3]; idx
         [B,M,S] -> out[:, :, col_off:col_off+C_out] of a ZERO-initialised float32 [B,M,ld] buffer.
-        ``cnt`` is accepted for signature parity with PackedMLP and ignored (rows are dense)."""
+        With ``cnt`` ([B,M] int32 from ball_query_multi(return_counts=True)) only the leading cnt
+        rows of each group are computed — the ball query's padding rows cannot change the max."""
         if not self.first_has_xyz:
             raise RuntimeError("this PackedMLPBf16 was packed without the xyz prefix")
         xyz = _need(xyz, "xyz", torch.float32, 3)
@@ -530,6 +531,12 @@ class PackedMLPBf16:
         a.xyz, a.new_xyz, a.idx = xyz.data_ptr(), new_xyz.data_ptr(), idx.data_ptr()
         a.B, a.N, a.M, a.S, a.C = B, N, M, S, C
         a.out, a.out_bf16, a.ld_out, a.col_off = out.data_ptr(), 0, out.stride(-2), col_off
+        if cnt is not None:
+            cnt = _need(cnt, "cnt", torch.int32, 2)
+            if tuple(cnt.shape) != (B, M):
+                raise ValueError("cnt must be [B,M]")
+            ws = torch.empty((lib().sad_mlp_workspace_bytes(B, M, S),), dtype=torch.uint8, device=xyz.device)
+            a.cnt, a.workspace = cnt.data_ptr(), ws.data_ptr()
         with _timed("mlp", self.name):
             check(lib().sad_mlp_chain_bf16(ctypes.byref(a), _stream()), "sad_mlp_chain_bf16")
         return out

@@ -239,7 +239,7 @@ def main():
             tsteps = max(1, timed_steps)
             mlp_ms = per_kind.get("mlp", 0.0) / tsteps
             flops = work["mlp_flops"] * B                      # dense definition (SPEC.md §6)
-            exec_flops, row_frac, per_flops = executed_flops(det, points, cfg, dense=args.dtype != "f32")
+            exec_flops, row_frac, per_flops = executed_flops(det, points, cfg)
             ach = exec_flops / (mlp_ms * 1e-3) / 1e12 if mlp_ms > 0 else 0.0
             n_mlp = sum(1 for k, _, _, _ in log if k == "mlp") // tsteps
             # the same launches without a sibling main stream (kernel durations are then not stretched

@@ -172,7 +172,7 @@ int sad_mlp_chain_f32(const sad_mlp_args *args, sad_stream_t stream);
  * for sad_mlp_pack_f32; `packed` needs sad_mlp_packed_bytes_bf16() bytes, 16-byte aligned).
  * Fields as in sad_mlp_args, except: feat is bf16 (feat_bf16 = 1) or f32 (0, rounded on load) with
  * ld_feat in ELEMENTS; grouped output is f32 and must be zero on entry (atomic max merge); plain
- * output is f32 or bf16 (out_bf16).  Dense rows: padding rows are computed, not skipped. */
+ * output is f32 or bf16 (out_bf16). */
 size_t sad_mlp_packed_bytes_bf16(int L, const int *dims, int first_has_xyz);
 int sad_mlp_pack_bf16(int L, const int *dims, int first_has_xyz, const float *const *W,
                       const float *const *bias, void *packed, sad_stream_t stream);
@@ -192,6 +192,11 @@ typedef struct sad_mlp_bf16_args {
     int out_bf16;
     int ld_out;
     int col_off;
+    /* optional, grouped mode: cnt[B,M] from the ball query + sad_mlp_workspace_bytes(B,M,S) bytes of
+     * 16-byte aligned scratch -> only the leading cnt rows of each group are computed (rows that
+     * repeat the first neighbour cannot change the max); both NULL = dense rows */
+    const int32_t *cnt;
+    void *workspace;
 } sad_mlp_bf16_args;
 int sad_mlp_chain_bf16(const sad_mlp_bf16_args *args, sad_stream_t stream);
 

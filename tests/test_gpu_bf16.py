@@ -86,6 +86,12 @@ def test_grouped_bf16(orc, sad, dev, B, N, M, S, C, mlp, radius):
     if C:   # float32 features are rounded on load: same result
         got32 = m.grouped(_t(xyz, dev), _t(feat, dev), _t(new_xyz, dev), _t(idx, dev)).cpu().numpy()
         assert np.array_equal(got32, got)
+    # padding rows skipped (counts from the ball query): a duplicate row cannot change the max, and a
+    # row's result does not depend on its tile position -> identical bits
+    idxs, cnts = ops.ball_query_multi([radius], [S], _t(xyz, dev), _t(new_xyz, dev), return_counts=True)
+    np.testing.assert_array_equal(idxs[0].cpu().numpy(), idx)
+    packed = m.grouped(_t(xyz, dev), ft, _t(new_xyz, dev), idxs[0], cnt=cnts[0]).cpu().numpy()
+    assert np.array_equal(packed, got), f"packed vs dense: {np.abs(packed - got).max()}"
 
 
 def test_nuscenes_stage_bf16(orc, sad, dev):
