@@ -62,6 +62,19 @@ TINY = DetectorConfig(
     n_cand=64,
 )
 
+# BASELINE.json configs[4]: nuScenes-shaped scenes — 65 536 points on [-51.2, 51.2]^2 with 4 extra
+# channels, "same topology x4 points" (SURVEY.md §8(d)); run with dtype="bf16" (SPEC.md §14).
+NUSCENES = DetectorConfig(
+    n_points=65536,
+    in_feat=4,
+    stages=(
+        SAStage(16384, (0.2, 0.4, 0.8), (32, 32, 64), ((16, 16, 32), (16, 16, 32), (32, 32, 64)), 64),
+        SAStage(4096, (0.4, 0.8, 1.6), (32, 32, 64), ((64, 64, 128), (64, 64, 128), (64, 96, 128)), 128),
+        SAStage(2048, (1.6, 3.2, 4.8), (32, 32, 32), ((128, 128, 256), (128, 192, 256), (128, 256, 256)), 256),
+    ),
+    n_cand=1024,
+)
+
 # BASELINE.json configs[0]: one SA layer, no features, no aggregation.
 CONFIG0_SA = SAStage(256, (0.2,), (32,), ((64, 64, 128),), 0)
 

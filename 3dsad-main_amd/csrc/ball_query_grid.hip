@@ -157,14 +157,19 @@ template <int NR>
 __global__ __launch_bounds__(GQ_WAVES * 64) void grid_query_kernel(const float *__restrict__ new_xyz,
                                                                    const char *__restrict__ ws,
                                                                    GQParams prm, int N, int M) {
-    extern __shared__ unsigned bm_all[];        // GQ_WAVES * NR * NWP words, zero between centroids
+    extern __shared__ unsigned bm_all[];        // GQ_WAVES * NR * (NWP + 64) words, zero between centroids
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int b = blockIdx.y;
     const int NW = (N + 31) >> 5;               // bitmap words
-    const int WPL = (NW + 63) >> 6;             // words per lane in the scan
+    int wshift = 0;                             // words per lane in the scan: 2^wshift (<= 32 for N <= 65536)
+    while ((64 << wshift) < NW) ++wshift;
+    const int WPL = 1 << wshift;
     const int NWP = WPL * 64;                   // padded words per bitmap
-    unsigned *bm = bm_all + (size_t)wave * NR * NWP;
+    unsigned *bm = bm_all + (size_t)wave * NR * (NWP + 64);
+    // second level: dm[r*64 + l] has bit k set iff word l*WPL + k of bitmap r is non-zero, so the
+    // scan touches only the words that received a bit (cost ~ accepted points, not N)
+    unsigned *dm = bm + NR * NWP;
     const char *base = ws + (size_t)b * scene_ws_bytes(N);
     const GridHdr *hdr = reinterpret_cast<const GridHdr *>(base);
     const int *cell_start = reinterpret_cast<const int *>(base + sizeof(GridHdr));
@@ -172,7 +177,7 @@ __global__ __launch_bounds__(GQ_WAVES * 64) void grid_query_kernel(const float *
     const float x0 = hdr->x0, y0 = hdr->y0, z0 = hdr->z0, inv = hdr->inv;
     const int gx = hdr->gx, gy = hdr->gy, gz = hdr->gz;
 
-    for (int w = lane; w < NR * NWP; w += 64) bm[w] = 0u;
+    for (int w = lane; w < NR * (NWP + 64); w += 64) bm[w] = 0u;
 
     for (int cc = 0; cc < GQ_CPW; ++cc) {
         const int m = (blockIdx.x * GQ_WAVES + wave) * GQ_CPW + cc;
@@ -214,7 +219,11 @@ __global__ __launch_bounds__(GQ_WAVES * 64) void grid_query_kernel(const float *
             const unsigned j = (unsigned)__float_as_int(pr.w);
 #pragma unroll
             for (int r = 0; r < NR; ++r)
-                if (valid && d < r2[r]) atomicOr(&bm[r * NWP + (j >> 5)], 1u << (j & 31));
+                if (valid && d < r2[r]) {
+                    const unsigned w = j >> 5;
+                    atomicOr(&bm[r * NWP + w], 1u << (j & 31));
+                    atomicOr(&dm[r * 64 + (w >> wshift)], 1u << (w & (WPL - 1)));
+                }
         }
         // scan each bitmap in ascending bit order; a lane owns WPL consecutive words
 #pragma unroll
@@ -222,8 +231,10 @@ __global__ __launch_bounds__(GQ_WAVES * 64) void grid_query_kernel(const float *
             const int S = prm.nsample[r];
             int32_t *out = prm.idx[r] + ((size_t)b * M + m) * S;
             unsigned *bw = bm + r * NWP + lane * WPL;
+            const unsigned dirty = dm[r * 64 + lane];
+            dm[r * 64 + lane] = 0u;
             int cnt = 0;
-            for (int k = 0; k < WPL; ++k) cnt += __builtin_popcount(bw[k]);
+            for (unsigned dd = dirty; dd; dd &= dd - 1) cnt += __builtin_popcount(bw[__builtin_ctz(dd)]);
             int incl = cnt;
             for (int off = 1; off < 64; off <<= 1) {
                 const int v = __shfl_up(incl, off, 64);
@@ -232,20 +243,18 @@ __global__ __launch_bounds__(GQ_WAVES * 64) void grid_query_kernel(const float *
             int slot = incl - cnt;                              // exclusive prefix
             const int total = __builtin_amdgcn_readlane(incl, 63);
             int myfirst = 0;
-            if (cnt) {
-                for (int k = 0; k < WPL; ++k) {
-                    unsigned wd = bw[k];
-                    if (!wd) continue;
-                    bw[k] = 0u;                                 // leave the bitmap clean
-                    const int wbase = (lane * WPL + k) << 5;
-                    if (slot == 0 && !myfirst) myfirst = wbase + __builtin_ctz(wd);
-                    while (wd && slot < S) {
-                        const int bit = __builtin_ctz(wd);
-                        wd &= wd - 1;
-                        out[slot++] = wbase + bit;
-                    }
-                    slot += __builtin_popcount(wd);             // bits beyond nsample
+            for (unsigned dd = dirty; dd; dd &= dd - 1) {
+                const int k = __builtin_ctz(dd);
+                unsigned wd = bw[k];
+                bw[k] = 0u;                                     // leave the bitmap clean
+                const int wbase = (lane * WPL + k) << 5;
+                if (slot == 0 && !myfirst) myfirst = wbase + __builtin_ctz(wd);
+                while (wd && slot < S) {
+                    const int bit = __builtin_ctz(wd);
+                    wd &= wd - 1;
+                    out[slot++] = wbase + bit;
                 }
+                slot += __builtin_popcount(wd);                 // bits beyond nsample
             }
             // SPEC.md §3 padding: the remaining slots repeat the first (lowest) accepted index
             const unsigned long long has = __ballot(cnt != 0);
@@ -260,8 +269,10 @@ __global__ __launch_bounds__(GQ_WAVES * 64) void grid_query_kernel(const float *
 template <int NR>
 void launch_query(const float *new_xyz, const char *ws, const GQParams &prm, int B, int N, int M,
                   hipStream_t st) {
-    const int NW = (N + 31) >> 5, WPL = (NW + 63) >> 6;
-    const size_t lds = sizeof(unsigned) * (size_t)GQ_WAVES * NR * WPL * 64;
+    const int NW = (N + 31) >> 5;
+    int WPL = 1;
+    while (64 * WPL < NW) WPL <<= 1;
+    const size_t lds = sizeof(unsigned) * (size_t)GQ_WAVES * NR * (WPL * 64 + 64);
     dim3 grid((M + GQ_WAVES * GQ_CPW - 1) / (GQ_WAVES * GQ_CPW), B);
     hipLaunchKernelGGL((grid_query_kernel<NR>), grid, dim3(GQ_WAVES * 64), lds, st, new_xyz, ws, prm, N, M);
 }

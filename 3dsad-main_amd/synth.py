@@ -38,6 +38,17 @@ def make_batch(first_scene: int, batch: int, n_points: int = 16384, **kw) -> np.
     return np.stack([make_scene(first_scene + i, n_points, **kw) for i in range(batch)], 0)
 
 
+def make_nuscenes_batch(first_scene: int, batch: int, n_points: int = 65536) -> np.ndarray:
+    """BASELINE.json configs[4] input: float32 [batch, n_points, 7] — the KITTI recipe on
+    [-51.2, 51.2]^2 with 160 boxes, plus 3 more uniform channels (4 extra channels in all)."""
+    out = []
+    for i in range(batch):
+        base = make_scene(first_scene + i, n_points, extent=(-51.2, 51.2, -51.2, 51.2), n_boxes=160)
+        extra = np.random.default_rng(99991 + first_scene + i).uniform(0.0, 1.0, (n_points, 3)).astype(np.float32)
+        out.append(np.concatenate([base, extra], 1))
+    return np.ascontiguousarray(np.stack(out, 0))
+
+
 def make_tiny_batch(first_scene: int, batch: int, n_points: int = 2048) -> np.ndarray:
     """Small dense scenes for the TINY topology (20 m x 20 m, 6 boxes)."""
     return make_batch(first_scene, batch, n_points, extent=(0.0, 20.0, -10.0, 10.0), n_boxes=6)

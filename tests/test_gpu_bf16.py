@@ -125,7 +125,7 @@ def _stage_oracle(orc, xyz, feat, new_xyz, idxs, weights, name, agg):
     return cat, out
 
 
-@pytest.mark.parametrize("cfg_name,batch", [("TINY", 2), ("KITTI", 1)])
+@pytest.mark.parametrize("cfg_name,batch", [("TINY", 2), ("KITTI", 1), ("NUSCENES", 1)])
 def test_detector_bf16_stagewise(orc, sad, dev, cfg_name, batch):
     """The whole path with dtype="bf16", each stage checked against the §14 oracle fed with the
     GPU's own upstream tensors (teacher forcing: a bf16 rounding flip must not be allowed to move
@@ -136,7 +136,8 @@ def test_detector_bf16_stagewise(orc, sad, dev, cfg_name, batch):
     from sad_amd.detector import SADDetector
     cfg = getattr(config, cfg_name)
     w = synth.make_weights(cfg, 0)
-    pts = synth.make_tiny_batch(0, batch, cfg.n_points) if cfg_name == "TINY" else synth.make_batch(0, batch)
+    pts = {"TINY": lambda: synth.make_tiny_batch(0, batch, cfg.n_points), "KITTI": lambda: synth.make_batch(0, batch),
+           "NUSCENES": lambda: synth.make_nuscenes_batch(0, batch)}[cfg_name]()   # configs[4]: 65 536 points
     det = SADDetector(cfg, w, dev, dtype="bf16")
     tr = {}
     boxes = det(_t(pts, dev), tr)
