@@ -392,3 +392,58 @@ def test_ffps_degenerate_and_fused(orc, sad, dev):
     wide = torch.zeros(2, 600, 10, device=dev)
     wide[:, :, 2:8] = _t(feat, dev)
     np.testing.assert_array_equal(ops.ffps(_t(xyz, dev), wide[:, :, 2:8], 50).cpu().numpy(), orc.ffps(xyz, feat, 50))
+
+
+# ---------------------------------------------------------------- randomized sweeps
+def test_random_fps_all_kernels(orc, sad, dev):
+    """Random sizes across every kernel's range (plain scan < 2048, register cell buckets <= 16384,
+    sorted-record cell buckets <= 65536), clustered / duplicated / planar point sets."""
+    from sad_amd import ops
+    rng = np.random.default_rng(2024)
+    for trial in range(14):
+        N = int(rng.choice([rng.integers(2, 2048), rng.integers(2048, 16385), rng.integers(16385, 40000)]))
+        B = int(rng.integers(1, 3))
+        M = int(rng.integers(1, min(N, 600) + 1))
+        kind = trial % 4
+        xyz = rng.normal(size=(B, N, 3)).astype(np.float32)
+        if kind == 1:      # a few tight clusters: many near-ties
+            xyz = (rng.integers(0, 5, (B, N, 3)) * 10 + rng.normal(scale=1e-3, size=(B, N, 3))).astype(np.float32)
+        elif kind == 2:    # heavy duplication
+            xyz = xyz[:, rng.integers(0, max(2, N // 7), N)]
+        elif kind == 3:    # planar, coarse lattice: exact ties
+            xyz = np.round(xyz * 4) / 4
+            xyz[:, :, 2] = 1.0
+        xyz = np.ascontiguousarray(xyz, dtype=np.float32)
+        got = ops.fps(_t(xyz, dev), M).cpu().numpy()
+        np.testing.assert_array_equal(got, orc.fps(xyz, M), err_msg=f"trial {trial}: N={N} M={M} kind={kind}")
+
+
+def test_random_ball_query_all_kernels(orc, sad, dev):
+    """Random (N, M, radii, nsample) on both sides of the grid-kernel threshold, scalar and
+    per-centroid radii, 1-4 radii per call; indices and counts bit-exact."""
+    from sad_amd import ops
+    rng = np.random.default_rng(4048)
+    for trial in range(12):
+        N = int(rng.choice([rng.integers(10, 2048), rng.integers(2048, 9000)]))
+        B = int(rng.integers(1, 3))
+        M = int(rng.integers(1, 300))
+        nr = int(rng.integers(1, 5))
+        radii = sorted(float(r) for r in rng.uniform(0.03, 0.5, nr))
+        ns = [int(rng.integers(1, 65)) for _ in range(nr)]
+        xyz = rng.random((B, N, 3), dtype=np.float32)
+        if trial % 3 == 0:
+            xyz[:, N // 2:] = xyz[:, :N - N // 2]          # duplicates
+        new_xyz = np.ascontiguousarray(xyz[:, rng.integers(0, N, M)] + rng.normal(scale=0.01, size=(B, M, 3)).astype(np.float32))
+        pc = rng.uniform(0.5, 2.0, (B, M)).astype(np.float32) if trial % 2 else None
+        idxs, cnts = ops.ball_query_multi(radii, ns, _t(xyz, dev), _t(new_xyz, dev),
+                                          None if pc is None else _t(pc, dev), return_counts=True)
+        for r, s, gi, gc in zip(radii, ns, idxs, cnts):
+            rad = np.float32(r) if pc is None else (np.float32(r) * pc).astype(np.float32)
+            want = orc.ball_query(rad, s, xyz, new_xyz)
+            np.testing.assert_array_equal(gi.cpu().numpy(), want, err_msg=f"trial {trial}: N={N} r={r} S={s}")
+            # count = leading rows that are not padding; recompute from the oracle's definition
+            d2 = ((xyz[:, None, :, :] - new_xyz[:, :, None, :]) ** 2)
+            d2 = (d2[..., 0] + d2[..., 1]) + d2[..., 2]
+            r2 = (rad * rad) if np.ndim(rad) == 0 else (rad * rad)[..., None]
+            wc = np.minimum((d2 < r2).sum(-1), s)
+            np.testing.assert_array_equal(gc.cpu().numpy(), wc)
