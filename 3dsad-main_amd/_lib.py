@@ -111,6 +111,10 @@ def lib():
             raise RuntimeError(
                 f"{SO_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; "
                 "g.build()'` (hipcc, gfx950).  sad_amd has no CPU fallback.")
+        # torch first: it brings its own HIP runtime (libamdhip64), and libsad_amd.so must bind to
+        # THAT copy — loaded the other way round the process ends up with the system runtime under
+        # torch's allocator and device-to-device copies of torch memory fail
+        import torch  # noqa: F401
         handle = ctypes.CDLL(SO_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(handle, name)  # AttributeError here = header/library mismatch
