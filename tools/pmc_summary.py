@@ -19,3 +19,9 @@ for key, c, n in rows:
     print(f"{key[0]} grid={key[1]} lds={key[2]} dispatches={n}")
     for k in sorted(c):
         print(f"    {k:34s} {c[k]:.4g}")
+    if c.get("GRBM_GUI_ACTIVE") and c.get("SQ_VALU_MFMA_BUSY_CYCLES"):
+        # GRBM_GUI_ACTIVE is summed over the 8 XCDs; MFMA busy cycles over 256 CUs x 4 SIMDs
+        dur = c["GRBM_GUI_ACTIVE"] / 8.0
+        print(f"    {'derived: MFMA pipe busy fraction':34s} {c['SQ_VALU_MFMA_BUSY_CYCLES'] / (1024.0 * dur):.3f}")
+    if c.get("FETCH_SIZE") is not None and c.get("WRITE_SIZE") is not None:
+        print(f"    {'derived: HBM MB (2*FETCH + WRITE)':34s} {(2 * c['FETCH_SIZE'] + c['WRITE_SIZE']) / 1024.0:.1f}")
