@@ -23,7 +23,7 @@ from .sa_module import SAModuleMSG
 class SADDetector(nn.Module):
     def __init__(self, cfg: DetectorConfig, weights: dict, device, overlap_fps: bool = True,
                  n_fps_streams: int = 4, n_main_streams: int = 2, nested_fps_shortcut: bool = True,
-                 dtype: str = "f32"):
+                 dtype: str = "f32", query_on_sampling_stream: bool = True):
         """``dtype="bf16"``: every MLP runs on the bf16 matrix-core path (SPEC.md §14, BASELINE.json
         configs[4]); sampling, ball query and box decode are unchanged."""
         super().__init__()
@@ -55,6 +55,9 @@ class SADDetector(nn.Module):
         self._anchor = (ctypes.c_float * 3)(*cfg.anchor_car)
         self._anchors = (ctypes.c_float * 9)(*[v for a in cfg.anchors for v in a])
         self.overlap_fps = overlap_fps
+        # The SA ball queries need coordinates only: run them right behind the sampling chain, off the
+        # main stream (whose MLP kernels they then overlap); the adaptive cluster query stays on main.
+        self.query_on_sampling_stream = query_on_sampling_stream
         # FPS of an FPS-ordered point set is the identity prefix: stage s+1 samples the first M_{s+1}
         # centroids of stage s (proof in _sample_stage).  Only stage 1 runs the FPS kernel.
         self.nested_fps_shortcut = nested_fps_shortcut
@@ -150,26 +153,34 @@ class SADDetector(nn.Module):
                 ev_xyz.record(side)
                 cur = xyz
                 centroids = []
+                queries = []
                 for si in range(len(self.stages)):
+                    prev = cur
                     cur = self._sample_stage(si, cur)
                     centroids.append(cur)
+                    queries.append(self.stages[si].query(prev, cur) if self.query_on_sampling_stream else None)
                     ev = torch.cuda.Event()
                     ev.record(side)
                     evs.append(ev)
             points.record_stream(side)
             for t in centroids + [xyz]:
                 t.record_stream(main)
+            for q in queries:
+                if q is not None:
+                    for t in q[0] + q[1]:
+                        t.record_stream(main)
             main.wait_event(ev_xyz)
         else:
             xyz = points[:, :, :3].contiguous()
             centroids = self._sample_chain(xyz)
             evs = [None] * len(centroids)
+            queries = [None] * len(centroids)
         cur_xyz, cur_feat = xyz, feat
         for si, m in enumerate(self.stages):
             if evs[si] is not None:
                 main.wait_event(evs[si])
             new_xyz = centroids[si]
-            cur_feat = m.group_and_pool(cur_xyz, cur_feat, new_xyz,
+            cur_feat = m.group_and_pool(cur_xyz, cur_feat, new_xyz, query=queries[si],
                                         keep=None if trace is None else trace.setdefault(f"sa{si + 1}", {}))
             if trace is not None:
                 trace[f"sa{si + 1}"].update(new_xyz=new_xyz, out=cur_feat)

@@ -56,15 +56,23 @@ class SAModuleMSG(nn.Module):
         fidx = ops.fps(xyz, self.stage.npoint)
         return fidx, ops.gather_xyz(xyz, fidx)
 
+    def query(self, xyz: torch.Tensor, new_xyz: torch.Tensor, radius_pc: Optional[torch.Tensor] = None,
+              radii: Optional[Sequence[float]] = None):
+        """The stage's multi-radius ball query: ([idx_b [B,M,S_b]], [cnt_b [B,M]])."""
+        st = self.stage
+        return ops.ball_query_multi(radii if radii is not None else st.radii, st.nsamples, xyz, new_xyz,
+                                    radius_pc, return_counts=True)
+
     def group_and_pool(self, xyz: torch.Tensor, feat_pm: Optional[torch.Tensor],
                        new_xyz: torch.Tensor, radius_pc: Optional[torch.Tensor] = None,
-                       radii: Optional[Sequence[float]] = None, keep: Optional[dict] = None
-                       ) -> torch.Tensor:
-        """ball query + fused MLP/max for every branch + aggregation -> [B,M,C'] point-major."""
+                       radii: Optional[Sequence[float]] = None, keep: Optional[dict] = None,
+                       query=None) -> torch.Tensor:
+        """ball query + fused MLP/max for every branch + aggregation -> [B,M,C'] point-major.
+        ``query`` = (idxs, cnts) from an earlier ``self.query(...)`` (the ball query needs coordinates
+        only, so a caller may run it ahead on another stream)."""
         st = self.stage
         B, M = new_xyz.shape[0], new_xyz.shape[1]
-        idxs, cnts = ops.ball_query_multi(radii if radii is not None else st.radii, st.nsamples, xyz,
-                                          new_xyz, radius_pc, return_counts=True)
+        idxs, cnts = query if query is not None else self.query(xyz, new_xyz, radius_pc, radii)
         if keep is not None:
             keep["ball_idx"] = idxs
         cat = torch.zeros((B, M, self.cat_channels), dtype=torch.float32, device=xyz.device)
