@@ -149,6 +149,16 @@ class SADDetector(nn.Module):
             evs = []
             with torch.cuda.stream(side):
                 xyz = points[:, :, :3].contiguous()
+                # the zero-initialised pooling buffers of every stage: one fill, covered by ev_xyz
+                shapes = [(B, m.stage.npoint, m.cat_channels) for m in self.stages]
+                shapes.append((B, cfg.n_cand, self.cluster_cat))
+                zeros = torch.zeros((sum(a * b_ * c_ for a, b_, c_ in shapes),), dtype=torch.float32,
+                                    device=points.device)
+                cats, o = [], 0
+                for shp in shapes:
+                    n_el = shp[0] * shp[1] * shp[2]
+                    cats.append(zeros[o:o + n_el].view(shp))
+                    o += n_el
                 ev_xyz = torch.cuda.Event()
                 ev_xyz.record(side)
                 cur = xyz
@@ -169,18 +179,20 @@ class SADDetector(nn.Module):
                 if q is not None:
                     for t in q[0] + q[1]:
                         t.record_stream(main)
+            zeros.record_stream(main)
             main.wait_event(ev_xyz)
         else:
             xyz = points[:, :, :3].contiguous()
             centroids = self._sample_chain(xyz)
             evs = [None] * len(centroids)
             queries = [None] * len(centroids)
+            cats = [None] * (len(centroids) + 1)
         cur_xyz, cur_feat = xyz, feat
         for si, m in enumerate(self.stages):
             if evs[si] is not None:
                 main.wait_event(evs[si])
             new_xyz = centroids[si]
-            cur_feat = m.group_and_pool(cur_xyz, cur_feat, new_xyz, query=queries[si],
+            cur_feat = m.group_and_pool(cur_xyz, cur_feat, new_xyz, query=queries[si], cat=cats[si],
                                         keep=None if trace is None else trace.setdefault(f"sa{si + 1}", {}))
             if trace is not None:
                 trace[f"sa{si + 1}"].update(new_xyz=new_xyz, out=cur_feat)
@@ -196,7 +208,9 @@ class SADDetector(nn.Module):
                                        rad.data_ptr(), main.cuda_stream), "sad_candidates_f32")
         idxs, cnts = ops.ball_query_multi(cfg.cluster_scales, cfg.cluster_nsamples, cur_xyz, cand, rad,
                                           return_counts=True)
-        cat = torch.zeros((B, K, self.cluster_cat), dtype=torch.float32, device=points.device)
+        cat = cats[-1]
+        if cat is None:
+            cat = torch.zeros((B, K, self.cluster_cat), dtype=torch.float32, device=points.device)
         jobs, off = [], 0
         for mlp, idx, cnt in zip(self.cluster_branches, idxs, cnts):
             jobs.append(lambda mlp=mlp, idx=idx, cnt=cnt, off=off:

@@ -66,7 +66,7 @@ class SAModuleMSG(nn.Module):
     def group_and_pool(self, xyz: torch.Tensor, feat_pm: Optional[torch.Tensor],
                        new_xyz: torch.Tensor, radius_pc: Optional[torch.Tensor] = None,
                        radii: Optional[Sequence[float]] = None, keep: Optional[dict] = None,
-                       query=None) -> torch.Tensor:
+                       query=None, cat: Optional[torch.Tensor] = None) -> torch.Tensor:
         """ball query + fused MLP/max for every branch + aggregation -> [B,M,C'] point-major.
         ``query`` = (idxs, cnts) from an earlier ``self.query(...)`` (the ball query needs coordinates
         only, so a caller may run it ahead on another stream)."""
@@ -75,7 +75,8 @@ class SAModuleMSG(nn.Module):
         idxs, cnts = query if query is not None else self.query(xyz, new_xyz, radius_pc, radii)
         if keep is not None:
             keep["ball_idx"] = idxs
-        cat = torch.zeros((B, M, self.cat_channels), dtype=torch.float32, device=xyz.device)
+        if cat is None:      # ``cat``: a caller-provided ZERO [B,M,sum C_b] float32 buffer
+            cat = torch.zeros((B, M, self.cat_channels), dtype=torch.float32, device=xyz.device)
         jobs, off = [], 0
         for mlp, idx, cnt in zip(self.branches, idxs, cnts):
             jobs.append(lambda mlp=mlp, idx=idx, cnt=cnt, off=off:
