@@ -521,6 +521,7 @@ SAD_API int sad_mlp_chain_bf16(const sad_mlp_bf16_args *a, sad_stream_t stream) 
         p.rows = (long long)a->B * a->M;
     }
     SAD_REQUIRE(a->C == 0 || a->feat, "sad_mlp_chain_bf16: NULL feat");
+    SAD_REQUIRE(p.rows < (1LL << 31), "sad_mlp_chain_bf16: %lld rows (the row maps are 32-bit)", p.rows);
     if (a->feat && (a->C & 7) == 0 && (a->ld_feat & 7) == 0)
         SAD_REQUIRE((uintptr_t)a->feat % 16 == 0, "sad_mlp_chain_bf16: feat must be 16-byte aligned");
     p.xyz = a->xyz; p.new_xyz = a->new_xyz; p.idx = a->idx;
