@@ -294,7 +294,8 @@ void launch_reg(const float *xyz, int B, int N, int M, int *idx, hipStream_t st,
 SAD_API size_t sad_fps_workspace_bytes(int B, int N) {
     if (B <= 0 || N < 2048) return 0;
     size_t n = (size_t)B * (size_t)N * sizeof(float);
-    if (N > 16384 && N <= 65536) n = ((n + 15) & ~(size_t)15) + (size_t)B * 65536 * 16;   // + sorted float4 records
+    // + sorted float4 records (used above 16384 points, or for any N with fps_variant = 5)
+    if (N <= 65536) n = ((n + 15) & ~(size_t)15) + (size_t)B * 65536 * 16;
     return n;
 }
 
@@ -306,7 +307,7 @@ SAD_API int sad_fps_f32(const float *xyz, int B, int N, int M, int32_t *idx, voi
     hipStream_t st = (hipStream_t)stream;
     const bool dpp = sad::get_option(sad::OPT_FPS_DPP) != 0;
     const int variant0 = sad::get_option(sad::OPT_FPS_VARIANT);
-    if (N > 16384 && N <= 65536 && workspace && (variant0 == 0 || variant0 >= 3)) {
+    if (((N > 16384 && (variant0 == 0 || variant0 >= 3)) || (variant0 == 5 && N >= 2048)) && N <= 65536 && workspace) {
         SAD_REQUIRE((uintptr_t)workspace % 16 == 0, "sad_fps_f32: workspace must be 16-byte aligned");
         return sad::launch_fps_cellg(xyz, B, N, M, idx, workspace, st);
     }
@@ -315,7 +316,7 @@ SAD_API int sad_fps_f32(const float *xyz, int B, int N, int M, int32_t *idx, voi
         hipLaunchKernelGGL(fps_big_kernel, dim3(B), dim3(1024), 0, st, xyz, N, M, (float *)workspace, idx);
         return sad::check_launch("sad_fps_f32");
     }
-    const int variant = sad::get_option(sad::OPT_FPS_VARIANT);   // 0 auto (cell buckets), 1 pair, 2 key, 3 wave buckets, 4 cell buckets
+    const int variant = sad::get_option(sad::OPT_FPS_VARIANT);   // 0 auto (cell buckets), 1 pair, 2 key, 3 wave buckets, 4 cell buckets, 5 cell buckets over sorted records for any N >= 2048
     if (workspace && N >= 2048 && (variant == 0 || variant >= 3))
         return sad::launch_fps_bucket(xyz, B, N, M, idx, workspace, st);
     if (N <= 2048) {

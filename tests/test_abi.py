@@ -52,7 +52,7 @@ def test_host_side_argument_errors(sad):
     assert L.sad_group_points(p, p, 1, 1, 8, 2, 2, 3, p, None) == -1  # elem_size 3
     assert L.sad_set_option(b"no_such_option", 1) == -1
     assert L.sad_fps_workspace_bytes(2, 1024) == 0
-    assert L.sad_fps_workspace_bytes(2, 16384) == 2 * 16384 * 4   # Z-order permutation (bucketed kernel)
+    assert L.sad_fps_workspace_bytes(2, 16384) == 2 * 16384 * 4 + 2 * 65536 * 16   # Z-order permutation + sorted records
     assert L.sad_fps_workspace_bytes(2, 65536) == 2 * 65536 * 4 + 2 * 65536 * 16   # permutation + sorted float4 records
     assert L.sad_fps_workspace_bytes(2, 100000) == 2 * 100000 * 4             # plain min-distance workspace
     assert L.sad_ffps_workspace_bytes(2, 1000) == 2 * 1000 * 1000 * 4
