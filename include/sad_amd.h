@@ -41,7 +41,14 @@ typedef void *sad_stream_t; /* hipStream_t */
 
 int sad_version(void);
 const char *sad_last_error(void);
-/* Tuning knobs for A/B measurements ("fps_dpp" 0/1, "mlp_rw" 0/1/2/4 (0 = auto)); returns SAD_EINVAL for an unknown key. */
+/* Tuning / A-B knobs (process-wide; defaults 0 = automatic).  Returns SAD_EINVAL for an unknown key.
+ *   fps_variant  1 pair kernel, 2 key kernel, 3 wave buckets, 4 cell buckets, 5 cell buckets over sorted records
+ *   fps_threads  cell-bucket geometry waves*100 + slots (e.g. 1616, 832); old kernels: 1024/512/256 threads
+ *   fps_dpp      1 = DPP reductions in the pair kernel
+ *   bq_variant   reserved (grid vs scan is the caller's choice: sad_ball_query_grid_f32 / sad_ball_query_multi_f32)
+ *   group_variant 1 = L2-gather group_points kernel only (no LDS staging)
+ *   mlp_rw, mlp_budget_kb, mlp_force, mlp_dedup_f, mlp_nodedup, mlp_static: f32 chain geometry overrides
+ *                (see sad_mlp_args.geometry; mlp_nodedup = 1 computes the padding rows too) */
 int sad_set_option(const char *key, int value);
 
 /* SPEC.md §2.  xyz[B,N,3] -> idx[B,M].  N < 2048 needs no workspace; otherwise pass
