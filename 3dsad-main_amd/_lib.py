@@ -81,6 +81,7 @@ SIGNATURES = {
                                        ctypes.POINTER(vp), ctypes.POINTER(vp), vp, vp]),
     "sad_mlp_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     "sad_mlp_chain_f32": (ctypes.c_int, [ctypes.POINTER(MlpArgs), vp]),
+    "sad_mlp_chain_multi_f32": (ctypes.c_int, [ctypes.POINTER(ctypes.POINTER(MlpArgs)), ctypes.c_int, vp]),
     "sad_mlp_packed_bytes_bf16": (ctypes.c_size_t, [ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.c_int]),
     "sad_mlp_pack_bf16": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.c_int,
                                         ctypes.POINTER(vp), ctypes.POINTER(vp), vp, vp]),

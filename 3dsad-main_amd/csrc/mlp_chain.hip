@@ -305,7 +305,7 @@ __device__ __forceinline__ void atomic_max_pos(float *addr, float v) {
 }
 
 template <int W, int RW>
-__global__ __launch_bounds__(W * 64) void mlp_chain_kernel(const MlpParams p) {
+__device__ __forceinline__ void mlp_chain_body(const MlpParams &p, const int block) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -339,13 +339,13 @@ __global__ __launch_bounds__(W * 64) void mlp_chain_kernel(const MlpParams p) {
     // first index (ball-query padding, SPEC.md §3) are dropped: a duplicate row cannot change the
     // max-pool, so only the leading `cnt` rows of each group are computed.  The surviving rows of the
     // G groups are numbered consecutively ("compact rows") and processed R at a time.
-    long long r0 = (long long)blockIdx.x * R;
+    long long r0 = (long long)block * R;
     long long g0 = 0;
     int T = R, npass = 1, G = p.G;
     const bool dyn = p.grouped && p.rowtab != nullptr;       // global packing + dynamic pass hand-out
     int &s_pass = s_off[p.s_off_entries];   // one int past the offsets (all LDS lives in the dynamic region)
     if (p.grouped && !dyn) {
-        g0 = (long long)blockIdx.x * p.G;
+        g0 = (long long)block * p.G;
         long long left = p.total_groups - g0;
         const int ng = (int)(left < p.G ? left : p.G);
         if (p.cnt) {                                        // counts come from the ball query
@@ -610,6 +610,35 @@ __global__ __launch_bounds__(W * 64) void mlp_chain_kernel(const MlpParams p) {
             __syncthreads();
         }
     }
+}
+
+template <int W, int RW>
+__global__ __launch_bounds__(W * 64) void mlp_chain_kernel(const MlpParams p) {
+    mlp_chain_body<W, RW>(p, blockIdx.x);
+}
+
+// Several independent chains (the branches of one multi-radius stage) in ONE dispatch: the
+// workgroups of the chains are laid out one after the other (heaviest first), so the light chains
+// fill the tail of the heavy one and the launch gaps between them disappear.  All chains share the
+// wave count W; the row blocking RW is a per-chain runtime switch (RWMAX bounds the register budget).
+constexpr int MULTI_MAX = 4;
+struct MultiParams {
+    MlpParams p[MULTI_MAX];
+    int first[MULTI_MAX + 1];   // first block of chain i; first[n] = grid size
+    int rw[MULTI_MAX];
+    int n;
+};
+
+template <int W, int RWMAX>
+__global__ __launch_bounds__(W * 64) void mlp_multi_kernel(const MultiParams mp) {
+    int c = 0;
+    while (c + 1 < mp.n && (int)blockIdx.x >= mp.first[c + 1]) ++c;
+    c = __builtin_amdgcn_readfirstlane(c);
+    const int block = blockIdx.x - mp.first[c];
+    const int rw = mp.rw[c];
+    if (rw == 1) mlp_chain_body<W, 1>(mp.p[c], block);
+    else if (RWMAX >= 2 && rw == 2) mlp_chain_body<W, (RWMAX >= 2 ? 2 : 1)>(mp.p[c], block);
+    else if (RWMAX >= 4 && rw == 4) mlp_chain_body<W, (RWMAX >= 4 ? 4 : 1)>(mp.p[c], block);
 }
 
 // ---- narrow chains on the vector ALU: one (b, m, s) row per lane ------------------------------
@@ -900,7 +929,20 @@ SAD_API size_t sad_mlp_workspace_bytes(int B, int M, int S) {
     return sizeof(int) * (4 + (ng + 1) + (ng * S / 32 + 2) + (ng / 1024 + 2)) + 64;
 }
 
-SAD_API int sad_mlp_chain_f32(const sad_mlp_args *a, sad_stream_t stream) {
+namespace {
+struct Prepared {
+    MlpParams p;
+    size_t lds;
+    long long nblocks;
+    int W, RW;
+    bool launched;      // the VALU kernel was launched instead (nothing left to do)
+};
+int launch_prepared(const Prepared &q, hipStream_t st);
+}  // namespace
+
+// Validation, geometry choice and the row-packing scan of one chain; fills `q` for the launch.
+static int prepare_chain(const sad_mlp_args *a, sad_stream_t stream, Prepared &q) {
+    q.launched = false;
     SAD_REQUIRE(a, "sad_mlp_chain_f32: NULL args");
     if (int e = check_dims("sad_mlp_chain_f32", a->L, a->dims)) return e;
     const bool grouped = a->idx != nullptr;
@@ -979,6 +1021,7 @@ SAD_API int sad_mlp_chain_f32(const sad_mlp_args *a, sad_stream_t stream) {
                 hipLaunchKernelGGL((mlp_valu_kernel<4, 16, 16, 32>), dim3((unsigned)nb), dim3(VALU_T), 0, (hipStream_t)stream, v);
             else
                 hipLaunchKernelGGL((mlp_valu_kernel<4, 32, 32, 64>), dim3((unsigned)nb), dim3(VALU_T), 0, (hipStream_t)stream, v);
+            q.launched = true;
             return sad::check_launch("sad_mlp_chain_f32 (valu)");
         }
     }
@@ -1085,18 +1128,104 @@ SAD_API int sad_mlp_chain_f32(const sad_mlp_args *a, sad_stream_t stream) {
     }
     const long long nblocks = grid_dyn ? grid_dyn : (grouped ? (p.total_groups + p.G - 1) / p.G : (p.total_rows + R - 1) / R);
     SAD_REQUIRE(nblocks < (1LL << 31), "sad_mlp_chain_f32: too many workgroups");
-    hipStream_t st = (hipStream_t)stream;
-    if (W == 16) {
-        if (RW == 1) return launch_mlp<16, 1>(p, lds, nblocks, st);
-        if (RW == 2) return launch_mlp<16, 2>(p, lds, nblocks, st);
-        return sad::fail(SAD_EUNSUPPORTED, "sad_mlp_chain_f32: 16 waves support RW 1 or 2");
+    if (W == 16 && RW == 4) return sad::fail(SAD_EUNSUPPORTED, "sad_mlp_chain_f32: 16 waves support RW 1 or 2");
+    q.p = p; q.lds = lds; q.nblocks = nblocks; q.W = W; q.RW = RW;
+    return SAD_OK;
+}
+
+namespace {
+int launch_prepared(const Prepared &q, hipStream_t st) {
+    const MlpParams &p = q.p;
+    const size_t lds = q.lds;
+    const long long nblocks = q.nblocks;
+    if (q.W == 16) {
+        if (q.RW == 1) return launch_mlp<16, 1>(p, lds, nblocks, st);
+        return launch_mlp<16, 2>(p, lds, nblocks, st);
     }
-    if (W == 8) {
-        if (RW == 1) return launch_mlp<8, 1>(p, lds, nblocks, st);
-        if (RW == 2) return launch_mlp<8, 2>(p, lds, nblocks, st);
+    if (q.W == 8) {
+        if (q.RW == 1) return launch_mlp<8, 1>(p, lds, nblocks, st);
+        if (q.RW == 2) return launch_mlp<8, 2>(p, lds, nblocks, st);
         return launch_mlp<8, 4>(p, lds, nblocks, st);
     }
-    if (RW == 1) return launch_mlp<4, 1>(p, lds, nblocks, st);
-    if (RW == 2) return launch_mlp<4, 2>(p, lds, nblocks, st);
+    if (q.RW == 1) return launch_mlp<4, 1>(p, lds, nblocks, st);
+    if (q.RW == 2) return launch_mlp<4, 2>(p, lds, nblocks, st);
     return launch_mlp<4, 4>(p, lds, nblocks, st);
+}
+
+template <int W, int RWMAX>
+int launch_multi(const MultiParams &mp, size_t lds, hipStream_t st) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&mlp_multi_kernel<W, RWMAX>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            (void)hipGetLastError();
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((mlp_multi_kernel<W, RWMAX>), dim3((unsigned)mp.first[mp.n]), dim3(W * 64), lds, st, mp);
+    return sad::check_launch("sad_mlp_chain_multi_f32");
+}
+}  // namespace
+
+SAD_API int sad_mlp_chain_f32(const sad_mlp_args *a, sad_stream_t stream) {
+    Prepared q;
+    if (int e = prepare_chain(a, stream, q)) return e;
+    if (q.launched) return SAD_OK;
+    return launch_prepared(q, (hipStream_t)stream);
+}
+
+SAD_API int sad_mlp_chain_multi_f32(const sad_mlp_args *const *args, int n, sad_stream_t stream) {
+    SAD_REQUIRE(args && n >= 1, "sad_mlp_chain_multi_f32: need at least one chain");
+    hipStream_t st = (hipStream_t)stream;
+    if (n > MULTI_MAX) {                       // more chains than one dispatch carries: in groups
+        for (int i = 0; i < n; i += MULTI_MAX)
+            if (int e = sad_mlp_chain_multi_f32(args + i, n - i < MULTI_MAX ? n - i : MULTI_MAX, stream)) return e;
+        return SAD_OK;
+    }
+    Prepared q[MULTI_MAX];
+    for (int i = 0; i < n; ++i)
+        if (int e = prepare_chain(args[i], stream, q[i])) return e;
+    // one dispatch needs a common wave count and nothing already launched; otherwise one by one
+    bool merge = n > 1;
+    for (int i = 0; i < n; ++i) merge = merge && !q[i].launched && q[i].W == q[0].W && q[i].W != 16;
+    if (!merge) {
+        for (int i = 0; i < n; ++i)
+            if (!q[i].launched)
+                if (int e = launch_prepared(q[i], st)) return e;
+        return SAD_OK;
+    }
+    // heaviest chain first (its workgroups start first, the light chains fill its tail)
+    int order[MULTI_MAX];
+    for (int i = 0; i < n; ++i) order[i] = i;
+    auto weight = [&](int i) {
+        double m = 0;
+        for (int l = 0; l < q[i].p.L; ++l) m += (double)q[i].p.kp[l] * q[i].p.np[l];
+        return m * (double)q[i].p.total_rows;
+    };
+    for (int i = 0; i < n; ++i)
+        for (int k = i + 1; k < n; ++k)
+            if (weight(order[k]) > weight(order[i])) { const int t = order[i]; order[i] = order[k]; order[k] = t; }
+    MultiParams mp{};
+    mp.n = n;
+    size_t lds = 0;
+    long long total = 0;
+    int rwmax = 1;
+    for (int i = 0; i < n; ++i) {
+        const Prepared &s = q[order[i]];
+        mp.p[i] = s.p;
+        mp.rw[i] = s.RW;
+        mp.first[i] = (int)total;
+        total += s.nblocks;
+        lds = s.lds > lds ? s.lds : lds;
+        rwmax = s.RW > rwmax ? s.RW : rwmax;
+    }
+    SAD_REQUIRE(total < (1LL << 31), "sad_mlp_chain_multi_f32: too many workgroups");
+    mp.first[n] = (int)total;
+    if (q[0].W == 8) {
+        if (rwmax == 1) return launch_multi<8, 1>(mp, lds, st);
+        if (rwmax == 2) return launch_multi<8, 2>(mp, lds, st);
+        return launch_multi<8, 4>(mp, lds, st);
+    }
+    if (rwmax == 1) return launch_multi<4, 1>(mp, lds, st);
+    if (rwmax == 2) return launch_multi<4, 2>(mp, lds, st);
+    return launch_multi<4, 4>(mp, lds, st);
 }

@@ -377,6 +377,12 @@ class PackedMLP:
         point-major [B,M,ld_out] buffer (allocated [B,M,C_out] when ``out`` is None).  A caller-
         provided ``out`` slice must be ZERO on entry (groups spanning two row tiles are combined
         with an atomic max).  Samples that repeat a group's first index are skipped."""
+        a, out, _keep = self._grouped_args(xyz, feat_pm, new_xyz, idx, out, col_off, cnt)
+        self._launch(a)
+        return out
+
+    def _grouped_args(self, xyz, feat_pm, new_xyz, idx, out, col_off, cnt):
+        """Validated ``MlpArgs`` of a grouped call + the output tensor + tensors to keep alive."""
         if not self.first_has_xyz:
             raise RuntimeError("this PackedMLP was packed without the xyz prefix")
         xyz = _need(xyz, "xyz", torch.float32, 3)
@@ -385,6 +391,7 @@ class PackedMLP:
         B, N, _ = xyz.shape
         _, M, S = idx.shape
         a = self._args()
+        keep = [xyz, new_xyz, idx]
         if feat_pm is None:
             C = 0
         else:
@@ -395,6 +402,7 @@ class PackedMLP:
             C = feat_pm.shape[2]
             a.feat = feat_pm.data_ptr()
             a.ld_feat = feat_pm.stride(1)
+            keep.append(feat_pm)
         if self.dims[0] != C + 3:
             raise ValueError(f"MLP expects {self.dims[0] - 3} feature channels, got {C}")
         if out is None:   # the kernel max-combines into the buffer: it must start at zero
@@ -410,10 +418,11 @@ class PackedMLP:
             a.cnt = cnt.data_ptr()
             ws = torch.empty((lib().sad_mlp_workspace_bytes(B, M, S),), dtype=torch.uint8, device=xyz.device)
             a.workspace = ws.data_ptr()   # global row packing + dynamic pass hand-out
+            keep += [cnt, ws]
         a.B, a.N, a.M, a.S, a.C = B, N, M, S, C
         a.out, a.ld_out, a.col_off = out.data_ptr(), out.stride(-2), col_off
-        self._launch(a)
-        return out
+        a.geometry = self._geom.get((bool(a.idx), a.B, a.N, a.M, a.S, a.ld_out)) or 0
+        return a, out, keep
 
     def rows(self, x: torch.Tensor, out: Optional[torch.Tensor] = None, col_off: int = 0
              ) -> torch.Tensor:
@@ -447,6 +456,26 @@ class PackedMLP:
             raise ValueError("out: expected a contiguous [rows, ld_out] buffer")
         if col_off < 0 or col_off + self.out_channels > out.shape[-1]:
             raise ValueError("out: col_off + C_out exceeds the buffer width")
+
+
+def grouped_multi(calls) -> None:
+    """Several independent fused group -> MLP -> max launches (the branches of one multi-radius
+    stage) as ONE dispatch (``sad_mlp_chain_multi_f32``): the light chains fill the tail of the
+    heavy one.  ``calls`` = [(PackedMLP, xyz, feat_pm, new_xyz, idx, out, col_off, cnt), ...] with
+    caller-provided zero ``out`` buffers.  While autotuning, or for a single call, each chain is
+    launched (and tuned) on its own."""
+    if AUTOTUNE or len(calls) < 2:
+        for mlp, xyz, feat_pm, new_xyz, idx, out, col_off, cnt in calls:
+            mlp.grouped(xyz, feat_pm, new_xyz, idx, out=out, col_off=col_off, cnt=cnt)
+        return
+    args, keep = [], []
+    for mlp, xyz, feat_pm, new_xyz, idx, out, col_off, cnt in calls:
+        a, _, k = mlp._grouped_args(xyz, feat_pm, new_xyz, idx, out, col_off, cnt)
+        args.append(a)
+        keep.append(k)
+    arr = (ctypes.POINTER(MlpArgs) * len(args))(*[ctypes.pointer(a) for a in args])
+    with _timed("mlp", "+".join(c[0].name for c in calls)):
+        check(lib().sad_mlp_chain_multi_f32(arr, len(args), _stream()), "sad_mlp_chain_multi_f32")
 
 
 class PackedMLPBf16:

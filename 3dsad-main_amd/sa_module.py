@@ -77,12 +77,17 @@ class SAModuleMSG(nn.Module):
             keep["ball_idx"] = idxs
         if cat is None:      # ``cat``: a caller-provided ZERO [B,M,sum C_b] float32 buffer
             cat = torch.zeros((B, M, self.cat_channels), dtype=torch.float32, device=xyz.device)
-        jobs, off = [], 0
-        for mlp, idx, cnt in zip(self.branches, idxs, cnts):
-            jobs.append(lambda mlp=mlp, idx=idx, cnt=cnt, off=off:
-                        mlp.grouped(xyz, feat_pm, new_xyz, idx, out=cat, col_off=off, cnt=cnt))
-            off += mlp.out_channels
-        ops.run_branches(jobs)       # independent branches share the chip
+        off = 0
+        if self.dtype == "f32":      # all branches in one dispatch (ops.grouped_multi)
+            calls = []
+            for mlp, idx, cnt in zip(self.branches, idxs, cnts):
+                calls.append((mlp, xyz, feat_pm, new_xyz, idx, cat, off, cnt))
+                off += mlp.out_channels
+            ops.grouped_multi(calls)
+        else:
+            for mlp, idx, cnt in zip(self.branches, idxs, cnts):
+                mlp.grouped(xyz, feat_pm, new_xyz, idx, out=cat, col_off=off, cnt=cnt)
+                off += mlp.out_channels
         if self.agg is None:
             return cat
         if self.dtype == "bf16":     # a stage output that feeds another stage is stored as bf16 (SPEC §14)

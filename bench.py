@@ -326,10 +326,12 @@ def main():
                          "frac": round(g_bytes / (g_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4),
                          "algorithmic_bytes": g_bytes})
             res["kernels"] = kern
-            res["mlp_launches"] = {n: {"ms": round(v / tsteps, 3), "executed_gflop": round(per_flops.get(n, 0) / 1e9, 1),
-                                       "tflops": round(per_flops.get(n, 0) / (v / tsteps * 1e-3) / 1e12, 1),
+            def fl(n):      # a merged dispatch is named "a+b+c"
+                return sum(per_flops.get(x, 0) for x in n.split("+"))
+            res["mlp_launches"] = {n: {"ms": round(v / tsteps, 3), "executed_gflop": round(fl(n) / 1e9, 1),
+                                       "tflops": round(fl(n) / (v / tsteps * 1e-3) / 1e12, 1),
                                        "ms_single_stream": round(iso_name.get(n, 0.0), 3),
-                                       "tflops_single_stream": round(per_flops.get(n, 0) / (iso_name[n] * 1e-3) / 1e12, 1) if iso_name.get(n) else None}
+                                       "tflops_single_stream": round(fl(n) / (iso_name[n] * 1e-3) / 1e12, 1) if iso_name.get(n) else None}
                                    for (k, n), v in sorted(per_name.items()) if k == "mlp"}
         if not args.no_cpu and world == 1:
             res["cpu_baseline"] = cpu_baseline(cfg, weights, args.cpu_scenes)

@@ -173,6 +173,10 @@ typedef struct sad_mlp_args {
 } sad_mlp_args;
 size_t sad_mlp_workspace_bytes(int B, int M, int S);
 int sad_mlp_chain_f32(const sad_mlp_args *args, sad_stream_t stream);
+/* n independent chains (typically the branches of one multi-radius stage, each writing its own
+ * column slice) in one dispatch when they share a wave count: the light chains fill the tail of the
+ * heavy one and the launch gaps disappear.  Same results as n sad_mlp_chain_f32 calls. */
+int sad_mlp_chain_multi_f32(const sad_mlp_args *const *args, int n, sad_stream_t stream);
 
 /* SPEC.md §14 — the same chain in bfloat16 on the matrix cores (BASELINE.json configs[4]).
  * Weights are rounded to bf16 and laid out in MFMA fragment order by sad_mlp_pack_bf16 (W/bias as

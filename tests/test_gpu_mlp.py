@@ -323,3 +323,29 @@ def test_nuscenes_scale_sa_module(orc, sad, dev):
     onx, onf = orc.sa_module(xyz, feat, st, ow, "s")
     np.testing.assert_array_equal(nx.cpu().numpy(), onx)
     _close(nf.cpu().numpy(), onf, "65536-point SA stage")
+
+
+def test_multi_chain_dispatch_matches_single_launches(orc, sad, dev):
+    """sad_mlp_chain_multi_f32 (the branches of a stage in one dispatch) writes the same bits as one
+    launch per branch, including branches with different row blocking and a mixed-width stage."""
+    import torch
+    from sad_amd import ops, synth
+    rng = np.random.default_rng(99)
+    B, N, M, C = 2, 3000, 300, 16
+    xyz = rng.random((B, N, 3), dtype=np.float32)
+    feat = rng.normal(size=(B, N, C)).astype(np.float32)
+    new_xyz = np.ascontiguousarray(xyz[:, :M])
+    radii, ns = [0.05, 0.1, 0.2], [16, 32, 64]
+    mlps = [[32, 32, 64], [64, 64, 128], [64, 96, 128]]
+    idxs, cnts = ops.ball_query_multi(radii, ns, _t(xyz, dev), _t(new_xyz, dev), return_counts=True)
+    nets = [ops.PackedMLP(synth.make_mlp_weights([C + 3] + m, rng), True, dev, name=f"t.b{i}") for i, m in enumerate(mlps)]
+    width = sum(m[-1] for m in mlps)
+    single = torch.zeros(B, M, width, device=dev)
+    merged = torch.zeros(B, M, width, device=dev)
+    calls, off = [], 0
+    for net, idx, cnt in zip(nets, idxs, cnts):
+        net.grouped(_t(xyz, dev), _t(feat, dev), _t(new_xyz, dev), idx, out=single, col_off=off, cnt=cnt)
+        calls.append((net, _t(xyz, dev), _t(feat, dev), _t(new_xyz, dev), idx, merged, off, cnt))
+        off += net.out_channels
+    ops.grouped_multi(calls)
+    assert torch.equal(single, merged)
