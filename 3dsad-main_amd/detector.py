@@ -52,6 +52,13 @@ class SADDetector(nn.Module):
                                          name="cluster.agg")
         self.head = mlp_cls(weights["head"], False, self.device,
                                   relu_mask=(1 << (len(weights["head"]) - 1)) - 1, name="head")
+        # aggregation + head as ONE chain (same fmaf chains, activations stay in LDS, one launch and
+        # no HBM round trip of the cluster features); used when no trace is requested
+        n_fused = len(weights["cluster.agg"]) + len(weights["head"])
+        self.agg_head = None
+        if dtype == "f32" and n_fused <= 4:
+            self.agg_head = ops.PackedMLP(list(weights["cluster.agg"]) + list(weights["head"]), False, self.device,
+                                          relu_mask=(1 << (n_fused - 1)) - 1, name="cluster.agg+head")
         self._anchor = (ctypes.c_float * 3)(*cfg.anchor_car)
         self._anchors = (ctypes.c_float * 9)(*[v for a in cfg.anchors for v in a])
         self.overlap_fps = overlap_fps
@@ -100,6 +107,8 @@ class SADDetector(nn.Module):
             ops.AUTOTUNE, self.overlap_fps = prev, ov
         mlps = [b for m in self.stages for b in m.branches] + [m.agg for m in self.stages if m.agg]
         mlps += [self.cand_mlp, self.cluster_agg, self.head] + self.cluster_branches
+        if self.agg_head is not None:      # (tuned by the forward pass above, which runs the fused chain)
+            mlps.append(self.agg_head)
         return {m.name: list(m._geom.values())[-1] for m in mlps if m._geom}
 
     def _sample_stage(self, si: int, cur: torch.Tensor) -> torch.Tensor:
@@ -222,9 +231,13 @@ class SADDetector(nn.Module):
             for mlp, idx, cnt in zip(self.cluster_branches, idxs, cnts):
                 mlp.grouped(cur_xyz, cur_feat, cand, idx, out=cat, col_off=off, cnt=cnt)
                 off += mlp.out_channels
-        cfeat = self.cluster_agg.rows(cat)
         # ---- head + decode (SPEC.md §9) -------------------------------------------------------
-        o = self.head.rows(cfeat)                                        # [B,K,10]
+        if self.agg_head is not None and trace is None:
+            cfeat = None
+            o = self.agg_head.rows(cat)                                  # [B,K,10]
+        else:
+            cfeat = self.cluster_agg.rows(cat)
+            o = self.head.rows(cfeat)                                    # [B,K,10]
         boxes = torch.empty((B, K, 9), dtype=torch.float32, device=points.device)
         check(lib().sad_decode_boxes_f32(cand.data_ptr(), o.data_ptr(), B, K, self._anchors,
                                          boxes.data_ptr(), main.cuda_stream), "sad_decode_boxes_f32")

@@ -307,54 +307,46 @@ class PackedMLP:
         with _timed("mlp", self.name):
             check(lib().sad_mlp_chain_f32(ctypes.byref(a), _stream()), "sad_mlp_chain_f32")
 
+    def _time(self, a: MlpArgs, stream) -> Optional[float]:
+        """ms per launch of the geometry in ``a`` (None if it does not fit): one warm launch, then the
+        faster of two timed batches of four — single batches of three picked different winners from
+        run to run."""
+        if lib().sad_mlp_chain_f32(ctypes.byref(a), _stream()) != 0:
+            return None             # does not fit LDS / not valid for this nsample
+        stream.synchronize()
+        best = None
+        for _ in range(2):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            for _ in range(4):
+                lib().sad_mlp_chain_f32(ctypes.byref(a), _stream())
+            e1.record(stream)
+            stream.synchronize()
+            ms = e0.elapsed_time(e1) / 4
+            best = ms if best is None or ms < best else best
+        return best
+
     def _tune(self, a: MlpArgs) -> int:
         stream = torch.cuda.current_stream()
         best, best_ms = 0, None
         for code in self._CANDIDATES + ([1] if a.idx else []):   # 1 = VALU row-per-lane kernel (narrow chains)
             a.geometry = code
-            if lib().sad_mlp_chain_f32(ctypes.byref(a), _stream()) != 0:
-                continue            # does not fit LDS / not valid for this nsample
-            stream.synchronize()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record(stream)
-            for _ in range(3):
-                lib().sad_mlp_chain_f32(ctypes.byref(a), _stream())
-            e1.record(stream)
-            stream.synchronize()
-            ms = e0.elapsed_time(e1)
-            if best_ms is None or ms < best_ms * 0.98:   # prefer earlier entries on ties
+            ms = self._time(a, stream)
+            if ms is not None and (best_ms is None or ms < best_ms * 0.98):   # prefer earlier entries on ties
                 best, best_ms = code, ms
         if a.idx:   # second sweep: groups per workgroup (how much padding is expected)
             base = best
             for f in self._F_CODES:
                 a.geometry = base + 1000 * f
-                if lib().sad_mlp_chain_f32(ctypes.byref(a), _stream()) != 0:
-                    continue
-                stream.synchronize()
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record(stream)
-                for _ in range(3):
-                    lib().sad_mlp_chain_f32(ctypes.byref(a), _stream())
-                e1.record(stream)
-                stream.synchronize()
-                ms = e0.elapsed_time(e1)
-                if ms < best_ms * 0.98:
+                ms = self._time(a, stream)
+                if ms is not None and ms < best_ms * 0.98:
                     best, best_ms = base + 1000 * f, ms
             if a.cnt and a.workspace:   # third sweep: global row packing (1) vs per-workgroup packing (2)
                 base, found = best, None
                 for d in (1, 2):
                     a.geometry = base + 10000 * d
-                    if lib().sad_mlp_chain_f32(ctypes.byref(a), _stream()) != 0:
-                        continue
-                    stream.synchronize()
-                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    e0.record(stream)
-                    for _ in range(3):
-                        lib().sad_mlp_chain_f32(ctypes.byref(a), _stream())
-                    e1.record(stream)
-                    stream.synchronize()
-                    ms = e0.elapsed_time(e1)
-                    if found is None or ms < found[1]:
+                    ms = self._time(a, stream)
+                    if ms is not None and (found is None or ms < found[1]):
                         found = (base + 10000 * d, ms)
                 if found is not None:
                     best = found[0]

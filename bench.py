@@ -111,6 +111,7 @@ def executed_flops(det, points, cfg, dense=False):
     K = cfg.n_cand
     for n in ("cand", "cluster.agg", "head"):
         per[n] = B * K * chain(dims[n])
+    per["cluster.agg+head"] = 0      # the fused chain is named "cluster.agg+head": fl() sums its parts
     ex = sum(per.values())
     return ex, exec_rows / max(1, dense_rows), per
 
@@ -327,7 +328,7 @@ def main():
                          "algorithmic_bytes": g_bytes})
             res["kernels"] = kern
             def fl(n):      # a merged dispatch is named "a+b+c"
-                return sum(per_flops.get(x, 0) for x in n.split("+"))
+                return sum(per_flops.get(x, 0) for x in n.split("+")) if "+" in n else per_flops.get(n, 0)
             res["mlp_launches"] = {n: {"ms": round(v / tsteps, 3), "executed_gflop": round(fl(n) / 1e9, 1),
                                        "tflops": round(fl(n) / (v / tsteps * 1e-3) / 1e12, 1),
                                        "ms_single_stream": round(iso_name.get(n, 0.0), 3),
