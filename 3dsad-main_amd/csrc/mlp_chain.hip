@@ -1123,7 +1123,9 @@ static int prepare_chain(const sad_mlp_args *a, sad_stream_t stream, Prepared &q
         p.rowtab = (int *)a->workspace;
         if (int e = sad::launch_rowscan(a->cnt, (int)p.total_groups, a->S, (int)R, p.rowtab, (hipStream_t)stream, p.nodedup)) return e;
         const long long upper = (p.total_groups * a->S + R - 1) / R;
-        const long long per_cu = lds_final > 80 * 1024 ? 1 : (lds_final > 52 * 1024 ? 2 : (lds_final > 39 * 1024 ? 3 : 4));
+        long long per_cu = lds_final > 80 * 1024 ? 1 : (lds_final > 52 * 1024 ? 2 : (lds_final > 39 * 1024 ? 3 : 4));
+        if (sad::get_option(sad::OPT_MLP_DYN_SLOTS) > 0 && sad::get_option(sad::OPT_MLP_DYN_SLOTS) < per_cu)
+            per_cu = sad::get_option(sad::OPT_MLP_DYN_SLOTS);
         grid_dyn = upper < 256 * per_cu ? upper : 256 * per_cu;
     }
     const long long nblocks = grid_dyn ? grid_dyn : (grouped ? (p.total_groups + p.G - 1) / p.G : (p.total_rows + R - 1) / R);
