@@ -47,6 +47,8 @@ struct MlpParams {
     int relu_mask;
     int ld_out, col_off;
     int wn_shift;          // WN = 1 << wn_shift
+    int flex;              // 1: (output tile, row tile) items of a layer are dealt round-robin to ALL waves
+                           //    (RW == 1): no wave idles in a layer with fewer than WN output tiles
     int kc;                // layer-0 k-chunk (multiple of 8); == kp[0] when the whole input fits
     int bufA_rows, bufB_rows;
     int cpr, cshift;       // float4 chunks per feature row (0 = scalar path), log2 of lanes per row
@@ -442,7 +444,7 @@ __device__ __forceinline__ void mlp_chain_body(const MlpParams &p, const int blo
             const float *in = (l & 1) ? bufB : bufA;
             float *outb = (l & 1) ? bufA : bufB;
             const int n_oc = p.np[l] >> 5;
-            const int nrounds = (n_oc + WN - 1) >> p.wn_shift;
+            const int nrounds = p.flex ? (n_oc * WM + W - 1) / W : (n_oc + WN - 1) >> p.wn_shift;
             const float4 *frags = reinterpret_cast<const float4 *>(p.packed + p.off[l] + p.np[l]);
             const int nT4 = p.kp[l] >> 3;
             const bool last = (l == p.L - 1);
@@ -452,7 +454,11 @@ __device__ __forceinline__ void mlp_chain_body(const MlpParams &p, const int blo
             const int keep = last ? p.cout_last : p.kp[l + 1];
 
             for (int round = 0; round < nrounds; ++round) {
-                const int oc = wn + (round << p.wn_shift);
+                // classic: wave (wn, wm) owns output tile wn + round*WN of its own RW row tiles;
+                // flex: item = wave + round*W -> row tile item % WM (adjacent waves share the weights)
+                const int item = wave + round * W;
+                const int oc = p.flex ? item / WM : wn + (round << p.wn_shift);
+                const int rtb = p.flex ? item - oc * WM : wm * RW;      // first row tile of this wave
                 const bool have = oc < n_oc;
                 f32x16 acc[RW];
                 if (have) {
@@ -513,7 +519,7 @@ __device__ __forceinline__ void mlp_chain_body(const MlpParams &p, const int blo
                         __syncthreads();
                     }
                     if (have) {
-                        const float4 *bp = reinterpret_cast<const float4 *>(in) + (size_t)h * (PS >> 2) + (wm * RW) * 32 + j;
+                        const float4 *bp = reinterpret_cast<const float4 *>(in) + (size_t)h * (PS >> 2) + rtb * 32 + j;
                         const float4 *af = frags + ((size_t)oc * nT4 + (k0 >> 3)) * 64 + lane;
                         mma_ktile<RW, 4>(acc, af, (k1 - k0) >> 3, bp, PS >> 1);
                     }
@@ -533,7 +539,7 @@ __device__ __forceinline__ void mlp_chain_body(const MlpParams &p, const int blo
                         if (oc * 32 + 8 * a >= keep) continue;   // the next layer never reads these
 #pragma unroll
                         for (int rt = 0; rt < RW; ++rt) {
-                            float *d = outb + (size_t)((oc * 4 + a) * 2) * PS + ((wm * RW + rt) * 32 + j) * 4 + 2 * h;
+                            float *d = outb + (size_t)((oc * 4 + a) * 2) * PS + ((rtb + rt) * 32 + j) * 4 + 2 * h;
                             *reinterpret_cast<float2 *>(d) = make_float2(acc[rt][4 * a + 0], acc[rt][4 * a + 2]);
                             *reinterpret_cast<float2 *>(d + PS) = make_float2(acc[rt][4 * a + 1], acc[rt][4 * a + 3]);
                         }
@@ -542,7 +548,7 @@ __device__ __forceinline__ void mlp_chain_body(const MlpParams &p, const int blo
                     // plain rows: lane (j,h) holds row j, channels oc*32 + 8a + 4h + (0..3)
 #pragma unroll
                     for (int rt = 0; rt < RW; ++rt) {
-                        const long long gr = r0 + (wm * RW + rt) * 32 + j;
+                        const long long gr = r0 + (rtb + rt) * 32 + j;
                         if (gr >= p.total_rows) continue;
                         float *o = p.out + gr * p.ld_out + p.col_off;
 #pragma unroll
@@ -565,7 +571,7 @@ __device__ __forceinline__ void mlp_chain_body(const MlpParams &p, const int blo
                     // atomic max (outputs are >= 0 after the ReLU and the buffer starts at zero).
 #pragma unroll
                     for (int rt = 0; rt < RW; ++rt) {
-                        const int rbase = (wm * RW + rt) * 32;
+                        const int rbase = (rtb + rt) * 32;
                         const int gid = sm_gid[rbase + j];
                         int same[5];
 #pragma unroll
@@ -975,6 +981,7 @@ static int prepare_chain(const sad_mlp_args *a, sad_stream_t stream, Prepared &q
     p.total_rows = (long long)a->B * a->M << sp_shift;   // plain mode: rows; VALU kernel: padded rows
     p.total_groups = (long long)a->B * a->M;
     int geom_all = a->geometry ? a->geometry : sad::get_option(sad::OPT_MLP_FORCE);
+    const int flex_code = (geom_all / 100000) % 10;          // 1 = flexible item distribution (needs RW == 1)
     const int dyn_code = (geom_all / 10000) % 10;            // 0 = heuristic, 1 = global packing, 2 = per-workgroup packing
     const int fcode = (geom_all / 1000) % 10;                // 0 = default
     const int geom_wg = geom_all % 1000;
@@ -1101,6 +1108,8 @@ static int prepare_chain(const sad_mlp_args *a, sad_stream_t stream, Prepared &q
         if (!found) return sad::fail(SAD_EUNSUPPORTED, "sad_mlp_chain_f32: layer widths do not fit LDS");
     }
     p.wn_shift = wn_shift;
+    if (flex_code == 1 && RW != 1) return sad::fail(SAD_EUNSUPPORTED, "sad_mlp_chain_f32: flexible distribution needs RW == 1");
+    p.flex = flex_code == 1 ? 1 : 0;
     p.kc = kc;
     lds_rows(kc, p.bufA_rows, p.bufB_rows);
     const size_t lds = lds_bytes(W, wn_shift, RW, kc);

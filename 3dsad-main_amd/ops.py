@@ -292,7 +292,8 @@ class PackedMLP:
 
     # Geometries tried by the autotuner: W*100 + log2(WN)*10 + RW (include/sad_amd.h, sad_mlp_args).
     _CANDIDATES = [w * 100 + n * 10 + r for w in (8, 4) for n in range(4) if (1 << n) <= w
-                   for r in (1, 2, 4)] + [1600 + n * 10 + r for n in (3, 4) for r in (1, 2)]
+                   for r in (1, 2, 4)] + [1600 + n * 10 + r for n in (3, 4) for r in (1, 2)] \
+        + [100000 + w * 100 + n * 10 + 1 for w in (8, 4) for n in range(3) if (2 << n) <= w]   # flexible item distribution
     _F_CODES = (2, 4, 5, 6)      # grouped mode: 2^f * R / S groups per workgroup (default f = 3)
 
     def _launch(self, a: MlpArgs) -> None:

@@ -168,7 +168,9 @@ typedef struct sad_mlp_args {
      * wave.  A geometry that does not fit LDS returns SAD_EUNSUPPORTED (autotuners skip it).
      * + 1000*f (f = 1..7): grouped mode, a workgroup owns 2^f * R / S groups (default 8: it assumes
      * about one row in eight survives the padding removal).
-     * + 10000*d: d = 1 forces global row packing (needs cnt + workspace), d = 2 forbids it. */
+     * + 10000*d: d = 1 forces global row packing (needs cnt + workspace), d = 2 forbids it.
+     * + 100000: with RW = 1, the (output tile, row tile) items of every layer are dealt round-robin
+     *   to all W waves instead of the fixed WN x WM grid (no wave idles in a layer narrower than WN tiles). */
     int geometry;
 } sad_mlp_args;
 size_t sad_mlp_workspace_bytes(int B, int M, int S);

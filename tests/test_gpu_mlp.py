@@ -349,3 +349,47 @@ def test_multi_chain_dispatch_matches_single_launches(orc, sad, dev):
         off += net.out_channels
     ops.grouped_multi(calls)
     assert torch.equal(single, merged)
+
+
+def test_every_geometry_code_is_bit_identical(orc, sad, dev):
+    """Every workgroup geometry the autotuner may pick (wave grid, row blocking, flexible item
+    distribution, groups per workgroup, global / per-workgroup packing, VALU kernel) gives the
+    oracle's bits; geometries that do not fit LDS are refused with SAD_EUNSUPPORTED, never wrong."""
+    import torch
+    from sad_amd import _lib, ops, synth
+    rng = np.random.default_rng(4711)
+    B, N, M, S, C = 2, 2500, 200, 32, 64
+    xyz = rng.random((B, N, 3), dtype=np.float32)
+    feat = rng.normal(size=(B, N, C)).astype(np.float32)
+    new_xyz = np.ascontiguousarray(xyz[:, :M])
+    idxs, cnts = ops.ball_query_multi([0.12], [S], _t(xyz, dev), _t(new_xyz, dev), return_counts=True)
+    layers = synth.make_mlp_weights([C + 3, 64, 96, 128], rng)
+    want = orc.sa_group_mlp_max(xyz, feat, new_xyz, idxs[0].cpu().numpy(), layers)
+    net = ops.PackedMLP(layers, True, dev)
+    rows = rng.normal(size=(700, 384)).astype(np.float32)
+    play = synth.make_mlp_weights([384, 128, 40], rng)
+    pwant = orc.mlp_rows(rows, play)
+    pnet = ops.PackedMLP(play, False, dev)
+    codes = list(ops.PackedMLP._CANDIDATES)
+    codes += [c + 1000 * f for c in (801, 811, 100811) for f in ops.PackedMLP._F_CODES]
+    codes += [c + 10000 * d for c in (801, 821, 100821, 5811) for d in (1, 2)]
+    ran = 0
+    try:
+        for code in codes:
+            _lib.set_option("mlp_force", code)
+            try:
+                got = net.grouped(_t(xyz, dev), _t(feat, dev), _t(new_xyz, dev), idxs[0], cnt=cnts[0]).cpu().numpy()
+            except RuntimeError as e:
+                assert "(-2)" in str(e), f"geometry {code}: {e}"      # SAD_EUNSUPPORTED only
+                continue
+            assert np.array_equal(got, want), f"grouped geometry {code}: max diff {np.abs(got - want).max()}"
+            if code < 1000:
+                try:
+                    pg = pnet.rows(_t(rows, dev)).cpu().numpy()
+                    assert np.array_equal(pg, pwant), f"plain geometry {code}"
+                except RuntimeError as e:
+                    assert "(-2)" in str(e), f"plain geometry {code}: {e}"
+            ran += 1
+    finally:
+        _lib.set_option("mlp_force", 0)
+    assert ran >= 20, f"only {ran} geometries ran"
