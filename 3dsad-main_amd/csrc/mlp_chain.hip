@@ -96,6 +96,10 @@ __device__ __forceinline__ float group_max(float v, int steps) {
 // Software pipeline written out by hand (hipcc otherwise sinks each load to its use): a ring of
 // four A registers refilled right after use (L2 latency covered by three k-steps of MFMAs) and two
 // B registers (LDS latency covered by one k-step).
+#ifndef SAD_MLP_ADEPTH
+#define SAD_MLP_ADEPTH 4   // k-steps of weight fragments in flight per accumulator chain
+#endif
+
 template <int RW>
 struct BFrag { float4 v[RW]; };
 
@@ -163,6 +167,57 @@ __device__ __forceinline__ void mma_ktile(f32x16 (&acc)[RW], const float4 *__res
         if (u < rem) {
             mma4<RW>(acc, a[u], b[u % BD]);
             if (u + BD < rem) b[u % BD] = ldb<RW>(bp, t + u + BD, n4, kbs);
+        }
+    }
+}
+
+// Two output tiles per wave (RW = 1): two independent accumulator chains share every B fragment and
+// alternate on the matrix pipe, so a wave keeps issuing MFMAs while one chain's operands are late —
+// worth it where LDS size leaves one 8-wave workgroup (2 waves per SIMD) on a CU.
+__device__ __forceinline__ void mma4x2(f32x16 &acc0, f32x16 &acc1, const float4 a0, const float4 a1, const float4 b) {
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b.x, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, b.x, acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, b.y, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, b.y, acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, b.z, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, b.z, acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, b.w, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, b.w, acc1, 0, 0, 0);
+}
+
+template <int D>
+__device__ __forceinline__ void mma_ktile2(f32x16 &acc0, f32x16 &acc1, const float4 *__restrict__ af0,
+                                           const float4 *__restrict__ af1, int n4,
+                                           const float4 *__restrict__ bp, int kbs) {
+    float4 a0[D], a1[D], b[2];
+#pragma unroll
+    for (int u = 0; u < D; ++u) { a0[u] = lda(af0, u, n4); a1[u] = lda(af1, u, n4); }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) b[u] = bp[(u < n4 ? u : n4 - 1) * kbs];
+    int t = 0;
+    if (n4 >= D) {
+#pragma unroll
+        for (int u = 0; u < D; ++u) { asm volatile("" : "+v"(a0[u].x)); asm volatile("" : "+v"(a1[u].x)); }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) asm volatile("" : "+v"(b[u].x));
+        for (; t + D <= n4; t += D) {
+#pragma unroll
+            for (int u = 0; u < D; ++u) {
+                mma4x2(acc0, acc1, a0[u], a1[u], b[u % 2]);
+                a0[u] = lda(af0, t + D + u, n4);
+                a1[u] = lda(af1, t + D + u, n4);
+                const int tb = t + u + 2;
+                b[u % 2] = bp[(tb < n4 ? tb : n4 - 1) * kbs];
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+    const int rem = n4 - t;
+#pragma unroll
+    for (int u = 0; u < D - 1; ++u) {
+        if (u < rem) {
+            mma4x2(acc0, acc1, a0[u], a1[u], b[u % 2]);
+            if (u + 2 < rem) b[u % 2] = bp[(t + u + 2) * kbs];
         }
     }
 }
@@ -306,8 +361,9 @@ __device__ __forceinline__ void atomic_max_pos(float *addr, float v) {
     atomicMax(reinterpret_cast<unsigned *>(addr), __builtin_bit_cast(unsigned, v));
 }
 
-template <int W, int RW>
+template <int W, int RW, int CW = 1>
 __device__ __forceinline__ void mlp_chain_body(const MlpParams &p, const int block) {
+    static_assert(CW == 1 || RW == 1, "two output tiles per wave only with one row tile");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -444,7 +500,7 @@ __device__ __forceinline__ void mlp_chain_body(const MlpParams &p, const int blo
             const float *in = (l & 1) ? bufB : bufA;
             float *outb = (l & 1) ? bufA : bufB;
             const int n_oc = p.np[l] >> 5;
-            const int nrounds = p.flex ? (n_oc * WM + W - 1) / W : (n_oc + WN - 1) >> p.wn_shift;
+            const int nrounds = p.flex ? (n_oc * WM + W * CW - 1) / (W * CW) : (n_oc + WN * CW - 1) / (WN * CW);
             const float4 *frags = reinterpret_cast<const float4 *>(p.packed + p.off[l] + p.np[l]);
             const int nT4 = p.kp[l] >> 3;
             const bool last = (l == p.L - 1);
@@ -456,21 +512,31 @@ __device__ __forceinline__ void mlp_chain_body(const MlpParams &p, const int blo
             for (int round = 0; round < nrounds; ++round) {
                 // classic: wave (wn, wm) owns output tile wn + round*WN of its own RW row tiles;
                 // flex: item = wave + round*W -> row tile item % WM (adjacent waves share the weights)
-                const int item = wave + round * W;
-                const int oc = p.flex ? item / WM : wn + (round << p.wn_shift);
-                const int rtb = p.flex ? item - oc * WM : wm * RW;      // first row tile of this wave
-                const bool have = oc < n_oc;
-                f32x16 acc[RW];
-                if (have) {
+                // (with CW = 2 the wave takes two such tiles per round; they share the row tile)
+                int ocs[CW];
+                bool haves[CW];
+                int rtb = wm * RW;                                      // first row tile of this wave
+#pragma unroll
+                for (int c = 0; c < CW; ++c) {
+                    const int item = wave + (round * CW + c) * W;
+                    ocs[c] = p.flex ? item / WM : wn + ((round * CW + c) << p.wn_shift);
+                    if (p.flex) rtb = item - ocs[c] * WM;               // same for every c: WM divides W
+                    haves[c] = ocs[c] < n_oc;
+                }
+                const bool have = haves[0];
+                f32x16 accs[CW][RW];
+#pragma unroll
+                for (int c = 0; c < CW; ++c) {
+                    if (!haves[c]) continue;
 #pragma unroll
                     for (int a = 0; a < 4; ++a) {
-                        const float4 bv = *reinterpret_cast<const float4 *>(sbias + bias_off + oc * 32 + 8 * a + 4 * h);
+                        const float4 bv = *reinterpret_cast<const float4 *>(sbias + bias_off + ocs[c] * 32 + 8 * a + 4 * h);
 #pragma unroll
                         for (int rt = 0; rt < RW; ++rt) {
-                            acc[rt][4 * a + 0] = bv.x;
-                            acc[rt][4 * a + 1] = bv.y;
-                            acc[rt][4 * a + 2] = bv.z;
-                            acc[rt][4 * a + 3] = bv.w;
+                            accs[c][rt][4 * a + 0] = bv.x;
+                            accs[c][rt][4 * a + 1] = bv.y;
+                            accs[c][rt][4 * a + 2] = bv.z;
+                            accs[c][rt][4 * a + 3] = bv.w;
                         }
                     }
                 }
@@ -520,12 +586,25 @@ __device__ __forceinline__ void mlp_chain_body(const MlpParams &p, const int blo
                     }
                     if (have) {
                         const float4 *bp = reinterpret_cast<const float4 *>(in) + (size_t)h * (PS >> 2) + rtb * 32 + j;
-                        const float4 *af = frags + ((size_t)oc * nT4 + (k0 >> 3)) * 64 + lane;
-                        mma_ktile<RW, 4>(acc, af, (k1 - k0) >> 3, bp, PS >> 1);
+                        const float4 *af = frags + ((size_t)ocs[0] * nT4 + (k0 >> 3)) * 64 + lane;
+                        if constexpr (CW == 2) {
+                            if (haves[CW - 1]) {
+                                const float4 *af1 = frags + ((size_t)ocs[CW - 1] * nT4 + (k0 >> 3)) * 64 + lane;
+                                mma_ktile2<SAD_MLP_ADEPTH>(accs[0][0], accs[CW - 1][0], af, af1, (k1 - k0) >> 3, bp, PS >> 1);
+                            } else {
+                                mma_ktile<RW, SAD_MLP_ADEPTH>(accs[0], af, (k1 - k0) >> 3, bp, PS >> 1);
+                            }
+                        } else {
+                            mma_ktile<RW, SAD_MLP_ADEPTH>(accs[0], af, (k1 - k0) >> 3, bp, PS >> 1);
+                        }
                     }
                 }
-                if (!have) continue;
-                // ---- epilogue -----------------------------------------------------------------
+                // ---- epilogue (per output tile of this wave) -----------------------------------
+#pragma unroll
+                for (int cw = 0; cw < CW; ++cw) {
+                if (!haves[cw]) continue;
+                const int oc = ocs[cw];
+                f32x16 (&acc)[RW] = accs[cw];
                 if (relu) {
 #pragma unroll
                     for (int rt = 0; rt < RW; ++rt)
@@ -611,6 +690,7 @@ __device__ __forceinline__ void mlp_chain_body(const MlpParams &p, const int blo
                         }
                     }
                 }
+                }   // cw
             }
             bias_off += p.np[l];
             __syncthreads();
@@ -623,6 +703,11 @@ __global__ __launch_bounds__(W * 64) void mlp_chain_kernel(const MlpParams p) {
     mlp_chain_body<W, RW>(p, blockIdx.x);
 }
 
+template <int W>
+__global__ __launch_bounds__(W * 64) void mlp_chain2_kernel(const MlpParams p) {   // two output tiles per wave
+    mlp_chain_body<W, 1, 2>(p, blockIdx.x);
+}
+
 // Several independent chains (the branches of one multi-radius stage) in ONE dispatch: the
 // workgroups of the chains are laid out one after the other (heaviest first), so the light chains
 // fill the tail of the heavy one and the launch gaps between them disappear.  All chains share the
@@ -632,17 +717,21 @@ struct MultiParams {
     MlpParams p[MULTI_MAX];
     int first[MULTI_MAX + 1];   // first block of chain i; first[n] = grid size
     int rw[MULTI_MAX];
+    int cw[MULTI_MAX];          // 2 = two output tiles per wave (rw == 1)
     int n;
 };
 
-template <int W, int RWMAX>
+template <int W, int RWMAX, bool CW2>
 __global__ __launch_bounds__(W * 64) void mlp_multi_kernel(const MultiParams mp) {
     int c = 0;
     while (c + 1 < mp.n && (int)blockIdx.x >= mp.first[c + 1]) ++c;
     c = __builtin_amdgcn_readfirstlane(c);
     const int block = blockIdx.x - mp.first[c];
     const int rw = mp.rw[c];
-    if (rw == 1) mlp_chain_body<W, 1>(mp.p[c], block);
+    // (the two-tile body is compiled in only when a chain of the dispatch uses it: it needs more
+    // registers than the others and would lower everybody's occupancy)
+    if (CW2 && mp.cw[c] == 2) mlp_chain_body<W, 1, (CW2 ? 2 : 1)>(mp.p[c], block);
+    else if (rw == 1) mlp_chain_body<W, 1>(mp.p[c], block);
     else if (RWMAX >= 2 && rw == 2) mlp_chain_body<W, (RWMAX >= 2 ? 2 : 1)>(mp.p[c], block);
     else if (RWMAX >= 4 && rw == 4) mlp_chain_body<W, (RWMAX >= 4 ? 4 : 1)>(mp.p[c], block);
 }
@@ -940,7 +1029,7 @@ struct Prepared {
     MlpParams p;
     size_t lds;
     long long nblocks;
-    int W, RW;
+    int W, RW, CW;
     bool launched;      // the VALU kernel was launched instead (nothing left to do)
 };
 int launch_prepared(const Prepared &q, hipStream_t st);
@@ -981,7 +1070,7 @@ static int prepare_chain(const sad_mlp_args *a, sad_stream_t stream, Prepared &q
     p.total_rows = (long long)a->B * a->M << sp_shift;   // plain mode: rows; VALU kernel: padded rows
     p.total_groups = (long long)a->B * a->M;
     int geom_all = a->geometry ? a->geometry : sad::get_option(sad::OPT_MLP_FORCE);
-    const int flex_code = (geom_all / 100000) % 10;          // 1 = flexible item distribution (needs RW == 1)
+    const int flex_code = (geom_all / 100000) % 10;          // bit 0 = flexible item distribution, bit 1 = two output tiles per wave (both need RW == 1)
     const int dyn_code = (geom_all / 10000) % 10;            // 0 = heuristic, 1 = global packing, 2 = per-workgroup packing
     const int fcode = (geom_all / 1000) % 10;                // 0 = default
     const int geom_wg = geom_all % 1000;
@@ -1108,8 +1197,10 @@ static int prepare_chain(const sad_mlp_args *a, sad_stream_t stream, Prepared &q
         if (!found) return sad::fail(SAD_EUNSUPPORTED, "sad_mlp_chain_f32: layer widths do not fit LDS");
     }
     p.wn_shift = wn_shift;
-    if (flex_code == 1 && RW != 1) return sad::fail(SAD_EUNSUPPORTED, "sad_mlp_chain_f32: flexible distribution needs RW == 1");
-    p.flex = flex_code == 1 ? 1 : 0;
+    if (flex_code > 3 || (flex_code && RW != 1))
+        return sad::fail(SAD_EUNSUPPORTED, "sad_mlp_chain_f32: flexible distribution / two tiles per wave need RW == 1");
+    if ((flex_code & 2) && W == 16) return sad::fail(SAD_EUNSUPPORTED, "sad_mlp_chain_f32: two tiles per wave: 4 or 8 waves");
+    p.flex = flex_code & 1;
     p.kc = kc;
     lds_rows(kc, p.bufA_rows, p.bufB_rows);
     const size_t lds = lds_bytes(W, wn_shift, RW, kc);
@@ -1140,15 +1231,29 @@ static int prepare_chain(const sad_mlp_args *a, sad_stream_t stream, Prepared &q
     const long long nblocks = grid_dyn ? grid_dyn : (grouped ? (p.total_groups + p.G - 1) / p.G : (p.total_rows + R - 1) / R);
     SAD_REQUIRE(nblocks < (1LL << 31), "sad_mlp_chain_f32: too many workgroups");
     if (W == 16 && RW == 4) return sad::fail(SAD_EUNSUPPORTED, "sad_mlp_chain_f32: 16 waves support RW 1 or 2");
-    q.p = p; q.lds = lds; q.nblocks = nblocks; q.W = W; q.RW = RW;
+    q.p = p; q.lds = lds; q.nblocks = nblocks; q.W = W; q.RW = RW; q.CW = (flex_code & 2) ? 2 : 1;
     return SAD_OK;
 }
 
 namespace {
+template <int W>
+int launch_mlp2(const MlpParams &p, size_t lds, long long nblocks, hipStream_t st) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&mlp_chain2_kernel<W>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            (void)hipGetLastError();
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((mlp_chain2_kernel<W>), dim3((unsigned)nblocks), dim3(W * 64), lds, st, p);
+    return sad::check_launch("sad_mlp_chain_f32");
+}
+
 int launch_prepared(const Prepared &q, hipStream_t st) {
     const MlpParams &p = q.p;
     const size_t lds = q.lds;
     const long long nblocks = q.nblocks;
+    if (q.CW == 2) return q.W == 8 ? launch_mlp2<8>(p, lds, nblocks, st) : launch_mlp2<4>(p, lds, nblocks, st);
     if (q.W == 16) {
         if (q.RW == 1) return launch_mlp<16, 1>(p, lds, nblocks, st);
         return launch_mlp<16, 2>(p, lds, nblocks, st);
@@ -1163,16 +1268,16 @@ int launch_prepared(const Prepared &q, hipStream_t st) {
     return launch_mlp<4, 4>(p, lds, nblocks, st);
 }
 
-template <int W, int RWMAX>
+template <int W, int RWMAX, bool CW2>
 int launch_multi(const MultiParams &mp, size_t lds, hipStream_t st) {
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&mlp_multi_kernel<W, RWMAX>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&mlp_multi_kernel<W, RWMAX, CW2>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             (void)hipGetLastError();
         attr_set = true;
     }
-    hipLaunchKernelGGL((mlp_multi_kernel<W, RWMAX>), dim3((unsigned)mp.first[mp.n]), dim3(W * 64), lds, st, mp);
+    hipLaunchKernelGGL((mlp_multi_kernel<W, RWMAX, CW2>), dim3((unsigned)mp.first[mp.n]), dim3(W * 64), lds, st, mp);
     return sad::check_launch("sad_mlp_chain_multi_f32");
 }
 }  // namespace
@@ -1224,6 +1329,7 @@ SAD_API int sad_mlp_chain_multi_f32(const sad_mlp_args *const *args, int n, sad_
         const Prepared &s = q[order[i]];
         mp.p[i] = s.p;
         mp.rw[i] = s.RW;
+        mp.cw[i] = s.CW;
         mp.first[i] = (int)total;
         total += s.nblocks;
         lds = s.lds > lds ? s.lds : lds;
@@ -1231,12 +1337,24 @@ SAD_API int sad_mlp_chain_multi_f32(const sad_mlp_args *const *args, int n, sad_
     }
     SAD_REQUIRE(total < (1LL << 31), "sad_mlp_chain_multi_f32: too many workgroups");
     mp.first[n] = (int)total;
+    bool cw2 = false;
+    for (int i = 0; i < n; ++i) cw2 = cw2 || mp.cw[i] == 2;
     if (q[0].W == 8) {
-        if (rwmax == 1) return launch_multi<8, 1>(mp, lds, st);
-        if (rwmax == 2) return launch_multi<8, 2>(mp, lds, st);
-        return launch_multi<8, 4>(mp, lds, st);
+        if (cw2) {
+            if (rwmax == 1) return launch_multi<8, 1, true>(mp, lds, st);
+            if (rwmax == 2) return launch_multi<8, 2, true>(mp, lds, st);
+            return launch_multi<8, 4, true>(mp, lds, st);
+        }
+        if (rwmax == 1) return launch_multi<8, 1, false>(mp, lds, st);
+        if (rwmax == 2) return launch_multi<8, 2, false>(mp, lds, st);
+        return launch_multi<8, 4, false>(mp, lds, st);
     }
-    if (rwmax == 1) return launch_multi<4, 1>(mp, lds, st);
-    if (rwmax == 2) return launch_multi<4, 2>(mp, lds, st);
-    return launch_multi<4, 4>(mp, lds, st);
+    if (cw2) {
+        if (rwmax == 1) return launch_multi<4, 1, true>(mp, lds, st);
+        if (rwmax == 2) return launch_multi<4, 2, true>(mp, lds, st);
+        return launch_multi<4, 4, true>(mp, lds, st);
+    }
+    if (rwmax == 1) return launch_multi<4, 1, false>(mp, lds, st);
+    if (rwmax == 2) return launch_multi<4, 2, false>(mp, lds, st);
+    return launch_multi<4, 4, false>(mp, lds, st);
 }

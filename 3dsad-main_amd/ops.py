@@ -293,7 +293,10 @@ class PackedMLP:
     # Geometries tried by the autotuner: W*100 + log2(WN)*10 + RW (include/sad_amd.h, sad_mlp_args).
     _CANDIDATES = [w * 100 + n * 10 + r for w in (8, 4) for n in range(4) if (1 << n) <= w
                    for r in (1, 2, 4)] + [1600 + n * 10 + r for n in (3, 4) for r in (1, 2)] \
-        + [100000 + w * 100 + n * 10 + 1 for w in (8, 4) for n in range(3) if (2 << n) <= w]   # flexible item distribution
+        + [100000 + w * 100 + n * 10 + 1 for w in (8, 4) for n in range(3) if (2 << n) <= w] \
+        + [200000 + w * 100 + n * 10 + 1 for w in (8, 4) for n in range(4) if (1 << n) <= w] \
+        + [300000 + w * 100 + n * 10 + 1 for w in (8, 4) for n in range(3) if (2 << n) <= w]
+    # +100000 flexible item distribution, +200000 two output tiles per wave, +300000 both
     _F_CODES = (2, 4, 5, 6)      # grouped mode: 2^f * R / S groups per workgroup (default f = 3)
 
     def _launch(self, a: MlpArgs) -> None:

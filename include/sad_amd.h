@@ -170,7 +170,9 @@ typedef struct sad_mlp_args {
      * about one row in eight survives the padding removal).
      * + 10000*d: d = 1 forces global row packing (needs cnt + workspace), d = 2 forbids it.
      * + 100000: with RW = 1, the (output tile, row tile) items of every layer are dealt round-robin
-     *   to all W waves instead of the fixed WN x WM grid (no wave idles in a layer narrower than WN tiles). */
+     *   to all W waves instead of the fixed WN x WM grid (no wave idles in a layer narrower than WN tiles).
+     * + 200000: with RW = 1 (4 or 8 waves), a wave computes two output tiles per round as two
+     *   independent accumulator chains sharing the activation operand (+300000 = both). */
     int geometry;
 } sad_mlp_args;
 size_t sad_mlp_workspace_bytes(int B, int M, int S);
