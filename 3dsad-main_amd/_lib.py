@@ -45,7 +45,7 @@ class MlpBf16Args(ctypes.Structure):
         ("L", ctypes.c_int), ("dims", ctypes.c_int * (MAX_LAYERS + 1)),
         ("packed", vp), ("relu_mask", ctypes.c_int),
         ("out", vp), ("out_bf16", ctypes.c_int), ("ld_out", ctypes.c_int), ("col_off", ctypes.c_int),
-        ("cnt", vp), ("workspace", vp),
+        ("cnt", vp), ("workspace", vp), ("geometry", ctypes.c_int),
     ]
 
 

@@ -552,9 +552,15 @@ SAD_API int sad_mlp_chain_bf16(const sad_mlp_bf16_args *a, sad_stream_t stream) 
     const size_t budget = 150 * 1024;
     int R = 128;
     auto lds_of = [&](int r) { return (((size_t)r * 2 * (ldA + ldB) + 15) & ~(size_t)15) + (size_t)(3 * r + 4) * sizeof(int); };
-    while (R > 32 && lds_of(R) > budget) R >>= 1;
+    if (a->geometry) {     // forced rows per tile (autotuners): 32 / 64 / 128 / 256
+        SAD_REQUIRE(a->geometry == 32 || a->geometry == 64 || a->geometry == 128 || a->geometry == 256,
+                    "sad_mlp_chain_bf16: geometry (rows per tile) must be 32, 64, 128 or 256");
+        R = a->geometry;
+        if (lds_of(R) > 160 * 1024) return sad::fail(SAD_EUNSUPPORTED, "sad_mlp_chain_bf16: %d rows per tile do not fit LDS", R);
+    }
+    while (!a->geometry && R > 32 && lds_of(R) > budget) R >>= 1;
     if (lds_of(R) > 160 * 1024) return sad::fail(SAD_EUNSUPPORTED, "sad_mlp_chain_bf16: layer widths need %zu bytes of LDS", lds_of(R));
-    while (R > 32 && p.rows <= R / 2) R >>= 1;
+    while (!a->geometry && R > 32 && p.rows <= R / 2) R >>= 1;
     p.R = R;
     p.bufA_elems = R * ldA;
     p.meta_off = (int)(((size_t)R * 2 * (ldA + ldB) + 15) & ~(size_t)15);

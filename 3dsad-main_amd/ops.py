@@ -499,7 +499,7 @@ class PackedMLPBf16:
         dims_c = (ctypes.c_int * (self.L + 1))(*self.dims)
         n = lib().sad_mlp_packed_bytes_bf16(self.L, dims_c, int(self.first_has_xyz))
         self.packed = torch.empty((n,), dtype=torch.uint8, device=self.device)
-        self._geom = {}      # no geometry autotuning on this path (kept for SADDetector.autotune)
+        self._geom = {}      # (mode, B, N, M, S, ld_out) -> rows per tile picked by the autotuner
         w_arr = (vp * self.L)(*[w.data_ptr() for w in ws])
         b_arr = (vp * self.L)(*[b.data_ptr() for b in bs])
         with torch.cuda.device(self.device):
@@ -562,9 +562,38 @@ class PackedMLPBf16:
                 raise ValueError("cnt must be [B,M]")
             ws = torch.empty((lib().sad_mlp_workspace_bytes(B, M, S),), dtype=torch.uint8, device=xyz.device)
             a.cnt, a.workspace = cnt.data_ptr(), ws.data_ptr()
+        self._launch(a)
+        return out
+
+    def _launch(self, a) -> None:
+        """Enqueue; with AUTOTUNE on, the first call for a shape times 64 / 128 / 256 rows per tile."""
+        key = (bool(a.idx), a.B, a.N, a.M, a.S, a.ld_out)
+        geom = self._geom.get(key)
+        if geom is None and AUTOTUNE:
+            stream = torch.cuda.current_stream()
+            best, best_ms = 0, None
+            for code in (0, 64, 128, 256):
+                a.geometry = code
+                if lib().sad_mlp_chain_bf16(ctypes.byref(a), _stream()) != 0:
+                    continue
+                stream.synchronize()
+                ms_best = None
+                for _ in range(2):
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(stream)
+                    for _ in range(4):
+                        lib().sad_mlp_chain_bf16(ctypes.byref(a), _stream())
+                    e1.record(stream)
+                    stream.synchronize()
+                    ms = e0.elapsed_time(e1)
+                    ms_best = ms if ms_best is None or ms < ms_best else ms_best
+                if best_ms is None or ms_best < best_ms * 0.98:
+                    best, best_ms = code, ms_best
+            geom = best
+            self._geom[key] = geom
+        a.geometry = geom or 0
         with _timed("mlp", self.name):
             check(lib().sad_mlp_chain_bf16(ctypes.byref(a), _stream()), "sad_mlp_chain_bf16")
-        return out
 
     def rows(self, x: torch.Tensor, out: Optional[torch.Tensor] = None, col_off: int = 0,
              out_dtype=torch.float32) -> torch.Tensor:
@@ -589,8 +618,7 @@ class PackedMLPBf16:
         a.B, a.N, a.M, a.S, a.C = 1, 0, R, 1, C
         a.out, a.out_bf16 = out.data_ptr(), int(out.dtype == torch.bfloat16)
         a.ld_out, a.col_off = out.stride(-2), col_off
-        with _timed("mlp", self.name):
-            check(lib().sad_mlp_chain_bf16(ctypes.byref(a), _stream()), "sad_mlp_chain_bf16")
+        self._launch(a)
         return out
 
 

@@ -212,6 +212,9 @@ typedef struct sad_mlp_bf16_args {
      * repeat the first neighbour cannot change the max); both NULL = dense rows */
     const int32_t *cnt;
     void *workspace;
+    /* 0 = built-in choice (128 rows per tile, fewer if LDS demands); else rows per tile 32/64/128/256
+     * (more rows amortise the per-tile gather latency of narrow chains; SAD_EUNSUPPORTED if LDS is short) */
+    int geometry;
 } sad_mlp_bf16_args;
 int sad_mlp_chain_bf16(const sad_mlp_bf16_args *args, sad_stream_t stream);
 
