@@ -318,9 +318,8 @@ __device__ __forceinline__ unsigned half_max_u32(unsigned v) {   // max over lan
 }
 
 template <int NW, int PPT>
-__global__ __launch_bounds__(NW * 64) void fps_cell_kernel(const float *__restrict__ xyz,
-                                                           const int *__restrict__ perm_in, int N,
-                                                           int M, int *__restrict__ idx_out) {
+__device__ __forceinline__ void fps_cell_body(const float *__restrict__ xyz, const int *__restrict__ perm_in, int N,
+                                              int M, int *__restrict__ idx_out) {
     static_assert(PPT <= 32 && NW <= 16, "bucket state lives in lanes 0..31; one record per wave");
     typedef float fvec __attribute__((ext_vector_type(PPT)));
     typedef unsigned uvec __attribute__((ext_vector_type(PPT)));
@@ -455,6 +454,12 @@ __global__ __launch_bounds__(NW * 64) void fps_cell_kernel(const float *__restri
         }
         if (tid == 0) out[i] = (int)(~glo);
     }
+}
+
+template <int NW, int PPT>
+__global__ __launch_bounds__(NW * 64) void fps_cell_kernel(const float *__restrict__ xyz, const int *__restrict__ perm_in,
+                                                           int N, int M, int *__restrict__ idx_out) {
+    fps_cell_body<NW, PPT>(xyz, perm_in, N, M, idx_out);
 }
 
 template <int NW, int PPT>
