@@ -119,8 +119,8 @@ def executed_flops(det, points, cfg, dense=False):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--batch", type=int, default=32, help="scenes per GPU per step")
     ap.add_argument("--no-overlap", action="store_true", help="run FPS on the main stream")
     ap.add_argument("--fps-streams", type=int, default=4, help="sampling streams used round-robin")
