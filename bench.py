@@ -194,13 +194,13 @@ def main():
     if world > 1:
         dist.barrier()
         torch.cuda.synchronize()
-    # per-launch HIP events are recorded on every 4th step of the timed region (a sample: event
+    # per-launch HIP events are recorded on every 8th step of the timed region (a sample: event
     # packets between kernels cost a few per cent of throughput when every launch carries them)
     log = None if args.no_launch_timing else []
     timed_steps = 0
     t0 = time.perf_counter()
     for i in range(args.steps):
-        sample = log is not None and i % 4 == 0
+        sample = log is not None and i % 8 == 4
         ops.LAUNCH_LOG = log if sample else None
         timed_steps += int(sample)
         out = step()
