@@ -451,12 +451,15 @@ __device__ __forceinline__ void mlp_chain_body(const MlpParams &p, const int blo
     }
     const int nchunks = (p.kp[0] + p.kc - 1) / p.kc;
 
+    // dynamic hand-out: the id of the NEXT pass is fetched (one global atomic, ~1.5 us round trip)
+    // while the current pass computes; it reaches LDS at the end of the pass
+    int next_pass = 0;
+    if (dyn && tid == 0) s_pass = atomicAdd(p.rowtab + 2, 1);
     for (int pass_i = 0; dyn || pass_i < npass; ++pass_i) {
         int pass = pass_i;          // static mode: pass of this workgroup's own rows
         int qoff = pass * R;        // compact-row coordinate of row 0 of the tile in s_off's frame
         if (dyn) {
-            // fetch the next pass of the launch; s_off becomes pass-local (row 0 of the pass = 0)
-            if (tid == 0) s_pass = atomicAdd(p.rowtab + 2, 1);
+            // s_off becomes pass-local (row 0 of the pass = 0)
             __syncthreads();
             pass = s_pass;
             const int total = p.rowtab[0];
@@ -494,6 +497,7 @@ __device__ __forceinline__ void mlp_chain_body(const MlpParams &p, const int blo
             }
         }
         __syncthreads();
+        if (dyn && tid == 0) next_pass = atomicAdd(p.rowtab + 2, 1);   // everybody has read s_pass by now
 
         int bias_off = 0;
         for (int l = 0; l < p.L; ++l) {
@@ -695,6 +699,7 @@ __device__ __forceinline__ void mlp_chain_body(const MlpParams &p, const int blo
             bias_off += p.np[l];
             __syncthreads();
         }
+        if (dyn && tid == 0) s_pass = next_pass;
     }
 }
 
