@@ -58,6 +58,7 @@ struct MlpParams {
     int nodedup;           // tuning/A-B switch: compute the padded duplicate rows too
     int s_off_entries;     // capacity of s_off (the work-counter broadcast slot follows it)
     int *rowtab;           // global row packing (see rowscan_kernel): hdr[4], row_start[ngroups+1], pass_first[]
+    const int *row_src, *row_gid;   // row map of the packed order (see RowMap)
     long long total_groups; // B*M
 };
 
@@ -228,8 +229,29 @@ __device__ __forceinline__ void mma_ktile2(f32x16 &acc0, f32x16 &acc1, const flo
 // Table (ints): hdr[0] = total rows, hdr[1] = passes, hdr[2] = next pass (work counter),
 // row_start[ngroups + 1] from offset 4, then pass_first[p] = group that contains row p*R.
 constexpr int SCAN_T = 1024;
+// Row map (optional, rowmap != NULL): for every packed row its source point b*N + idx[g*S + s] and
+// its group g (bit 30 set when the group lies inside one 32-row tile of the packed order), so the MLP
+// kernel finds the rows of a pass with two coalesced loads instead of table look-ups and a search.
+struct RowMap {
+    int *src;                 // [total rows] source point
+    int *gid;                 // [total rows] group | WHOLE_BIT
+    const int32_t *idx;       // [ngroups, S]
+    int N, M;
+};
+constexpr int WHOLE_BIT = 1 << 30;
+
+__device__ __forceinline__ void expand_group(const RowMap &rm, int g, int S, int run, int c) {
+    if (!rm.src) return;
+    const long long b = g / rm.M;
+    const int whole = ((run >> 5) == ((run + c - 1) >> 5)) ? WHOLE_BIT : 0;
+    for (int s2 = 0; s2 < c; ++s2) {
+        rm.src[run + s2] = (int)(b * rm.N + rm.idx[(long long)g * S + s2]);
+        rm.gid[run + s2] = g | whole;
+    }
+}
+
 __global__ __launch_bounds__(SCAN_T) void rowscan_kernel(const int32_t *__restrict__ cnt, int ngroups, int S,
-                                                         int nodedup, int R, int *__restrict__ tab) {
+                                                         int nodedup, int R, int *__restrict__ tab, RowMap rm) {
     __shared__ int wsum[16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int *row_start = tab + 4;
@@ -259,6 +281,7 @@ __global__ __launch_bounds__(SCAN_T) void rowscan_kernel(const int32_t *__restri
         row_start[g] = run;
         // passes whose first row lies inside this group
         for (int pp = (run + R - 1) / R; pp * R < run + c; ++pp) pass_first[pp] = g;
+        expand_group(rm, g, S, run, c);
         run += c;
     }
     if (tid == SCAN_T - 1) {
@@ -297,7 +320,7 @@ __global__ __launch_bounds__(SCAN_T) void rowscan_sums_kernel(const int32_t *__r
 
 __global__ __launch_bounds__(SCAN_T) void rowscan_write_kernel(const int32_t *__restrict__ cnt, int ngroups, int S,
                                                                int nodedup, int R, const int *__restrict__ blk_sum,
-                                                               int *__restrict__ tab) {
+                                                               int *__restrict__ tab, RowMap rm) {
     __shared__ int wsum[16];
     __shared__ int s_base;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -335,6 +358,7 @@ __global__ __launch_bounds__(SCAN_T) void rowscan_write_kernel(const int32_t *__
     if (g < ngroups) {
         row_start[g] = run;
         for (int pp = (run + R - 1) / R; pp * R < run + c; ++pp) pass_first[pp] = g;
+        expand_group(rm, g, S, run, c);
         if (g == ngroups - 1) {
             const int total = run + c;
             row_start[ngroups] = total;
@@ -464,19 +488,19 @@ __device__ __forceinline__ void mlp_chain_body(const MlpParams &p, const int blo
             pass = s_pass;
             const int total = p.rowtab[0];
             if (pass >= p.rowtab[1]) break;                 // uniform
-            const int *row_start = p.rowtab + 4;
-            const int *pass_first = p.rowtab + 4 + (int)p.total_groups + 1;
-            const int gA = pass_first[pass];
-            const int gB = pass + 1 < p.rowtab[1] ? pass_first[pass + 1] : (int)p.total_groups - 1;
-            G = gB - gA + 1;                                // groups touching this pass (<= R + 1)
-            g0 = gA;
-            for (int i = tid; i <= G; i += W * 64) s_off[i] = row_start[gA + i] - pass * R;
             T = total - pass * R < R ? total - pass * R : R;
             qoff = 0;
-            __syncthreads();
+            g0 = 0;                                         // sm_gid holds global group ids in this mode
+            for (int r = tid; r < R; r += W * 64) {
+                const bool valid = r < T;
+                const int q = pass * R + (valid ? r : T - 1);
+                sm_idx[r] = p.row_src[q];
+                const int gv = p.row_gid[q];
+                sm_gid[r] = valid ? gv : ~gv;               // invalid rows: negative, still name a real group
+            }
         }
-        // ---- per-row source index ---------------------------------------------------------------
-        for (int r = tid; r < R; r += W * 64) {
+        // ---- per-row source index (static packing / plain rows) ----------------------------------
+        for (int r = tid; r < R && !dyn; r += W * 64) {
             if (p.grouped) {
                 int q = qoff + r;
                 const bool valid = dyn ? r < T : q < T;
@@ -553,7 +577,9 @@ __device__ __forceinline__ void mlp_chain_body(const MlpParams &p, const int blo
                         if (!(round == 0 && ck == 0)) __syncthreads();  // previous readers are done
                         if (p.grouped && k0 == 0) {  // channels 0..3 = point - centroid, 0 (SPEC §6)
                             for (int r = tid; r < R; r += W * 64) {
-                                const int gi = sm_gid[r] < 0 ? s_off_last_group(s_off, G, T) : sm_gid[r];
+                                const int gv = sm_gid[r];
+                                const int gi = dyn ? ((gv < 0 ? ~gv : gv) & (WHOLE_BIT - 1))
+                                                   : (gv < 0 ? s_off_last_group(s_off, G, T) : gv);
                                 const float *q = p.xyz + (long long)sm_idx[r] * 3;
                                 const float *c = p.new_xyz + (g0 + gi) * 3;
                                 *reinterpret_cast<float2 *>(bufA + r * 4) = make_float2(q[0] - c[0], q[2] - c[2]);
@@ -676,8 +702,8 @@ __device__ __forceinline__ void mlp_chain_body(const MlpParams &p, const int blo
                         const bool tail = gid >= 0 && (j == 31 || ng != gid);
                         if (!tail) continue;
                         const int q0 = qoff + rbase;                      // compact row of lane 0 (s_off frame)
-                        const bool whole = s_off[gid] >= q0 && s_off[gid + 1] <= q0 + 32;
-                        float *o = p.out + (g0 + gid) * p.ld_out + p.col_off;
+                        const bool whole = dyn ? (gid & WHOLE_BIT) != 0 : (s_off[gid] >= q0 && s_off[gid + 1] <= q0 + 32);
+                        float *o = p.out + (g0 + (dyn ? (gid & (WHOLE_BIT - 1)) : gid)) * p.ld_out + p.col_off;
 #pragma unroll
                         for (int a = 0; a < 4; ++a) {
                             const int ch = oc * 32 + 8 * a + 4 * h;
@@ -1008,15 +1034,23 @@ SAD_API int sad_mlp_pack_f32(int L, const int *dims, int first_has_xyz, const fl
 namespace sad {
 // Prefix-sums the per-group row counts into the table described at rowscan_kernel (shared with the
 // bf16 chain, csrc/mlp_bf16.hip).
-int launch_rowscan(const int32_t *cnt, int ngroups, int S, int R, int *tab, hipStream_t st, int nodedup) {
+int launch_rowscan(const int32_t *cnt, int ngroups, int S, int R, int *tab, hipStream_t st, int nodedup,
+                   const int32_t *idx, int N, int M) {
+    // layout (ints): hdr[4] | row_start[ngroups+1] | pass_first[ngroups*S/32+2] | blk_sum[ngroups/1024+2]
+    //                | row map: src[ngroups*S] | gid[ngroups*S]   (only written when idx != NULL)
+    int *blk_sum = tab + 4 + (ngroups + 1) + ((long long)ngroups * S / 32 + 2);
+    RowMap rm{};
+    if (idx) {
+        rm.src = blk_sum + (ngroups / 1024 + 2);
+        rm.gid = rm.src + (long long)ngroups * S;
+        rm.idx = idx; rm.N = N; rm.M = M;
+    }
     if (ngroups <= 4096) {
-        hipLaunchKernelGGL(rowscan_kernel, dim3(1), dim3(SCAN_T), 0, st, cnt, ngroups, S, nodedup, R, tab);
+        hipLaunchKernelGGL(rowscan_kernel, dim3(1), dim3(SCAN_T), 0, st, cnt, ngroups, S, nodedup, R, tab, rm);
     } else {
-        // block sums live behind the table (sad_mlp_workspace_bytes reserves them)
         const int nblk = (ngroups + SCAN_T - 1) / SCAN_T;
-        int *blk_sum = tab + 4 + (ngroups + 1) + ((long long)ngroups * S / 32 + 2);
         hipLaunchKernelGGL(rowscan_sums_kernel, dim3(nblk), dim3(SCAN_T), 0, st, cnt, ngroups, S, nodedup, blk_sum);
-        hipLaunchKernelGGL(rowscan_write_kernel, dim3(nblk), dim3(SCAN_T), 0, st, cnt, ngroups, S, nodedup, R, blk_sum, tab);
+        hipLaunchKernelGGL(rowscan_write_kernel, dim3(nblk), dim3(SCAN_T), 0, st, cnt, ngroups, S, nodedup, R, blk_sum, tab, rm);
     }
     return check_launch("rowscan");
 }
@@ -1026,7 +1060,7 @@ SAD_API size_t sad_mlp_workspace_bytes(int B, int M, int S) {
     if (B < 1 || M < 1 || S < 1) return 0;
     const size_t ng = (size_t)B * M;
     // hdr, row_start, pass_first (R >= 32), block sums of the two-launch scan
-    return sizeof(int) * (4 + (ng + 1) + (ng * S / 32 + 2) + (ng / 1024 + 2)) + 64;
+    return sizeof(int) * (4 + (ng + 1) + (ng * S / 32 + 2) + (ng / 1024 + 2) + 2 * ng * S) + 64;   // + row map
 }
 
 namespace {
@@ -1226,7 +1260,10 @@ static int prepare_chain(const sad_mlp_args *a, sad_stream_t stream, Prepared &q
         SAD_REQUIRE((uintptr_t)a->workspace % 16 == 0, "sad_mlp_chain_f32: workspace must be 16-byte aligned");
         SAD_REQUIRE(p.total_groups < (1LL << 30), "sad_mlp_chain_f32: too many groups");
         p.rowtab = (int *)a->workspace;
-        if (int e = sad::launch_rowscan(a->cnt, (int)p.total_groups, a->S, (int)R, p.rowtab, (hipStream_t)stream, p.nodedup)) return e;
+        if (int e = sad::launch_rowscan(a->cnt, (int)p.total_groups, a->S, (int)R, p.rowtab, (hipStream_t)stream, p.nodedup,
+                                        a->idx, a->N, a->M)) return e;
+        p.row_src = p.rowtab + 4 + (p.total_groups + 1) + (p.total_groups * a->S / 32 + 2) + (p.total_groups / 1024 + 2);
+        p.row_gid = p.row_src + p.total_groups * a->S;
         const long long upper = (p.total_groups * a->S + R - 1) / R;
         long long per_cu = lds_final > 80 * 1024 ? 1 : (lds_final > 52 * 1024 ? 2 : (lds_final > 39 * 1024 ? 3 : 4));
         if (sad::get_option(sad::OPT_MLP_DYN_SLOTS) > 0 && sad::get_option(sad::OPT_MLP_DYN_SLOTS) < per_cu)
