@@ -90,12 +90,41 @@ def tiny_detector():
         head=tr["cluster"]["head"])
 
 
+def extensions():
+    """SPEC.md §13-§16 operators: NMS, bf16 chain, F-FPS, scatter-add / arg-max references."""
+    rng = np.random.default_rng(1316)
+    d = {}
+    xyz = rng.random((2, 400, 3), dtype=np.float32)
+    feat = rng.standard_normal((2, 400, 6)).astype(np.float32)
+    d["ffps_xyz"], d["ffps_feat"] = xyz, feat
+    d["ffps_idx_w1"] = oracle.ffps(xyz, feat, 64, 1.0)
+    d["ffps_idx_w0"] = oracle.ffps(xyz, feat, 64, 0.0)
+    layers = synth.make_mlp_weights([9, 24, 40], rng)
+    for i, (w, b) in enumerate(layers):
+        d[f"bf16_w{i}"], d[f"bf16_b{i}"] = w, b
+    new_xyz = np.ascontiguousarray(xyz[:, :50])
+    idx = oracle.ball_query(0.2, 16, xyz, new_xyz)
+    fb = oracle.bf16_round(feat)
+    d["bf16_idx"] = idx
+    d["bf16_pooled"] = oracle.sa_group_mlp_max_bf16(xyz, fb, new_xyz, idx, layers)
+    d["bf16_rows"] = oracle.mlp_rows_bf16(np.concatenate([xyz[0, :32], feat[0, :32]], 1), layers)
+    boxes = np.zeros((1, 40, 9), np.float32)
+    boxes[0, :, 0:2] = rng.uniform(0, 12, (40, 2))
+    boxes[0, :, 3:6] = rng.uniform(1.0, 4.0, (40, 3))
+    boxes[0, :, 6] = rng.uniform(-3.0, 3.0, 40)
+    boxes[0, :, 7] = rng.uniform(0, 1, 40)
+    keep, order, count = oracle.nms_bev(boxes, 0.1, 0.2)
+    d["nms_boxes"], d["nms_keep"], d["nms_order"], d["nms_count"] = boxes, keep, order, count
+    np.savez_compressed(os.path.join(OUT, "extensions.npz"), **d)
+
+
 if __name__ == "__main__":
     oracle.build()
     config0()
     edge_cases()
     adaptive()
     tiny_detector()
+    extensions()
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(OUT, f)))

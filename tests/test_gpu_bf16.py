@@ -181,3 +181,26 @@ def test_detector_bf16_stagewise(orc, sad, dev, cfg_name, batch):
     b = boxes.cpu().numpy()
     np.testing.assert_array_equal(b[..., 8], want_b[..., 8])
     assert np.abs(b - want_b).max() <= 1e-4 * (1 + np.abs(want_b).max())
+
+
+def test_golden_extensions_gpu(sad, dev):
+    """The committed vectors of tests/golden/extensions.npz (SPEC §13-§15), without the live oracle."""
+    import os
+    from conftest import GOLDEN
+    from sad_amd import ops
+    g = np.load(os.path.join(GOLDEN, "extensions.npz"))
+    xyz, feat = g["ffps_xyz"], g["ffps_feat"]
+    np.testing.assert_array_equal(ops.ffps(_t(xyz, dev), _t(feat, dev), 64, 1.0).cpu().numpy(), g["ffps_idx_w1"])
+    np.testing.assert_array_equal(ops.ffps(_t(xyz, dev), _t(feat, dev), 64, 0.0).cpu().numpy(), g["ffps_idx_w0"])
+    layers = [(g[f"bf16_w{i}"], g[f"bf16_b{i}"]) for i in range(2)]
+    new_xyz = np.ascontiguousarray(xyz[:, :50])
+    idx = ops.ball_query(0.2, 16, _t(xyz, dev), _t(new_xyz, dev))
+    np.testing.assert_array_equal(idx.cpu().numpy(), g["bf16_idx"])
+    got = ops.PackedMLPBf16(layers, True, dev).grouped(_t(xyz, dev), _t(feat, dev), _t(new_xyz, dev), idx).cpu().numpy()
+    _close(got, g["bf16_pooled"], "golden bf16 pooled")
+    rows = np.concatenate([xyz[0, :32], feat[0, :32]], 1)
+    _close(ops.PackedMLPBf16(layers, False, dev).rows(_t(rows, dev)).cpu().numpy(), g["bf16_rows"], "golden bf16 rows")
+    keep, order, count = ops.nms_bev(_t(g["nms_boxes"], dev), 0.1, 0.2)
+    np.testing.assert_array_equal(keep.cpu().numpy(), g["nms_keep"])
+    np.testing.assert_array_equal(order.cpu().numpy(), g["nms_order"])
+    np.testing.assert_array_equal(count.cpu().numpy(), g["nms_count"])

@@ -443,3 +443,21 @@ def test_ffps_oracle_reduces_to_fps_and_is_greedy(orc):
         for i in range(1, 30):
             mind = np.minimum(mind, metric(b, idx[b, i - 1]))
             assert int(np.argmax(mind)) == idx[b, i]
+
+
+def test_golden_extensions(orc):
+    """SPEC §13-§15 operators against the committed vectors (pins the oracle against drift)."""
+    g = np.load(os.path.join(GOLDEN, "extensions.npz"))
+    np.testing.assert_array_equal(orc.ffps(g["ffps_xyz"], g["ffps_feat"], 64, 1.0), g["ffps_idx_w1"])
+    np.testing.assert_array_equal(orc.ffps(g["ffps_xyz"], g["ffps_feat"], 64, 0.0), g["ffps_idx_w0"])
+    layers = [(g[f"bf16_w{i}"], g[f"bf16_b{i}"]) for i in range(2)]
+    xyz, feat = g["ffps_xyz"], g["ffps_feat"]
+    new_xyz = np.ascontiguousarray(xyz[:, :50])
+    np.testing.assert_array_equal(orc.ball_query(0.2, 16, xyz, new_xyz), g["bf16_idx"])
+    np.testing.assert_array_equal(orc.sa_group_mlp_max_bf16(xyz, orc.bf16_round(feat), new_xyz, g["bf16_idx"], layers),
+                                  g["bf16_pooled"])
+    np.testing.assert_array_equal(orc.mlp_rows_bf16(np.concatenate([xyz[0, :32], feat[0, :32]], 1), layers), g["bf16_rows"])
+    keep, order, count = orc.nms_bev(g["nms_boxes"], 0.1, 0.2)
+    np.testing.assert_array_equal(keep, g["nms_keep"])
+    np.testing.assert_array_equal(order, g["nms_order"])
+    np.testing.assert_array_equal(count, g["nms_count"])
