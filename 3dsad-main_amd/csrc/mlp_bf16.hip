@@ -52,8 +52,9 @@ struct BfParams {
     // repeats the group's first neighbour cannot change the max).  rowtab from sad::launch_rowscan:
     // hdr[4] = {total rows, tiles, -, -}, row_start[ngroups + 1], tile_first[tiles]
     const int *rowtab;
+    const int *row_src, *row_gid;   // row map of the packed order (sad::launch_rowscan with idx): source point, group
     int ngroups;
-    int meta_off;              // byte offset of the per-tile row maps (s_srow[R], s_grp[R]) in LDS
+    int meta_off;              // byte offset of the per-tile row maps (s_pt[R], s_grp[R]) in LDS
 };
 
 __device__ __forceinline__ void atomic_max_pos(float *addr, float v) {
@@ -295,59 +296,36 @@ __global__ __launch_bounds__(BF_T) void mlp_bf16_kernel(const BfParams p) {
     const int ld0 = p.kp[0] + 8;
     const bool vec = p.feat && (C & 7) == 0 && (p.ld_feat & 7) == 0;   // 16-byte (bf16) / 32-byte (f32) chunks
 
-    int *const s_srow = reinterpret_cast<int *>(smem + p.meta_off);   // dense row (b*M + m)*S + s of tile row r, -1 = none
-    int *const s_grp = s_srow + R;                                    // its group b*M + m, -1 = none
-    int *const s_rs = s_grp + R;                                      // packed mode: row_start of the tile's groups (R + 1)
+    int *const s_pt = reinterpret_cast<int *>(smem + p.meta_off);     // source row of tile row r: point b*N + j (grouped) or
+                                                                      // plain row index; -1 = none
+    int *const s_grp = s_pt + R;                                      // its group b*M + m (plain: the row), -1 = none
     const bool packed = p.rowtab != nullptr;
     const int ntiles = packed ? p.rowtab[1] : p.tiles;
 
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const long long row0 = (long long)tile * R;
-        // ---- which dense row does tile row r stand for? ---------------------------------------
-        if (packed) {
-            const int *row_start = p.rowtab + 4;
-            const int lo = row_start[p.ngroups + 1 + tile];          // tile_first[tile]
+        // ---- which source row does tile row r stand for? --------------------------------------
+        if (packed) {        // two coalesced loads from the row map written by the scan kernels
             const int total = p.rowtab[0];
-            for (int i = tid; i <= R; i += BF_T) s_rs[i] = lo + i <= p.ngroups ? row_start[lo + i] : 0x7fffffff;
-            for (int i = tid; i < R; i += BF_T) s_grp[i] = 0;       // head marks
-            __syncthreads();
-            for (int i = tid + 1; i <= R; i += BF_T) {               // group lo + i starts at tile row s_rs[i] - row0
-                const long long pos = (long long)s_rs[i] - row0;
-                if (pos >= 0 && pos < R && lo + i < p.ngroups) s_grp[pos] = i;
-            }
-            __syncthreads();
-            // inclusive prefix max of the head marks = index (relative to lo) of the group of each row;
-            // every wave scans both 64-row halves itself (no carry exchange)
-            int carry = 0, mine = 0;
-            for (int h = 0; h * 64 < R; ++h) {
-                int v = s_grp[h * 64 + lane];
-                v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, false));   // row_shr:1
-                v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, false));   // row_shr:2
-                v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, false));   // row_shr:4
-                v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, false));   // row_shr:8
-                v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false));   // row_bcast:15
-                v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false));   // row_bcast:31
-                v = max(v, carry);
-                if (h == (tid >> 6)) mine = v;
-                carry = __builtin_amdgcn_readlane(v, 63);
-            }
-            __syncthreads();
-            if (tid < R) {
-                const long long pr = row0 + tid;
-                int g = -1, srow = -1;
-                if (pr < total) {
-                    g = lo + mine;
-                    srow = g * p.S + (int)(pr - s_rs[mine]);
-                }
-                s_grp[tid] = g;
-                s_srow[tid] = srow;
+            for (int r = tid; r < R; r += BF_T) {
+                const long long q = row0 + r;
+                const bool ok = q < total;
+                s_pt[r] = ok ? p.row_src[q] : -1;
+                s_grp[r] = ok ? (p.row_gid[q] & 0x3fffffff) : -1;
             }
         } else {
             for (int r = tid; r < R; r += BF_T) {
                 const long long row = row0 + r;
                 const bool ok = row < p.rows;
-                s_srow[r] = ok ? (int)row : -1;
-                s_grp[r] = ok ? (int)(grouped ? row / p.S : row) : -1;
+                int pt = -1, g = -1;
+                if (ok && grouped) {
+                    g = (int)(row / p.S);
+                    pt = (int)((long long)(g / p.M) * p.N + p.idx[row]);
+                } else if (ok) {
+                    pt = g = (int)row;
+                }
+                s_pt[r] = pt;
+                s_grp[r] = g;
             }
         }
         __syncthreads();
@@ -356,16 +334,10 @@ __global__ __launch_bounds__(BF_T) void mlp_bf16_kernel(const BfParams p) {
             const int C8 = C >> 3;
             for (int e = tid; e < R * C8; e += BF_T) {
                 const int r = e / C8, c8 = e - r * C8;
-                const int row = s_srow[r];
+                const int pt = s_pt[r];
                 bf16x8 v = {};
-                if (row >= 0) {
-                    size_t src;
-                    if (grouped) {
-                        const int b = s_grp[r] / p.M;
-                        src = ((size_t)b * p.N + p.idx[row]) * p.ld_feat + c8 * 8;
-                    } else {
-                        src = (size_t)row * p.ld_feat + c8 * 8;
-                    }
+                if (pt >= 0) {
+                    const size_t src = (size_t)pt * p.ld_feat + c8 * 8;
                     if (p.feat_bf16) {
                         v = *reinterpret_cast<const bf16x8 *>(reinterpret_cast<const __bf16 *>(p.feat) + src);
                     } else {
@@ -379,24 +351,14 @@ __global__ __launch_bounds__(BF_T) void mlp_bf16_kernel(const BfParams p) {
             }
         }
         for (int r = tid; r < R; r += BF_T) {
-            const int row = s_srow[r];
-            const bool ok = row >= 0;
+            const int pt = s_pt[r];
+            const bool ok = pt >= 0;
             __bf16 *x = buf0 + r * ld0;
-            size_t src = 0;
-            long long g = 0, b = 0;
-            int j = 0;
-            if (ok && grouped) {
-                g = s_grp[r];
-                b = g / p.M;
-                j = p.idx[row];
-                src = ((size_t)b * p.N + j) * p.ld_feat;
-            } else if (ok) {
-                src = (size_t)row * p.ld_feat;
-            }
+            const size_t src = ok ? (size_t)pt * p.ld_feat : 0;
             float d[3] = {0.f, 0.f, 0.f};
             if (ok && grouped) {
-                const float *q = p.xyz + ((size_t)b * p.N + j) * 3;
-                const float *cen = p.new_xyz + (size_t)g * 3;
+                const float *q = p.xyz + (size_t)pt * 3;
+                const float *cen = p.new_xyz + (size_t)s_grp[r] * 3;
                 d[0] = q[0] - cen[0];
                 d[1] = q[1] - cen[1];
                 d[2] = q[2] - cen[2];
@@ -551,7 +513,7 @@ SAD_API int sad_mlp_chain_bf16(const sad_mlp_bf16_args *a, sad_stream_t stream) 
     p.kp[a->L] = kpad(a->L, a->dims[a->L]);
     const size_t budget = 150 * 1024;
     int R = 128;
-    auto lds_of = [&](int r) { return (((size_t)r * 2 * (ldA + ldB) + 15) & ~(size_t)15) + (size_t)(3 * r + 4) * sizeof(int); };
+    auto lds_of = [&](int r) { return (((size_t)r * 2 * (ldA + ldB) + 15) & ~(size_t)15) + (size_t)(2 * r + 4) * sizeof(int); };
     if (a->geometry) {     // forced rows per tile (autotuners): 32 / 64 / 128 / 256
         SAD_REQUIRE(a->geometry == 32 || a->geometry == 64 || a->geometry == 128 || a->geometry == 256,
                     "sad_mlp_chain_bf16: geometry (rows per tile) must be 32, 64, 128 or 256");
@@ -567,7 +529,10 @@ SAD_API int sad_mlp_chain_bf16(const sad_mlp_bf16_args *a, sad_stream_t stream) 
     const long long tiles = (p.rows + R - 1) / R;       // packed mode: an upper bound, the kernel reads the real count
     if (packed) {
         p.rowtab = (const int *)a->workspace;
-        if (int e = sad::launch_rowscan(a->cnt, p.ngroups, a->S, R, (int *)a->workspace, (hipStream_t)stream)) return e;
+        if (int e = sad::launch_rowscan(a->cnt, p.ngroups, a->S, R, (int *)a->workspace, (hipStream_t)stream, 0,
+                                        a->idx, a->N, a->M)) return e;
+        p.row_src = p.rowtab + 4 + ((long long)p.ngroups + 1) + ((long long)p.ngroups * a->S / 32 + 2) + (p.ngroups / 1024 + 2);
+        p.row_gid = p.row_src + (long long)p.ngroups * a->S;
     }
     SAD_REQUIRE(tiles < (1LL << 31), "sad_mlp_chain_bf16: too many rows");
     p.tiles = (int)tiles;
