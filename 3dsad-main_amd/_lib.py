@@ -86,6 +86,7 @@ SIGNATURES = {
     "sad_mlp_pack_bf16": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.c_int,
                                         ctypes.POINTER(vp), ctypes.POINTER(vp), vp, vp]),
     "sad_mlp_chain_bf16": (ctypes.c_int, [ctypes.POINTER(MlpBf16Args), vp]),
+    "sad_mlp_chain_multi_bf16": (ctypes.c_int, [ctypes.POINTER(ctypes.POINTER(MlpBf16Args)), ctypes.c_int, vp]),
     "sad_candidates_f32": (ctypes.c_int, [vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                          ctypes.c_float, ctypes.c_float, ctypes.c_float, c_f32p,
                                          vp, vp, vp]),

@@ -284,7 +284,7 @@ __device__ __forceinline__ void run_units(const BfParams &p, int l, const __bf16
     }
 }
 
-__global__ __launch_bounds__(BF_T) void mlp_bf16_kernel(const BfParams p) {
+__device__ __forceinline__ void mlp_bf16_body(const BfParams &p, const int block, const int nblocks) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __bf16 *const buf0 = reinterpret_cast<__bf16 *>(smem);
     __bf16 *const buf1 = buf0 + p.bufA_elems;
@@ -302,7 +302,7 @@ __global__ __launch_bounds__(BF_T) void mlp_bf16_kernel(const BfParams p) {
     const bool packed = p.rowtab != nullptr;
     const int ntiles = packed ? p.rowtab[1] : p.tiles;
 
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    for (int tile = block; tile < ntiles; tile += nblocks) {
         const long long row0 = (long long)tile * R;
         // ---- which source row does tile row r stand for? --------------------------------------
         if (packed) {        // two coalesced loads from the row map written by the scan kernels
@@ -406,6 +406,26 @@ __global__ __launch_bounds__(BF_T) void mlp_bf16_kernel(const BfParams p) {
     }
 }
 
+__global__ __launch_bounds__(BF_T) void mlp_bf16_kernel(const BfParams p) {
+    mlp_bf16_body(p, blockIdx.x, gridDim.x);
+}
+
+// Several independent chains (the branches of one multi-radius stage) in one dispatch, heaviest
+// first: the light chains fill the tail of the heavy one and the launch gaps disappear.
+constexpr int BF_MULTI_MAX = 4;
+struct BfMultiParams {
+    BfParams p[BF_MULTI_MAX];
+    int first[BF_MULTI_MAX + 1];   // first block of chain i; first[n] = grid size
+    int n;
+};
+
+__global__ __launch_bounds__(BF_T) void mlp_bf16_multi_kernel(const BfMultiParams mp) {
+    int c = 0;
+    while (c + 1 < mp.n && (int)blockIdx.x >= mp.first[c + 1]) ++c;
+    c = __builtin_amdgcn_readfirstlane(c);
+    mlp_bf16_body(mp.p[c], blockIdx.x - mp.first[c], mp.first[c + 1] - mp.first[c]);
+}
+
 // W[l] f32 [cout][cin] row-major -> fragment image + padded bias.  Internal input order of layer 0
 // in grouped mode is [feat(C) ‖ xyz(3)]: internal k < C reads W column 3 + k, k = C..C+2 column k - C.
 __global__ void pack_bf16_kernel(const float *__restrict__ W, const float *__restrict__ bias, int cin, int cout,
@@ -465,7 +485,16 @@ SAD_API int sad_mlp_pack_bf16(int L, const int *dims, int first_has_xyz, const f
     return sad::check_launch("sad_mlp_pack_bf16");
 }
 
-SAD_API int sad_mlp_chain_bf16(const sad_mlp_bf16_args *a, sad_stream_t stream) {
+namespace {
+struct BfPrepared {
+    BfParams p;
+    size_t lds;
+    int grid;
+};
+}  // namespace
+
+// Validation, tile size, row-packing scan of one chain; fills `q` for the launch.
+static int prepare_bf16(const sad_mlp_bf16_args *a, sad_stream_t stream, BfPrepared &prep) {
     SAD_REQUIRE(a, "sad_mlp_chain_bf16: NULL args");
     SAD_REQUIRE(a->L >= 1 && a->L <= SAD_MAX_LAYERS && a->packed && a->out, "sad_mlp_chain_bf16: bad argument");
     SAD_REQUIRE((uintptr_t)a->packed % 16 == 0, "sad_mlp_chain_bf16: packed must be 16-byte aligned");
@@ -536,17 +565,70 @@ SAD_API int sad_mlp_chain_bf16(const sad_mlp_bf16_args *a, sad_stream_t stream) 
     }
     SAD_REQUIRE(tiles < (1LL << 31), "sad_mlp_chain_bf16: too many rows");
     p.tiles = (int)tiles;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&mlp_bf16_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-            (void)hipGetLastError();
-        attr_set = true;
-    }
     const size_t lds_now = lds_of(R);
     int per_cu = (int)((160 * 1024) / (lds_now > 0 ? lds_now : 1));
     per_cu = per_cu < 1 ? 1 : (per_cu > 4 ? 4 : per_cu);
-    const int grid = (int)(tiles < 256LL * per_cu ? tiles : 256LL * per_cu);
-    hipLaunchKernelGGL(mlp_bf16_kernel, dim3(grid), dim3(BF_T), lds_now, (hipStream_t)stream, p);
+    prep.p = p;
+    prep.lds = lds_now;
+    prep.grid = (int)(tiles < 256LL * per_cu ? tiles : 256LL * per_cu);
+    return SAD_OK;
+}
+
+static void bf16_attrs() {
+    static bool attr_set = false;
+    if (attr_set) return;
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&mlp_bf16_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void *>(&mlp_bf16_multi_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+        (void)hipGetLastError();
+    attr_set = true;
+}
+
+SAD_API int sad_mlp_chain_bf16(const sad_mlp_bf16_args *a, sad_stream_t stream) {
+    BfPrepared q;
+    if (int e = prepare_bf16(a, stream, q)) return e;
+    bf16_attrs();
+    hipLaunchKernelGGL(mlp_bf16_kernel, dim3(q.grid), dim3(BF_T), q.lds, (hipStream_t)stream, q.p);
     return sad::check_launch("sad_mlp_chain_bf16");
+}
+
+SAD_API int sad_mlp_chain_multi_bf16(const sad_mlp_bf16_args *const *args, int n, sad_stream_t stream) {
+    SAD_REQUIRE(args && n >= 1, "sad_mlp_chain_multi_bf16: need at least one chain");
+    if (n > BF_MULTI_MAX) {
+        for (int i = 0; i < n; i += BF_MULTI_MAX)
+            if (int e = sad_mlp_chain_multi_bf16(args + i, n - i < BF_MULTI_MAX ? n - i : BF_MULTI_MAX, stream)) return e;
+        return SAD_OK;
+    }
+    BfPrepared q[BF_MULTI_MAX];
+    for (int i = 0; i < n; ++i)
+        if (int e = prepare_bf16(args[i], stream, q[i])) return e;
+    bf16_attrs();
+    if (n == 1) {
+        hipLaunchKernelGGL(mlp_bf16_kernel, dim3(q[0].grid), dim3(BF_T), q[0].lds, (hipStream_t)stream, q[0].p);
+        return sad::check_launch("sad_mlp_chain_bf16");
+    }
+    int order[BF_MULTI_MAX];
+    for (int i = 0; i < n; ++i) order[i] = i;
+    auto weight = [&](int i) {
+        double m = 0;
+        for (int l = 0; l < q[i].p.L; ++l) m += (double)q[i].p.kp[l] * q[i].p.cout[l];
+        return m * (double)q[i].p.rows;
+    };
+    for (int i = 0; i < n; ++i)
+        for (int k = i + 1; k < n; ++k)
+            if (weight(order[k]) > weight(order[i])) { const int t = order[i]; order[i] = order[k]; order[k] = t; }
+    BfMultiParams mp{};
+    mp.n = n;
+    size_t lds = 0;
+    long long total = 0;
+    for (int i = 0; i < n; ++i) {
+        mp.p[i] = q[order[i]].p;
+        mp.first[i] = (int)total;
+        total += q[order[i]].grid;
+        lds = q[order[i]].lds > lds ? q[order[i]].lds : lds;
+    }
+    mp.first[n] = (int)total;
+    hipLaunchKernelGGL(mlp_bf16_multi_kernel, dim3((unsigned)total), dim3(BF_T), lds, (hipStream_t)stream, mp);
+    return sad::check_launch("sad_mlp_chain_multi_bf16");
 }

@@ -220,17 +220,11 @@ class SADDetector(nn.Module):
         cat = cats[-1]
         if cat is None:
             cat = torch.zeros((B, K, self.cluster_cat), dtype=torch.float32, device=points.device)
-        off = 0
-        if self.dtype == "f32":
-            calls = []
-            for mlp, idx, cnt in zip(self.cluster_branches, idxs, cnts):
-                calls.append((mlp, cur_xyz, cur_feat, cand, idx, cat, off, cnt))
-                off += mlp.out_channels
-            ops.grouped_multi(calls)
-        else:
-            for mlp, idx, cnt in zip(self.cluster_branches, idxs, cnts):
-                mlp.grouped(cur_xyz, cur_feat, cand, idx, out=cat, col_off=off, cnt=cnt)
-                off += mlp.out_channels
+        calls, off = [], 0
+        for mlp, idx, cnt in zip(self.cluster_branches, idxs, cnts):
+            calls.append((mlp, cur_xyz, cur_feat, cand, idx, cat, off, cnt))
+            off += mlp.out_channels
+        ops.grouped_multi(calls)
         # ---- head + decode (SPEC.md §9) -------------------------------------------------------
         if self.agg_head is not None and trace is None:
             cfeat = None

@@ -454,13 +454,17 @@ class PackedMLP:
             raise ValueError("out: col_off + C_out exceeds the buffer width")
 
 
+# bf16 chains: merge the branches of a stage into one dispatch (sad_mlp_chain_multi_bf16)?
+MERGE_BF16: bool = True
+
+
 def grouped_multi(calls) -> None:
     """Several independent fused group -> MLP -> max launches (the branches of one multi-radius
     stage) as ONE dispatch (``sad_mlp_chain_multi_f32``): the light chains fill the tail of the
     heavy one.  ``calls`` = [(PackedMLP, xyz, feat_pm, new_xyz, idx, out, col_off, cnt), ...] with
     caller-provided zero ``out`` buffers.  While autotuning, or for a single call, each chain is
     launched (and tuned) on its own."""
-    if AUTOTUNE or len(calls) < 2:
+    if AUTOTUNE or len(calls) < 2 or (not MERGE_BF16 and isinstance(calls[0][0], PackedMLPBf16)):
         for mlp, xyz, feat_pm, new_xyz, idx, out, col_off, cnt in calls:
             mlp.grouped(xyz, feat_pm, new_xyz, idx, out=out, col_off=col_off, cnt=cnt)
         return
@@ -469,9 +473,16 @@ def grouped_multi(calls) -> None:
         a, _, k = mlp._grouped_args(xyz, feat_pm, new_xyz, idx, out, col_off, cnt)
         args.append(a)
         keep.append(k)
-    arr = (ctypes.POINTER(MlpArgs) * len(args))(*[ctypes.pointer(a) for a in args])
+    bf16 = isinstance(calls[0][0], PackedMLPBf16)
+    if any(isinstance(c[0], PackedMLPBf16) != bf16 for c in calls):
+        raise TypeError("grouped_multi: all chains must be of the same class (f32 or bf16)")
     with _timed("mlp", "+".join(c[0].name for c in calls)):
-        check(lib().sad_mlp_chain_multi_f32(arr, len(args), _stream()), "sad_mlp_chain_multi_f32")
+        if bf16:
+            arr = (ctypes.POINTER(_lib.MlpBf16Args) * len(args))(*[ctypes.pointer(a) for a in args])
+            check(lib().sad_mlp_chain_multi_bf16(arr, len(args), _stream()), "sad_mlp_chain_multi_bf16")
+        else:
+            arr = (ctypes.POINTER(MlpArgs) * len(args))(*[ctypes.pointer(a) for a in args])
+            check(lib().sad_mlp_chain_multi_f32(arr, len(args), _stream()), "sad_mlp_chain_multi_f32")
 
 
 class PackedMLPBf16:
@@ -530,6 +541,12 @@ class PackedMLPBf16:
         [B,M,S] -> out[:, :, col_off:col_off+C_out] of a ZERO-initialised float32 [B,M,ld] buffer.
         With ``cnt`` ([B,M] int32 from ball_query_multi(return_counts=True)) only the leading cnt
         rows of each group are computed — the ball query's padding rows cannot change the max."""
+        a, out, _keep = self._grouped_args(xyz, feat_pm, new_xyz, idx, out, col_off, cnt)
+        self._launch(a)
+        return out
+
+    def _grouped_args(self, xyz, feat_pm, new_xyz, idx, out, col_off, cnt):
+        """Validated ``MlpBf16Args`` of a grouped call + the output tensor + tensors to keep alive."""
         if not self.first_has_xyz:
             raise RuntimeError("this PackedMLPBf16 was packed without the xyz prefix")
         xyz = _need(xyz, "xyz", torch.float32, 3)
@@ -538,6 +555,7 @@ class PackedMLPBf16:
         B, N, _ = xyz.shape
         _, M, S = idx.shape
         a = self._args()
+        keep = [xyz, new_xyz, idx]
         C = 0
         if feat_pm is not None:
             a.feat_bf16 = self._feat(feat_pm, "feat_pm")
@@ -547,6 +565,7 @@ class PackedMLPBf16:
                 feat_pm = feat_pm.contiguous()
             C = feat_pm.shape[2]
             a.feat, a.ld_feat = feat_pm.data_ptr(), feat_pm.stride(1)
+            keep.append(feat_pm)
         if self.dims[0] != C + 3:
             raise ValueError(f"MLP expects {self.dims[0] - 3} feature channels, got {C}")
         if out is None:
@@ -562,8 +581,9 @@ class PackedMLPBf16:
                 raise ValueError("cnt must be [B,M]")
             ws = torch.empty((lib().sad_mlp_workspace_bytes(B, M, S),), dtype=torch.uint8, device=xyz.device)
             a.cnt, a.workspace = cnt.data_ptr(), ws.data_ptr()
-        self._launch(a)
-        return out
+            keep += [cnt, ws]
+        a.geometry = self._geom.get((bool(a.idx), a.B, a.N, a.M, a.S, a.ld_out)) or 0
+        return a, out, keep
 
     def _launch(self, a) -> None:
         """Enqueue; with AUTOTUNE on, the first call for a shape times 64 / 128 / 256 rows per tile."""

@@ -77,17 +77,11 @@ class SAModuleMSG(nn.Module):
             keep["ball_idx"] = idxs
         if cat is None:      # ``cat``: a caller-provided ZERO [B,M,sum C_b] float32 buffer
             cat = torch.zeros((B, M, self.cat_channels), dtype=torch.float32, device=xyz.device)
-        off = 0
-        if self.dtype == "f32":      # all branches in one dispatch (ops.grouped_multi)
-            calls = []
-            for mlp, idx, cnt in zip(self.branches, idxs, cnts):
-                calls.append((mlp, xyz, feat_pm, new_xyz, idx, cat, off, cnt))
-                off += mlp.out_channels
-            ops.grouped_multi(calls)
-        else:
-            for mlp, idx, cnt in zip(self.branches, idxs, cnts):
-                mlp.grouped(xyz, feat_pm, new_xyz, idx, out=cat, col_off=off, cnt=cnt)
-                off += mlp.out_channels
+        calls, off = [], 0               # all branches in one dispatch (ops.grouped_multi)
+        for mlp, idx, cnt in zip(self.branches, idxs, cnts):
+            calls.append((mlp, xyz, feat_pm, new_xyz, idx, cat, off, cnt))
+            off += mlp.out_channels
+        ops.grouped_multi(calls)
         if self.agg is None:
             return cat
         if self.dtype == "bf16":     # a stage output that feeds another stage is stored as bf16 (SPEC §14)

@@ -182,6 +182,8 @@ def main():
     torch.cuda.synchronize()
 
     ops.BRANCH_OVERLAP = args.branch_overlap
+    if os.environ.get("SAD_NO_MERGE_BF16"):
+        ops.MERGE_BF16 = False
     tuned = None if args.no_autotune else det.autotune(points)
 
     def step():

@@ -217,6 +217,8 @@ typedef struct sad_mlp_bf16_args {
     int geometry;
 } sad_mlp_bf16_args;
 int sad_mlp_chain_bf16(const sad_mlp_bf16_args *args, sad_stream_t stream);
+/* n independent bf16 chains in one dispatch (see sad_mlp_chain_multi_f32). */
+int sad_mlp_chain_multi_bf16(const sad_mlp_bf16_args *const *args, int n, sad_stream_t stream);
 
 /* SPEC.md §8 steps 2-4.  xyz3[B,M3,3], c[B,K,6] -> cand[B,K,3], radius[B,K]; anchor[3] host. */
 int sad_candidates_f32(const float *xyz3, const float *c, int B, int M3, int K, float shift_max,
