@@ -483,7 +483,6 @@ __device__ __forceinline__ void mlp_chain_body(const MlpParams &p, const int blo
         int pass = pass_i;          // static mode: pass of this workgroup's own rows
         int qoff = pass * R;        // compact-row coordinate of row 0 of the tile in s_off's frame
         if (dyn) {
-            // s_off becomes pass-local (row 0 of the pass = 0)
             __syncthreads();
             pass = s_pass;
             const int total = p.rowtab[0];

@@ -642,44 +642,6 @@ class PackedMLPBf16:
         return out
 
 
-_BRANCH_STREAMS = {}
-
-
-def run_branches(jobs) -> None:
-    """Run independent launches (the branches of one multi-radius stage) side by side: job i goes
-    to helper stream i (job 0 stays on the current stream) behind an event, and the current stream
-    waits for all of them.  After padding removal a branch often has too few row tiles to fill 256
-    CUs, so concurrent branches fill each other's tails.  Disabled while autotuning (timings)."""
-    if len(jobs) <= 1 or AUTOTUNE or not BRANCH_OVERLAP:
-        for job in jobs:
-            job()
-        return
-    cur = torch.cuda.current_stream()
-    key = (cur.device, cur.cuda_stream)
-    pool = _BRANCH_STREAMS.get(key)
-    if pool is None or len(pool) < len(jobs) - 1:
-        pool = [torch.cuda.Stream(device=cur.device) for _ in range(len(jobs) - 1)]
-        _BRANCH_STREAMS[key] = pool
-    fork = torch.cuda.Event()
-    fork.record(cur)
-    joins = []
-    for st, job in zip(pool, jobs[1:]):
-        st.wait_event(fork)
-        with torch.cuda.stream(st):
-            job()
-            ev = torch.cuda.Event()
-            ev.record(st)
-            joins.append(ev)
-    jobs[0]()
-    for ev in joins:
-        cur.wait_event(ev)
-
-
-# Measured on MI355X (B = 32): concurrent branches slow each other down more than they fill tails
-# (7 280 -> 6 470-6 820 scenes/s), so this stays off; bench.py --branch-overlap turns it on.
-BRANCH_OVERLAP: bool = False
-
-
 def mlp_chain(x: torch.Tensor, layers, relu_mask: Optional[int] = None) -> torch.Tensor:
     """One-shot convenience: pack ``layers`` and apply them to rows x [..., C]."""
     return PackedMLP(layers, False, x.device, relu_mask).rows(x)

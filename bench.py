@@ -129,7 +129,6 @@ def main():
     ap.add_argument("--cpu-scenes", type=int, default=32)
     ap.add_argument("--no-launch-timing", action="store_true")
     ap.add_argument("--no-autotune", action="store_true", help="use the built-in geometry heuristic")
-    ap.add_argument("--branch-overlap", action="store_true", help="run MSG branches on helper streams")
     ap.add_argument("--config", choices=("kitti", "nuscenes"), default="kitti",
                     help="nuscenes = BASELINE configs[4] shape (65536-pt scenes, 4 extra channels); secondary, "
                          "use with --dtype bf16 --batch 8 --no-cpu; the headline metric is the kitti default")
@@ -181,7 +180,6 @@ def main():
     points = torch.from_numpy(make(rank * B, B, cfg.n_points)).to(dev)
     torch.cuda.synchronize()
 
-    ops.BRANCH_OVERLAP = args.branch_overlap
     if os.environ.get("SAD_NO_MERGE_BF16"):
         ops.MERGE_BF16 = False
     tuned = None if args.no_autotune else det.autotune(points)
