@@ -64,6 +64,7 @@ SIGNATURES = {
     "sad_gather_points": (ctypes.c_int, [vp, vp] + [ctypes.c_int] * 5 + [vp, vp]),
     "sad_group_points": (ctypes.c_int, [vp, vp] + [ctypes.c_int] * 6 + [vp, vp]),
     "sad_group_points_grad_f32": (ctypes.c_int, [vp, vp] + [ctypes.c_int] * 5 + [vp, vp]),
+    "sad_group_points_grad_pm_f32": (ctypes.c_int, [vp, vp] + [ctypes.c_int] * 5 + [vp, vp]),
     "sad_max_pool_s_f32": (ctypes.c_int, [vp] + [ctypes.c_int] * 4 + [vp, vp, vp]),
     "sad_max_pool_s_grad_f32": (ctypes.c_int, [vp, vp] + [ctypes.c_int] * 4 + [vp, vp]),
     "sad_ball_query_f32": (ctypes.c_int, [vp, vp, ctypes.c_float, vp] + [ctypes.c_int] * 4 + [vp, vp]),
@@ -92,6 +93,9 @@ SIGNATURES = {
                                          vp, vp, vp]),
     "sad_nms_bev_f32": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_float,
                                       vp, vp, vp, vp]),
+    "sad_nms_bev_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int]),
+    "sad_nms_bev_ws_f32": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_float,
+                                         vp, vp, vp, vp, vp]),
     "sad_decode_boxes_f32": (ctypes.c_int, [vp, vp, ctypes.c_int, ctypes.c_int, c_f32p, vp, vp]),
 }
 

@@ -21,8 +21,12 @@ def _f32(t, name, ndim):
     return t.contiguous()
 
 
-def group_points_grad(grad_out: torch.Tensor, idx: torch.Tensor, N: int) -> torch.Tensor:
-    """grad_out [B,C,M,S] (or [B,C,M] with idx [B,M]) -> grad_feat [B,C,N] (scatter-add)."""
+def group_points_grad(grad_out: torch.Tensor, idx: torch.Tensor, N: int, point_major: bool = False,
+                      via_point_major: bool = True) -> torch.Tensor:
+    """grad_out [B,C,M,S] (or [B,C,M] with idx [B,M]) -> grad_feat [B,C,N] (scatter-add), or
+    [B,N,C] with ``point_major=True``.  By default the sum is formed point-major (contiguous float
+    atomics, ~10x faster) and transposed at the end; ``via_point_major=False`` uses the direct
+    channel-major scatter."""
     if grad_out.dim() == 3:
         grad_out, idx = grad_out.unsqueeze(-1), idx.unsqueeze(-1)
     grad_out = _f32(grad_out, "grad_out", 4)
@@ -32,6 +36,11 @@ def group_points_grad(grad_out: torch.Tensor, idx: torch.Tensor, N: int) -> torc
     B, C, M, S = grad_out.shape
     if tuple(idx.shape) != (B, M, S):
         raise ValueError("idx must be [B,M,S]")
+    if point_major or via_point_major:
+        g = torch.zeros((B, N, C), dtype=torch.float32, device=grad_out.device)
+        check(lib().sad_group_points_grad_pm_f32(grad_out.data_ptr(), idx.data_ptr(), B, C, N, M, S, g.data_ptr(),
+                                                 _stream()), "sad_group_points_grad_pm_f32")
+        return g if point_major else g.transpose(1, 2).contiguous()
     g = torch.zeros((B, C, N), dtype=torch.float32, device=grad_out.device)
     check(lib().sad_group_points_grad_f32(grad_out.data_ptr(), idx.data_ptr(), B, C, N, M, S, g.data_ptr(),
                                           _stream()), "sad_group_points_grad_f32")

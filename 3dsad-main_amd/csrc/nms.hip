@@ -197,6 +197,136 @@ __global__ __launch_bounds__(THREADS) void nms_bev_kernel(const float *__restric
     }
 }
 
+// ---- three-kernel variant (caller workspace): the K x K suppression matrix is spread over the chip --
+// prep (one workgroup per scene): ranking, corners, areas -> workspace; mask (one WAVE per ranked
+// box, 16 boxes per workgroup): lane l tests box p against boxes 64k + l, the ballot is the mask
+// word; walk (one wave per scene).  Same arithmetic as nms_bev_kernel, same keep decisions.
+struct NmsWs {            // per-scene slices of the workspace
+    int *n;               // [4] (n, pad)
+    int *rank2idx;        // [K]
+    float *area;          // [K]
+    float *cx, *cy;       // [K][4]
+    unsigned long long *mask;   // [K][NMS_WORDS]
+};
+__host__ __device__ inline size_t nms_ws_scene_bytes(int K) {
+    return 16 + (size_t)K * 4 * 2 + (size_t)K * 16 * 2 + (size_t)K * NMS_WORDS * 8;
+}
+__device__ __forceinline__ NmsWs nms_ws(void *base, int scene, int K) {
+    unsigned char *q = (unsigned char *)base + (size_t)scene * nms_ws_scene_bytes(K);
+    NmsWs w;
+    w.n = (int *)q; q += 16;
+    w.rank2idx = (int *)q; q += (size_t)K * 4;
+    w.area = (float *)q; q += (size_t)K * 4;
+    w.cx = (float *)q; q += (size_t)K * 16;
+    w.cy = (float *)q; q += (size_t)K * 16;
+    w.mask = (unsigned long long *)q;
+    return w;
+}
+
+__global__ __launch_bounds__(256) void nms_prep_kernel(const float *__restrict__ boxes, int K, float score_thr,
+                                                       int32_t *__restrict__ keep, int32_t *__restrict__ order,
+                                                       void *__restrict__ wsbase) {
+    __shared__ float s_score[NMS_MAXK];
+    __shared__ int s_rank2idx[NMS_MAXK];
+    __shared__ int s_n;
+    const int tid = threadIdx.x;
+    const float *bx = boxes + (size_t)blockIdx.x * K * 9;
+    int32_t *kp = keep + (size_t)blockIdx.x * K, *od = order + (size_t)blockIdx.x * K;
+    const NmsWs w = nms_ws(wsbase, blockIdx.x, K);
+    for (int i = tid; i < K; i += 256) {
+        s_score[i] = bx[i * 9 + 7];
+        kp[i] = 0;
+        od[i] = -1;
+    }
+    if (tid == 0) s_n = 0;
+    __syncthreads();
+    int nloc = 0;
+    for (int i = tid; i < K; i += 256) {
+        const float si = s_score[i];
+        if (si >= score_thr) {
+            int r = 0;
+            for (int j = 0; j < K; ++j) {
+                const float sj = s_score[j];
+                r += (sj >= score_thr) && (sj > si || (sj == si && j < i));
+            }
+            s_rank2idx[r] = i;
+            ++nloc;
+        }
+    }
+    atomicAdd(&s_n, nloc);
+    __syncthreads();
+    const int n = s_n;
+    if (tid == 0) w.n[0] = n;
+    for (int p = tid; p < n; p += 256) {
+        const int i = s_rank2idx[p];
+        const float *b = bx + (size_t)i * 9;
+        float cx[4], cy[4];
+        box_corners(b, cx, cy);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { w.cx[p * 4 + k] = cx[k]; w.cy[p * 4 + k] = cy[k]; }
+        w.area[p] = b[3] * b[4];
+        w.rank2idx[p] = i;
+    }
+}
+
+constexpr int NMS_ROWS_PER_WG = 16;
+__global__ __launch_bounds__(256) void nms_mask_kernel(int K, float iou_thr, void *__restrict__ wsbase) {
+    __shared__ float s_poly[4 * 10 * 256];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const NmsWs w = nms_ws(wsbase, blockIdx.y, K);
+    const int n = w.n[0];
+    for (int rr = wave; rr < NMS_ROWS_PER_WG; rr += 4) {
+        const int p = blockIdx.x * NMS_ROWS_PER_WG + rr;
+        if (p >= n) continue;                                   // wave-uniform
+        float pcx[4], pcy[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { pcx[k] = w.cx[p * 4 + k]; pcy[k] = w.cy[p * 4 + k]; }
+        const float pa = w.area[p];
+        for (int k = 0; k < NMS_WORDS; ++k) {
+            unsigned long long word = 0ull;
+            if (64 * k + 63 > p && 64 * k < n) {                // some q > p in this chunk
+                const int q = 64 * k + lane;
+                bool sup = false;
+                if (q > p && q < n) {
+                    float qcx[4], qcy[4];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) { qcx[c] = w.cx[q * 4 + c]; qcy[c] = w.cy[q * 4 + c]; }
+                    const float inter = poly_clip_area<256>(pcx, pcy, qcx, qcy, s_poly + tid);
+                    float den = pa + w.area[q];
+                    den = den - inter;
+                    const float iou = den > 0.0f ? inter / den : 0.0f;
+                    sup = iou > iou_thr;
+                }
+                word = __ballot(sup);
+            }
+            if (lane == 0) w.mask[(size_t)p * NMS_WORDS + k] = word;
+        }
+    }
+}
+
+__global__ __launch_bounds__(64) void nms_walk_kernel(int K, int32_t *__restrict__ keep, int32_t *__restrict__ order,
+                                                      int32_t *__restrict__ count, void *__restrict__ wsbase) {
+    const int tid = threadIdx.x;
+    const NmsWs w = nms_ws(wsbase, blockIdx.x, K);
+    int32_t *kp = keep + (size_t)blockIdx.x * K, *od = order + (size_t)blockIdx.x * K;
+    const int n = w.n[0];
+    unsigned long long removed = 0ull;
+    int nk = 0;
+    for (int p = 0; p < n; ++p) {
+        const unsigned long long word = __shfl(removed, p >> 6, 64);
+        if (!((word >> (p & 63)) & 1ull)) {
+            if (tid == 0) {
+                const int i = w.rank2idx[p];
+                od[nk] = i;
+                kp[i] = 1;
+            }
+            ++nk;
+            if (tid < NMS_WORDS) removed |= w.mask[(size_t)p * NMS_WORDS + tid];
+        }
+    }
+    if (tid == 0) count[blockIdx.x] = nk;
+}
+
 }  // namespace
 
 SAD_API int sad_nms_bev_f32(const float *boxes, int B, int K, float iou_thr, float score_thr,
@@ -207,4 +337,22 @@ SAD_API int sad_nms_bev_f32(const float *boxes, int B, int K, float iou_thr, flo
     hipLaunchKernelGGL((nms_bev_kernel<256>), dim3(B), dim3(256), 0, (hipStream_t)stream, boxes, K, iou_thr,
                        score_thr, keep, order, count);
     return sad::check_launch("sad_nms_bev_f32");
+}
+
+SAD_API size_t sad_nms_bev_workspace_bytes(int B, int K) {
+    if (B < 1 || K < 1 || K > NMS_MAXK) return 0;
+    return (size_t)B * nms_ws_scene_bytes(K);
+}
+
+SAD_API int sad_nms_bev_ws_f32(const float *boxes, int B, int K, float iou_thr, float score_thr,
+                               int32_t *keep, int32_t *order, int32_t *count, void *workspace, sad_stream_t stream) {
+    SAD_REQUIRE(boxes && keep && order && count && workspace, "sad_nms_bev_ws_f32: NULL pointer");
+    SAD_REQUIRE(B >= 1 && B <= 65535 && K >= 1, "sad_nms_bev_ws_f32: need 1 <= B <= 65535, K >= 1");
+    SAD_REQUIRE((uintptr_t)workspace % 16 == 0, "sad_nms_bev_ws_f32: workspace must be 16-byte aligned");
+    if (K > NMS_MAXK) return sad::fail(SAD_EUNSUPPORTED, "sad_nms_bev_ws_f32: K=%d > %d", K, NMS_MAXK);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(nms_prep_kernel, dim3(B), dim3(256), 0, st, boxes, K, score_thr, keep, order, workspace);
+    hipLaunchKernelGGL(nms_mask_kernel, dim3((K + NMS_ROWS_PER_WG - 1) / NMS_ROWS_PER_WG, B), dim3(256), 0, st, K, iou_thr, workspace);
+    hipLaunchKernelGGL(nms_walk_kernel, dim3(B), dim3(64), 0, st, K, keep, order, count, workspace);
+    return sad::check_launch("sad_nms_bev_ws_f32");
 }

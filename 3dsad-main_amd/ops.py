@@ -235,10 +235,12 @@ def knn_query(k: int, xyz: torch.Tensor, new_xyz: torch.Tensor) -> torch.Tensor:
     return idx
 
 
-def nms_bev(boxes: torch.Tensor, iou_thr: float, score_thr: float = 0.0
+def nms_bev(boxes: torch.Tensor, iou_thr: float, score_thr: float = 0.0, single_kernel: bool = False
             ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
     """Rotated-box NMS in bird's-eye view (SPEC.md §13).  boxes [B,K,9] f32, K <= 512 ->
-    (keep [B,K] int32 0/1, order [B,K] int32 kept indices in rank order (-1 padded), count [B])."""
+    (keep [B,K] int32 0/1, order [B,K] int32 kept indices in rank order (-1 padded), count [B]).
+    Default: the three-kernel variant (suppression matrix spread over the chip, workspace allocated
+    here); ``single_kernel=True``: one workgroup per scene, no workspace.  Same keep decisions."""
     boxes = _need(boxes, "boxes", torch.float32, 3)
     B, K, nine = boxes.shape
     if nine != 9:
@@ -247,9 +249,15 @@ def nms_bev(boxes: torch.Tensor, iou_thr: float, score_thr: float = 0.0
     order = torch.empty((B, K), dtype=torch.int32, device=boxes.device)
     count = torch.empty((B,), dtype=torch.int32, device=boxes.device)
     with _timed("nms", f"K{K}"):
-        check(lib().sad_nms_bev_f32(boxes.data_ptr(), B, K, float(np.float32(iou_thr)),
-                                    float(np.float32(score_thr)), keep.data_ptr(), order.data_ptr(),
-                                    count.data_ptr(), _stream()), "sad_nms_bev_f32")
+        if single_kernel:
+            check(lib().sad_nms_bev_f32(boxes.data_ptr(), B, K, float(np.float32(iou_thr)),
+                                        float(np.float32(score_thr)), keep.data_ptr(), order.data_ptr(),
+                                        count.data_ptr(), _stream()), "sad_nms_bev_f32")
+        else:
+            ws = torch.empty((lib().sad_nms_bev_workspace_bytes(B, K),), dtype=torch.uint8, device=boxes.device)
+            check(lib().sad_nms_bev_ws_f32(boxes.data_ptr(), B, K, float(np.float32(iou_thr)),
+                                           float(np.float32(score_thr)), keep.data_ptr(), order.data_ptr(),
+                                           count.data_ptr(), ws.data_ptr(), _stream()), "sad_nms_bev_ws_f32")
     return keep, order, count
 
 

@@ -87,6 +87,11 @@ int sad_group_points(const void *feat, const int32_t *idx, int B, int C, int N, 
  * max_pool_s_grad: grad_out[B,C,M], arg -> grad_x[B,C,M,S]. */
 int sad_group_points_grad_f32(const float *grad_out, const int32_t *idx, int B, int C, int N, int M,
                               int S, float *grad_feat, sad_stream_t stream);
+/* Same sum into a POINT-MAJOR gradient grad_feat_pm[B,N,C] (zero / accumulate on entry): channels on
+ * the lanes, so the float atomics are 256 contiguous bytes per wave instruction (full memory-side
+ * rate, ~16x the channel-major scatter).  Transpose afterwards if a [B,C,N] gradient is needed. */
+int sad_group_points_grad_pm_f32(const float *grad_out, const int32_t *idx, int B, int C, int N,
+                                 int M, int S, float *grad_feat_pm, sad_stream_t stream);
 int sad_max_pool_s_f32(const float *x, int B, int C, int M, int S, float *out, int32_t *arg,
                        sad_stream_t stream);
 int sad_max_pool_s_grad_f32(const float *grad_out, const int32_t *arg, int B, int C, int M, int S,
@@ -233,6 +238,11 @@ int sad_decode_boxes_f32(const float *cand, const float *o, int B, int K, const 
  * in rank order, -1 padded), count[B]. */
 int sad_nms_bev_f32(const float *boxes, int B, int K, float iou_thr, float score_thr, int32_t *keep,
                     int32_t *order, int32_t *count, sad_stream_t stream);
+/* Same result with sad_nms_bev_workspace_bytes(B,K) bytes of 16-byte aligned scratch: the K x K
+ * suppression matrix is computed by B*K waves spread over the chip instead of one workgroup per scene. */
+size_t sad_nms_bev_workspace_bytes(int B, int K);
+int sad_nms_bev_ws_f32(const float *boxes, int B, int K, float iou_thr, float score_thr, int32_t *keep,
+                       int32_t *order, int32_t *count, void *workspace, sad_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -32,9 +32,12 @@ def test_group_points_grad(orc, sad, dev, B, C, N, M, S):
     xyz = rng.random((B, N, 3), dtype=np.float32)
     idx = orc.ball_query(0.2, S, xyz, np.ascontiguousarray(xyz[:, :M]))     # realistic: padded groups, heavy collisions
     gout = rng.standard_normal((B, C, M, S)).astype(np.float32)
-    got = ag.group_points_grad(_t(gout, dev), _t(idx, dev), N).cpu().numpy()
     ref, mag = _scatter_ref(gout, idx, N)
-    assert np.all(np.abs(got - ref) <= 1e-5 * mag + 1e-30)
+    for via_pm in (True, False):        # point-major atomics + transpose (default) / direct channel-major scatter
+        got = ag.group_points_grad(_t(gout, dev), _t(idx, dev), N, via_point_major=via_pm).cpu().numpy()
+        assert np.all(np.abs(got - ref) <= 1e-5 * mag + 1e-30), f"via_point_major={via_pm}"
+    got_pm = ag.group_points_grad(_t(gout, dev), _t(idx, dev), N, point_major=True).cpu().numpy()
+    assert np.all(np.abs(got_pm.transpose(0, 2, 1) - ref) <= 1e-5 * mag + 1e-30)
     # gather_points_grad = the S == 1 case
     fidx = orc.fps(xyz, M)
     g1 = rng.standard_normal((B, C, M)).astype(np.float32)

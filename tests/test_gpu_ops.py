@@ -289,6 +289,8 @@ def test_nms_bev_parity(orc, sad, dev, B, K, thr, sthr):
         bx[0, 5, 7] = bx[0, 9, 7]                           # score tie
         bx[-1, :, 7] = 0.5                                  # a scene where every score ties
     keep, order, count = ops.nms_bev(_t(bx, dev), thr, sthr)
+    k1, o1, c1 = ops.nms_bev(_t(bx, dev), thr, sthr, single_kernel=True)     # one workgroup per scene
+    assert bool((keep == k1).all()) and bool((order == o1).all()) and bool((count == c1).all())
     okeep, oorder, ocount = orc.nms_bev(bx, thr, sthr)
     np.testing.assert_array_equal(count.cpu().numpy(), ocount)
     np.testing.assert_array_equal(order.cpu().numpy(), oorder)
