@@ -81,26 +81,43 @@ __global__ __launch_bounds__(256) void pairdist_kernel(const float *__restrict__
     }
 }
 
-__device__ __forceinline__ u64 shfl_xor_u64(u64 v, int m) {
-    const unsigned lo = __shfl_xor((unsigned)v, m, 64), hi = __shfl_xor((unsigned)(v >> 32), m, 64);
-    return ((u64)hi << 32) | lo;
+template <int CTRL>
+__device__ __forceinline__ unsigned dpp_max_u32(unsigned v) {
+    const unsigned o = __builtin_amdgcn_update_dpp(0u, v, CTRL, 0xF, 0xF, false);
+    return o > v ? o : v;
+}
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v) {   // full-wave max, wave-uniform result
+    v = dpp_max_u32<0xB1>(v);    // quad_perm [1,0,3,2]
+    v = dpp_max_u32<0x4E>(v);    // quad_perm [2,3,0,1]
+    v = dpp_max_u32<0x141>(v);   // row_half_mirror
+    v = dpp_max_u32<0x140>(v);   // row_mirror
+    unsigned o = __builtin_amdgcn_update_dpp(v, v, 0x142, 0xA, 0xF, false);   // row_bcast:15
+    v = o > v ? o : v;
+    o = __builtin_amdgcn_update_dpp(v, v, 0x143, 0xC, 0xF, false);            // row_bcast:31
+    v = o > v ? o : v;
+    return __builtin_amdgcn_readlane(v, 63);
 }
 
+// The chain per step: one coalesced row of the matrix, min, per-thread best, a two-phase 32-bit DPP
+// wave max (distance bits, then ~index among the ties), one LDS atomic max per wave into a rotating
+// slot, one barrier, one broadcast read.
 template <int PPT>
 __global__ __launch_bounds__(1024) void fps_dmat_kernel(const float *__restrict__ dmat, int N, int M,
                                                         int *__restrict__ idx_out) {
-    __shared__ u64 s_key[2][16];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ u64 s_gkey[3];
+    const int tid = threadIdx.x, lane = tid & 63;
     const float *D = dmat + (size_t)blockIdx.x * N * N;
     int *out = idx_out + (size_t)blockIdx.x * M;
     float md[PPT];
 #pragma unroll
     for (int k = 0; k < PPT; ++k) md[k] = tid + k * 1024 < N ? __builtin_inff() : -1.0f;   // padding never wins
     if (tid == 0) out[0] = 0;
-    int last = 0;
+    if (tid < 3) s_gkey[tid] = 0ull;
+    __syncthreads();
+    int last = 0, b3 = 1;
     for (int i = 1; i < M; ++i) {
         const float *row = D + (size_t)last * N;
-        u64 best = 0;
+        unsigned bhi = 0u, blo = 0u;        // key = (distance bits, ~index); real distances are >= +0
 #pragma unroll
         for (int k = 0; k < PPT; ++k) {
             const int j = tid + k * 1024;
@@ -108,24 +125,23 @@ __global__ __launch_bounds__(1024) void fps_dmat_kernel(const float *__restrict_
                 const float d = row[j];
                 const float m = md[k] < d ? md[k] : d;
                 md[k] = m;
-                const u64 key = ((u64)__builtin_bit_cast(unsigned, m) << 32) | (unsigned)(~(unsigned)j);
-                best = key > best ? key : best;
+                const unsigned hi = __builtin_bit_cast(unsigned, m), lo = ~(unsigned)j;
+                const bool better = hi > bhi || (hi == bhi && lo > blo);
+                bhi = better ? hi : bhi;
+                blo = better ? lo : blo;
             }
         }
-        for (int off = 32; off >= 1; off >>= 1) {
-            const u64 o = shfl_xor_u64(best, off);
-            best = o > best ? o : best;
+        const unsigned whi = wave_max_u32(bhi);
+        const unsigned wlo = wave_max_u32(bhi == whi ? blo : 0u);
+        const int b3n = b3 == 2 ? 0 : b3 + 1;
+        if (lane == 0) {
+            atomicMax(&s_gkey[b3], ((u64)whi << 32) | wlo);
+            if (tid == 0) s_gkey[b3n] = 0ull;
         }
-        const int buf = i & 1;
-        if (lane == 0) s_key[buf][wave] = best;
         __syncthreads();
-        u64 g = s_key[buf][lane & 15];
-        for (int off = 8; off >= 1; off >>= 1) {
-            const u64 o = shfl_xor_u64(g, off);
-            g = o > g ? o : g;
-        }
-        last = (int)(~(unsigned)g);
-        last = __builtin_amdgcn_readfirstlane(last);
+        const u64 g = s_gkey[b3];
+        last = __builtin_amdgcn_readfirstlane((int)(~(unsigned)g));
+        b3 = b3n;
         if (tid == 0) out[i] = last;
     }
 }
