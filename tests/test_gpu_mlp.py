@@ -393,3 +393,26 @@ def test_every_geometry_code_is_bit_identical(orc, sad, dev):
     finally:
         _lib.set_option("mlp_force", 0)
     assert ran >= 20, f"only {ran} geometries ran"
+
+
+@pytest.mark.parametrize("mlp", [[16, 16, 32], [32, 32, 64]])
+def test_valu_kernel_parity(orc, sad, dev, mlp):
+    """geometry 1 = the row-per-lane vector-ALU kernel for the two narrow SA1 chain shapes (an
+    autotune candidate): same fmaf chains, bit-identical to the oracle, with and without counts."""
+    from sad_amd import _lib, ops, synth
+    rng = np.random.default_rng(sum(mlp))
+    B, N, M, S = 2, 3000, 400, 32 if mlp[0] == 16 else 64
+    xyz = rng.random((B, N, 3), dtype=np.float32)
+    feat = rng.random((B, N, 1), dtype=np.float32)
+    new_xyz = np.ascontiguousarray(xyz[:, :M])
+    idxs, cnts = ops.ball_query_multi([0.08], [S], _t(xyz, dev), _t(new_xyz, dev), return_counts=True)
+    layers = synth.make_mlp_weights([4] + mlp, rng)
+    want = orc.sa_group_mlp_max(xyz, feat, new_xyz, idxs[0].cpu().numpy(), layers)
+    net = ops.PackedMLP(layers, True, dev)
+    _lib.set_option("mlp_force", 1)
+    try:
+        got = net.grouped(_t(xyz, dev), _t(feat, dev), _t(new_xyz, dev), idxs[0], cnt=cnts[0]).cpu().numpy()
+        got2 = net.grouped(_t(xyz, dev), _t(feat, dev), _t(new_xyz, dev), idxs[0]).cpu().numpy()
+    finally:
+        _lib.set_option("mlp_force", 0)
+    assert np.array_equal(got, want) and np.array_equal(got2, want)
