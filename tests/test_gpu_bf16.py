@@ -204,3 +204,34 @@ def test_golden_extensions_gpu(sad, dev):
     np.testing.assert_array_equal(keep.cpu().numpy(), g["nms_keep"])
     np.testing.assert_array_equal(order.cpu().numpy(), g["nms_order"])
     np.testing.assert_array_equal(count.cpu().numpy(), g["nms_count"])
+
+
+def test_bf16_rows_per_tile_geometries_agree(orc, sad, dev):
+    """The rows-per-tile geometries the bf16 autotuner tries (32..256) give identical bits (a row's
+    result does not depend on its tile), packed and dense; geometries that do not fit LDS are refused."""
+    import ctypes
+    import torch
+    from sad_amd import ops, synth, _lib
+    rng = np.random.default_rng(256)
+    B, N, M, S, C = 2, 2000, 150, 32, 16
+    xyz = rng.random((B, N, 3), dtype=np.float32)
+    feat = orc.bf16_round(rng.normal(size=(B, N, C)).astype(np.float32))
+    new_xyz = np.ascontiguousarray(xyz[:, :M])
+    idxs, cnts = ops.ball_query_multi([0.12], [S], _t(xyz, dev), _t(new_xyz, dev), return_counts=True)
+    layers = synth.make_mlp_weights([C + 3, 32, 64], rng)
+    net = ops.PackedMLPBf16(layers, True, dev)
+    ref = None
+    for geom in (0, 32, 64, 128, 256):
+        for cnt in (None, cnts[0]):
+            a, out, keep = net._grouped_args(_t(xyz, dev), _t(feat, dev).bfloat16(), _t(new_xyz, dev), idxs[0], None, 0, cnt)
+            a.geometry = geom
+            rc = _lib.lib().sad_mlp_chain_bf16(ctypes.byref(a), torch.cuda.current_stream().cuda_stream)
+            assert rc == 0, _lib.lib().sad_last_error()
+            got = out.cpu().numpy()
+            if ref is None:
+                ref = got
+                _close(got, orc.sa_group_mlp_max_bf16(xyz, feat, new_xyz, idxs[0].cpu().numpy(), layers), "geometry 0")
+            assert np.array_equal(got, ref), f"geometry {geom} cnt={'yes' if cnt is not None else 'no'}"
+    a, out, keep = net._grouped_args(_t(xyz, dev), _t(feat, dev).bfloat16(), _t(new_xyz, dev), idxs[0], None, 0, None)
+    a.geometry = 100
+    assert _lib.lib().sad_mlp_chain_bf16(ctypes.byref(a), torch.cuda.current_stream().cuda_stream) == -1
