@@ -449,3 +449,24 @@ def test_random_ball_query_all_kernels(orc, sad, dev):
             r2 = (rad * rad) if np.ndim(rad) == 0 else (rad * rad)[..., None]
             wc = np.minimum((d2 < r2).sum(-1), s)
             np.testing.assert_array_equal(gc.cpu().numpy(), wc)
+
+
+def test_fps_cell_geometries_agree(orc, sad, dev):
+    """Every (waves x slots) geometry of the cell-bucket kernel that can hold the scene returns the
+    oracle's indices; one that cannot is refused (SAD_EINVAL), never wrong."""
+    from sad_amd import _lib, ops
+    rng = np.random.default_rng(1616)
+    cases = {16384: (1616, 832), 5000: (816, 1608, 432, 1616, 832), 2048: (408, 804, 416, 232, 132, 216)}
+    try:
+        for N, geos in cases.items():
+            xyz = rng.normal(size=(2, N, 3)).astype(np.float32)
+            xyz[1] = np.round(xyz[1] * 3) / 3          # lattice: ties
+            want = orc.fps(xyz, 300)
+            for g in geos:
+                _lib.set_option("fps_threads", g)
+                np.testing.assert_array_equal(ops.fps(_t(xyz, dev), 300).cpu().numpy(), want, err_msg=f"N={N} geometry {g}")
+        _lib.set_option("fps_threads", 404)            # 4 waves x 4 slots x 64 = 1024 points < 16384
+        with pytest.raises(RuntimeError):
+            ops.fps(_t(rng.normal(size=(1, 16384, 3)).astype(np.float32), dev), 10)
+    finally:
+        _lib.set_option("fps_threads", 0)
