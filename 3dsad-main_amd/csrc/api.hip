@@ -32,6 +32,7 @@ SAD_API int sad_set_option(const char *key, int value) {
     if (!strcmp(key, "mlp_dedup_f")) { sad::g_opt[sad::OPT_MLP_DEDUP_F] = value; return SAD_OK; }
     if (!strcmp(key, "mlp_nodedup")) { sad::g_opt[sad::OPT_MLP_NODEDUP] = value; return SAD_OK; }
     if (!strcmp(key, "mlp_static")) { sad::g_opt[sad::OPT_MLP_STATIC] = value; return SAD_OK; }
+    if (!strcmp(key, "mlp_noxcd")) { sad::g_opt[sad::OPT_MLP_NOXCD] = value; return SAD_OK; }   // 1 = plain chunk order
     if (!strcmp(key, "mlp_dyn_slots")) { sad::g_opt[sad::OPT_MLP_DYN_SLOTS] = value; return SAD_OK; }   // workgroups per CU of the global-packing grid
     if (!strcmp(key, "group_variant")) { sad::g_opt[sad::OPT_GROUP_VARIANT] = value; return SAD_OK; }   // 1 = L2-gather kernel only
     if (!strcmp(key, "bq_variant")) { sad::g_opt[sad::OPT_BQ_VARIANT] = value; return SAD_OK; }

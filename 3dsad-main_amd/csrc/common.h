@@ -17,7 +17,7 @@ int launch_rowscan(const int32_t *cnt, int ngroups, int S, int R, int *tab, hipS
                    const int32_t *idx = nullptr, int N = 0, int M = 1);
 int launch_fps_cellg(const float *xyz, int B, int N, int M, int32_t *idx, void *workspace, hipStream_t st);
 int launch_fps_bucket(const float *xyz, int B, int N, int M, int32_t *idx, void *workspace, hipStream_t st);
-enum { OPT_FPS_DPP = 0, OPT_MLP_RW = 1, OPT_MLP_BUDGET_KB = 2, OPT_BQ_VARIANT = 3, OPT_FPS_VARIANT = 4, OPT_MLP_FORCE = 5, OPT_MLP_DEDUP_F = 6, OPT_MLP_NODEDUP = 7, OPT_FPS_THREADS = 8, OPT_MLP_STATIC = 9, OPT_GROUP_VARIANT = 10, OPT_MLP_DYN_SLOTS = 11, OPT_COUNT };
+enum { OPT_FPS_DPP = 0, OPT_MLP_RW = 1, OPT_MLP_BUDGET_KB = 2, OPT_BQ_VARIANT = 3, OPT_FPS_VARIANT = 4, OPT_MLP_FORCE = 5, OPT_MLP_DEDUP_F = 6, OPT_MLP_NODEDUP = 7, OPT_FPS_THREADS = 8, OPT_MLP_STATIC = 9, OPT_GROUP_VARIANT = 10, OPT_MLP_DYN_SLOTS = 11, OPT_MLP_NOXCD = 12, OPT_COUNT };
 
 inline int fail(int code, const char *fmt, ...) {
     char buf[480];

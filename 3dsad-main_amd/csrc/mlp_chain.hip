@@ -47,6 +47,9 @@ struct MlpParams {
     int relu_mask;
     int ld_out, col_off;
     int wn_shift;          // WN = 1 << wn_shift
+    int xcd_nb;            // > 0 (static packing / plain rows): number of work chunks; workgroup L takes chunk
+                           //   (L % 8) * ceil(nb / 8) + L / 8, so the chunks an XCD works on are one contiguous
+                           //   range of scenes and its L2 holds only their points / features / indices
     int flex;              // 1: (output tile, row tile) items of a layer are dealt round-robin to ALL waves
                            //    (RW == 1): no wave idles in a layer with fewer than WN output tiles
     int kc;                // layer-0 k-chunk (multiple of 8); == kp[0] when the whole input fits
@@ -386,8 +389,14 @@ __device__ __forceinline__ void atomic_max_pos(float *addr, float v) {
 }
 
 template <int W, int RW, int CW = 1>
-__device__ __forceinline__ void mlp_chain_body(const MlpParams &p, const int block) {
+__device__ __forceinline__ void mlp_chain_body(const MlpParams &p, const int block_in) {
     static_assert(CW == 1 || RW == 1, "two output tiles per wave only with one row tile");
+    int block = block_in;
+    if (p.xcd_nb > 0) {                       // XCD-aware chunk order (workgroups go to XCDs round-robin)
+        const int per = (p.xcd_nb + 7) >> 3;
+        block = (block_in & 7) * per + (block_in >> 3);
+        if (block >= p.xcd_nb) return;        // padding workgroup (uniform exit, before any barrier)
+    }
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -1273,6 +1282,10 @@ static int prepare_chain(const sad_mlp_args *a, sad_stream_t stream, Prepared &q
     SAD_REQUIRE(nblocks < (1LL << 31), "sad_mlp_chain_f32: too many workgroups");
     if (W == 16 && RW == 4) return sad::fail(SAD_EUNSUPPORTED, "sad_mlp_chain_f32: 16 waves support RW 1 or 2");
     q.p = p; q.lds = lds; q.nblocks = nblocks; q.W = W; q.RW = RW; q.CW = (flex_code & 2) ? 2 : 1;
+    if (!grid_dyn && !sad::get_option(sad::OPT_MLP_NOXCD)) {       // static chunks: XCD-aware order, grid padded to 8 * ceil(nb / 8)
+        q.p.xcd_nb = (int)nblocks;
+        q.nblocks = ((nblocks + 7) / 8) * 8;
+    }
     return SAD_OK;
 }
 
@@ -1372,7 +1385,7 @@ SAD_API int sad_mlp_chain_multi_f32(const sad_mlp_args *const *args, int n, sad_
         mp.rw[i] = s.RW;
         mp.cw[i] = s.CW;
         mp.first[i] = (int)total;
-        total += s.nblocks;
+        total += (s.nblocks + 7) / 8 * 8;          // chain starts stay multiples of 8 (XCD-aware chunk order)
         lds = s.lds > lds ? s.lds : lds;
         rwmax = s.RW > rwmax ? s.RW : rwmax;
     }

@@ -47,7 +47,7 @@ const char *sad_last_error(void);
  *   fps_dpp      1 = DPP reductions in the pair kernel
  *   bq_variant   reserved (grid vs scan is the caller's choice: sad_ball_query_grid_f32 / sad_ball_query_multi_f32)
  *   group_variant 1 = L2-gather group_points kernel only (no LDS staging)
- *   mlp_rw, mlp_budget_kb, mlp_force, mlp_dedup_f, mlp_nodedup, mlp_static, mlp_dyn_slots: f32 chain geometry overrides
+ *   mlp_rw, mlp_budget_kb, mlp_force, mlp_dedup_f, mlp_nodedup, mlp_static, mlp_dyn_slots, mlp_noxcd: f32 chain geometry overrides
  *                (see sad_mlp_args.geometry; mlp_nodedup = 1 computes the padding rows too) */
 int sad_set_option(const char *key, int value);
 
