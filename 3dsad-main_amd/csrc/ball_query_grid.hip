@@ -156,11 +156,16 @@ constexpr int GQ_CPW = 4;     // centroids per wave, processed one after the oth
 template <int NR>
 __global__ __launch_bounds__(GQ_WAVES * 64) void grid_query_kernel(const float *__restrict__ new_xyz,
                                                                    const char *__restrict__ ws,
-                                                                   GQParams prm, int N, int M) {
+                                                                   GQParams prm, int N, int M, int B, int nbx) {
     extern __shared__ unsigned bm_all[];        // GQ_WAVES * NR * (NWP + 64) words, zero between centroids
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int b = blockIdx.y;
+    // XCD-aware order: workgroups go to the 8 XCDs round-robin; all centroid blocks of scene
+    // xcd + 8*i run on one XCD, so its L2 holds that scene's grid records once
+    const int slot = blockIdx.x >> 3;
+    const int b = (blockIdx.x & 7) + 8 * (slot / nbx);
+    const int bx = slot - (slot / nbx) * nbx;
+    if (b >= B) return;
     const int NW = (N + 31) >> 5;               // bitmap words
     int wshift = 0;                             // words per lane in the scan: 2^wshift (<= 32 for N <= 65536)
     while ((64 << wshift) < NW) ++wshift;
@@ -180,7 +185,7 @@ __global__ __launch_bounds__(GQ_WAVES * 64) void grid_query_kernel(const float *
     for (int w = lane; w < NR * (NWP + 64); w += 64) bm[w] = 0u;
 
     for (int cc = 0; cc < GQ_CPW; ++cc) {
-        const int m = (blockIdx.x * GQ_WAVES + wave) * GQ_CPW + cc;
+        const int m = (bx * GQ_WAVES + wave) * GQ_CPW + cc;
         if (m >= M) break;                      // wave-uniform
         const float *q = new_xyz + ((size_t)b * M + m) * 3;
         const float cx = q[0], cy = q[1], cz = q[2];
@@ -273,8 +278,9 @@ void launch_query(const float *new_xyz, const char *ws, const GQParams &prm, int
     int WPL = 1;
     while (64 * WPL < NW) WPL <<= 1;
     const size_t lds = sizeof(unsigned) * (size_t)GQ_WAVES * NR * (WPL * 64 + 64);
-    dim3 grid((M + GQ_WAVES * GQ_CPW - 1) / (GQ_WAVES * GQ_CPW), B);
-    hipLaunchKernelGGL((grid_query_kernel<NR>), grid, dim3(GQ_WAVES * 64), lds, st, new_xyz, ws, prm, N, M);
+    const int nbx = (M + GQ_WAVES * GQ_CPW - 1) / (GQ_WAVES * GQ_CPW);
+    const long long nwg = 8LL * ((B + 7) / 8) * nbx;
+    hipLaunchKernelGGL((grid_query_kernel<NR>), dim3((unsigned)nwg), dim3(GQ_WAVES * 64), lds, st, new_xyz, ws, prm, N, M, B, nbx);
 }
 
 }  // namespace
