@@ -33,6 +33,32 @@ def all_gather_boxes(local_boxes: torch.Tensor, group=None) -> torch.Tensor:
     return out
 
 
+class AsyncBoxGather:
+    """``post`` hook for ``SADDetector.submit``: the all_gather of a step's boxes runs on its own
+    stream behind an event, so the compute streams never wait for the other ranks — a straggler
+    delays only the collective, not the next batch's kernels.  The returned tensor is valid once
+    the communication stream (``.stream``) has been synchronised (``wait()``)."""
+
+    def __init__(self, device, group=None):
+        self.stream = torch.cuda.Stream(device=device)
+        self.group = group
+
+    def __call__(self, local_boxes: torch.Tensor) -> torch.Tensor:
+        if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(self.group) == 1:
+            return local_boxes
+        cur = torch.cuda.current_stream()
+        ev = torch.cuda.Event()
+        ev.record(cur)
+        with torch.cuda.stream(self.stream):
+            self.stream.wait_event(ev)
+            out = all_gather_boxes(local_boxes, self.group)
+        local_boxes.record_stream(self.stream)
+        return out
+
+    def wait(self) -> None:
+        self.stream.synchronize()
+
+
 def run_sharded(forward: Callable[[torch.Tensor], torch.Tensor], points: torch.Tensor,
                 group=None) -> torch.Tensor:
     """``points`` [B,N,D] is the GLOBAL batch (same on every rank, or at least this rank's slice

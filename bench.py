@@ -144,7 +144,7 @@ def main():
     import sad_amd  # noqa: F401
     from sad_amd import config, ops, synth
     from sad_amd.detector import SADDetector
-    from sad_amd.dist import all_gather_boxes
+    from sad_amd.dist import AsyncBoxGather
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -175,6 +175,7 @@ def main():
     det = SADDetector(cfg, weights, dev, overlap_fps=not args.no_overlap, n_fps_streams=args.fps_streams,
                       n_main_streams=args.main_streams, dtype=args.dtype)
     PEAK = PEAK_MFMA_F32_TFLOPS if args.dtype == "f32" else PEAK_MFMA_BF16_TFLOPS
+    gather = AsyncBoxGather(dev)       # the step's one collective, off the compute streams
     B = args.batch
     make = synth.make_batch if args.config == "kitti" else synth.make_nuscenes_batch
     points = torch.from_numpy(make(rank * B, B, cfg.n_points)).to(dev)
@@ -185,7 +186,7 @@ def main():
     tuned = None if args.no_autotune else det.autotune(points)
 
     def step():
-        out, _ = det.submit(points, post=all_gather_boxes)
+        out, _ = det.submit(points, post=gather)
         return out
 
     for _ in range(args.warmup):
