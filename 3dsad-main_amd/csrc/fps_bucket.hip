@@ -491,10 +491,12 @@ __global__ __launch_bounds__(256) void fps_records_kernel(const float *__restric
     }
 }
 
+template <int PPT>      // slots per wave: 64 (up to 65 536 points) or 16 (up to 16 384 points, ~60 VGPRs)
 __global__ __launch_bounds__(1024) void fps_cellg_kernel(const float4 *__restrict__ rec_in, int N, int NP, int M,
                                                          int *__restrict__ idx_out) {
-    constexpr int NW = 16, PPT = 64;
-    typedef float fvec32 __attribute__((ext_vector_type(32)));
+    constexpr int NW = 16;
+    constexpr int VW = PPT < 32 ? PPT : 32;
+    typedef float fvec32 __attribute__((ext_vector_type(VW)));
     __shared__ u64 s_gkey[3];
     __shared__ __attribute__((aligned(16))) float s_wxyz[2][16][4];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -511,7 +513,7 @@ __global__ __launch_bounds__(1024) void fps_cellg_kernel(const float4 *__restric
         const int pos = (k * NW + wave) * 64 + lane;       // < NP by construction
         const bool real = pos < N;
         const float4 r = rec[pos];
-        if (k < 32) md0[k] = real ? __builtin_inff() : 0.f; else md1[k - 32] = real ? __builtin_inff() : 0.f;
+        if (k < 32) md0[k & (VW - 1)] = real ? __builtin_inff() : 0.f; else md1[k & (VW - 1)] = real ? __builtin_inff() : 0.f;
         float lo[3] = {real ? r.x : 3.0e38f, real ? r.y : 3.0e38f, real ? r.z : 3.0e38f};
         float hi[3] = {real ? r.x : -3.0e38f, real ? r.y : -3.0e38f, real ? r.z : -3.0e38f};
 #pragma unroll
@@ -558,8 +560,8 @@ __global__ __launch_bounds__(1024) void fps_cellg_kernel(const float4 *__restric
                 const unsigned n = __builtin_bit_cast(unsigned, r.w);
                 const float d = sad::d2f(r.x, r.y, r.z, cx, cy, cz);
                 float m;
-                if (k < 32) { m = __builtin_fminf(md0[k], d); md0[k] = m; }
-                else { m = __builtin_fminf(md1[k - 32], d); md1[k - 32] = m; }
+                if (PPT <= 32 || k < 32) { m = __builtin_fminf(md0[k & (VW - 1)], d); md0[k & (VW - 1)] = m; }
+                else { m = __builtin_fminf(md1[k & (VW - 1)], d); md1[k & (VW - 1)] = m; }
                 const unsigned mb = __builtin_bit_cast(unsigned, m);
                 const unsigned hi = wave_max_u32_bcast(mb);
                 const unsigned long long tie = __ballot(mb == hi);
@@ -627,13 +629,14 @@ int launch_fps_cellg(const float *xyz, int B, int N, int M, int32_t *idx, void *
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
         attr_set = true;
     }
-    constexpr int NP = 65536;
+    const int NP = N <= 16384 ? 16384 : 65536;
     int *perm = (int *)workspace;
     const size_t off = (((size_t)B * N * sizeof(int)) + 15) & ~(size_t)15;
     float4 *rec = (float4 *)((unsigned char *)workspace + off);
     hipLaunchKernelGGL(fps_sort_kernel, dim3(B), dim3(SORT_T), sizeof(int) * SORT_CELLS, st, xyz, N, perm);
     hipLaunchKernelGGL(fps_records_kernel, dim3(64, B), dim3(256), 0, st, xyz, perm, N, NP, rec);
-    hipLaunchKernelGGL(fps_cellg_kernel, dim3(B), dim3(1024), 0, st, rec, N, NP, M, idx);
+    if (NP == 16384) hipLaunchKernelGGL((fps_cellg_kernel<16>), dim3(B), dim3(1024), 0, st, rec, N, NP, M, idx);
+    else hipLaunchKernelGGL((fps_cellg_kernel<64>), dim3(B), dim3(1024), 0, st, rec, N, NP, M, idx);
     return check_launch("sad_fps_f32 (cell, global records)");
 }
 
