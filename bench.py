@@ -264,7 +264,7 @@ def main():
                 if k == "mlp":
                     iso_name[n] = iso_name.get(n, 0.0) + e0.elapsed_time(e1) / 5
             traffic = None
-            tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_v10_pmc_traffic.json")
+            tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_v12_pmc_traffic.json")
             if args.dtype == "f32" and args.config == "kitti" and os.path.exists(tpath):
                 # HBM bytes of the same launches from the committed rocprofv3 --pmc passes (bench.py cannot
                 # collect PMC counters itself): corrected FETCH_SIZE + WRITE_SIZE, per step like `achieved`
@@ -274,8 +274,8 @@ def main():
                 "kernel": f"{'mlp_chain_kernel' if args.dtype == 'f32' else 'mlp_bf16_kernel'} ({n_mlp} launches per step, summed)",
                 "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK,
                 "unit": "TFLOP/s", "frac": round(ach / PEAK, 4), "traffic": traffic,
-                "traffic_note": "bytes per step from profiles/r01_v10_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, "
-                                "17 launches summed); 1.4 GB per 2.8 ms = 0.5 TB/s: the kernel is MFMA-bound, not HBM-bound",
+                "traffic_note": "bytes per step from profiles/r01_v12_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, "
+                                "the step's MLP dispatches summed); ~1.1 GB per 2.8 ms = 0.4 TB/s: the kernel is MFMA-bound, not HBM-bound",
                 "flop_per_step": exec_flops, "ms_per_step": round(mlp_ms, 3), "sampled_steps": tsteps,
                 "note": "durations are HIP-event intervals on the launching stream inside the timed region, where "
                         "two main streams run consecutive batches side by side (kernels share the chip, so "
