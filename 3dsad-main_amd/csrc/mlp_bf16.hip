@@ -55,6 +55,7 @@ struct BfParams {
     const int *row_src, *row_gid;   // row map of the packed order (sad::launch_rowscan with idx): source point, group
     int ngroups;
     int meta_off;              // byte offset of the per-tile row maps (s_pt[R], s_grp[R]) in LDS
+    int noxcd;                 // A/B switch (option mlp_noxcd): plain tile stride
 };
 
 __device__ __forceinline__ void atomic_max_pos(float *addr, float v) {
@@ -302,7 +303,16 @@ __device__ __forceinline__ void mlp_bf16_body(const BfParams &p, const int block
     const bool packed = p.rowtab != nullptr;
     const int ntiles = packed ? p.rowtab[1] : p.tiles;
 
-    for (int tile = block; tile < ntiles; tile += nblocks) {
+    // XCD-aware tile order: workgroups go to the 8 XCDs round-robin, so XCD x (workgroups with
+    // L % 8 == x) strides through the x-th eighth of the tiles — its L2 serves one contiguous range of
+    // scenes (points, features, indices) while concurrently running workgroups still work on
+    // neighbouring tiles.  Needs a grid that is a multiple of 8 (otherwise the plain stride).
+    const bool xcd = (nblocks & 7) == 0 && !p.noxcd;
+    const int t8 = xcd ? (ntiles + 7) >> 3 : ntiles;                 // tiles per XCD range
+    const int t_lo = xcd ? (block & 7) * t8 : 0;
+    const int t_hi = t_lo + t8 < ntiles ? t_lo + t8 : ntiles;
+    const int t_step = xcd ? nblocks >> 3 : nblocks;
+    for (int tile = t_lo + (xcd ? block >> 3 : block); tile < t_hi; tile += t_step) {
         const long long row0 = (long long)tile * R;
         // ---- which source row does tile row r stand for? --------------------------------------
         if (packed) {        // two coalesced loads from the row map written by the scan kernels
@@ -568,6 +578,7 @@ static int prepare_bf16(const sad_mlp_bf16_args *a, sad_stream_t stream, BfPrepa
     const size_t lds_now = lds_of(R);
     int per_cu = (int)((160 * 1024) / (lds_now > 0 ? lds_now : 1));
     per_cu = per_cu < 1 ? 1 : (per_cu > 4 ? 4 : per_cu);
+    p.noxcd = sad::get_option(sad::OPT_MLP_NOXCD);
     prep.p = p;
     prep.lds = lds_now;
     prep.grid = (int)(tiles < 256LL * per_cu ? tiles : 256LL * per_cu);
