@@ -21,6 +21,7 @@ __global__ __launch_bounds__(256) void group_grad_kernel(const float *__restrict
     const int t = blockIdx.x * 256 + threadIdx.x;
     if (t >= MS) return;
     const int j = idx[(size_t)b * MS + t];
+    if ((unsigned)j >= (unsigned)N) return;   // out-of-range / negative index: contributes nothing (both variants agree)
 #pragma unroll
     for (int cc = 0; cc < CH; ++cc) {
         const int c = c0 + cc;
@@ -50,7 +51,7 @@ __global__ __launch_bounds__(256) void group_grad_pm_kernel(const float *__restr
     const int c = c0 + lane;
     for (int tt = wave; tt < 64; tt += 4) {            // lanes along channels: contiguous atomics
         const int j = sidx[tt];
-        if (j < 0 || c >= C) continue;
+        if ((unsigned)j >= (unsigned)N || c >= C) continue;   // padding slot (-1) or out-of-range index
         const float g = tile[lane][tt];
         if (g != 0.f) atomicAdd(gfeat_pm + ((size_t)b * N + j) * C + c, g);
     }

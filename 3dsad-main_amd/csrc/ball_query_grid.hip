@@ -80,17 +80,38 @@ __global__ __launch_bounds__(BUILD_T) void grid_build_kernel(const float *__rest
             hi[d] = red[3 + d][w] > hi[d] ? red[3 + d][w] : hi[d];
         }
     // 2. grid geometry (identical in every thread): double the cell edge until the grid fits
+    // Non-finite coordinates are undefined behaviour for the RESULT (SPEC.md §3), never for memory:
+    // an extent that is not a finite non-negative number (Inf / NaN input, or no finite point at all)
+    // selects a one-cell grid — every query then tests every point, like the scan kernel — and the
+    // doubling loop is bounded, so the kernel neither spins nor leaves its tables.
+    bool sane = true;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        const float e = hi[d] - lo[d];
+        sane = sane && (e >= 0.f) && (e < 1.0e30f);
+    }
+    sane = sane && (cs_min > 0.f) && (cs_min < 1.0e30f);
     float cs = cs_min;
-    int gx, gy, gz;
-    for (;;) {
+    int gx = 1, gy = 1, gz = 1;
+    for (int it = 0; sane; ++it) {
         const float inv = 1.0f / cs;
-        gx = (int)((hi[0] - lo[0]) * inv) + 1;
-        gy = (int)((hi[1] - lo[1]) * inv) + 1;
-        gz = (int)((hi[2] - lo[2]) * inv) + 1;
+        const float fx = (hi[0] - lo[0]) * inv, fy = (hi[1] - lo[1]) * inv, fz = (hi[2] - lo[2]) * inv;
+        if (it >= 128 || !(fx < 2.0e9f) || !(fy < 2.0e9f) || !(fz < 2.0e9f)) {
+            if (it >= 128) { sane = false; break; }
+            cs = cs * 2.0f;                 // still far too fine for an int cell count
+            continue;
+        }
+        gx = (int)fx + 1;
+        gy = (int)fy + 1;
+        gz = (int)fz + 1;
         if ((long long)gx * gy * gz <= GRID_MAXC) break;
         cs = cs * 2.0f;
     }
-    const float inv = 1.0f / cs;
+    if (!sane) {
+        gx = gy = gz = 1;
+        lo[0] = lo[1] = lo[2] = 0.f;
+    }
+    const float inv = sane ? 1.0f / cs : 0.f;
     const int ncell = gx * gy * gz;
     if (tid == 0) {
         hdr->x0 = lo[0]; hdr->y0 = lo[1]; hdr->z0 = lo[2]; hdr->inv = inv;
@@ -311,12 +332,8 @@ SAD_API int sad_ball_query_grid_f32(const float *xyz, const float *new_xyz, int 
         rmax = radii[r] > rmax ? radii[r] : rmax;
     }
     hipStream_t st = (hipStream_t)stream;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&grid_build_kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-        attr_set = true;
-    }
+    static std::atomic<uint64_t> attr_done{0};
+    sad::lds_attr_once(attr_done, reinterpret_cast<const void *>(&grid_build_kernel), 96 * 1024);
     hipLaunchKernelGGL(grid_build_kernel, dim3(B), dim3(BUILD_T), sizeof(int) * (GRID_MAXC + 64), st, xyz, N,
                        rmax * 1.001f, (char *)workspace);
     if (int e = sad::check_launch("sad_ball_query_grid_f32 (build)")) return e;

@@ -1,6 +1,7 @@
 // Shared host-side helpers for the libsad_amd.so translation units (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <stdarg.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -27,6 +28,19 @@ inline int fail(int code, const char *fmt, ...) {
     va_end(ap);
     set_error("%s", buf);
     return code;
+}
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel, device).  `done` is the call
+// site's mask of devices already served.  Thread-safe (two threads racing set the same value twice,
+// which is harmless) and per device (a process that drives several GPUs gets the attribute on each);
+// a refused attribute is not allowed to poison the launch check — the launch then reports it.
+inline void lds_attr_once(std::atomic<uint64_t> &done, const void *fn, int bytes) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return; }
+    const uint64_t bit = 1ull << (dev & 63);
+    if (done.load(std::memory_order_acquire) & bit) return;
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) (void)hipGetLastError();
+    done.fetch_or(bit, std::memory_order_release);
 }
 
 inline int check_launch(const char *what) {

@@ -623,12 +623,8 @@ namespace sad {
 
 // 16 384 < N <= 65 536: workspace = perm[B*N] ints, then B * 65 536 float4 records (16-byte aligned).
 int launch_fps_cellg(const float *xyz, int B, int N, int M, int32_t *idx, void *workspace, hipStream_t st) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&fps_sort_kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-        attr_set = true;
-    }
+    static std::atomic<uint64_t> attr_done{0};
+    lds_attr_once(attr_done, reinterpret_cast<const void *>(&fps_sort_kernel), 80 * 1024);
     const int NP = N <= 16384 ? 16384 : 65536;
     int *perm = (int *)workspace;
     const size_t off = (((size_t)B * N * sizeof(int)) + 15) & ~(size_t)15;
@@ -642,12 +638,8 @@ int launch_fps_cellg(const float *xyz, int B, int N, int M, int32_t *idx, void *
 
 // Called by sad_fps_f32 when a workspace (B*N ints) is available and N <= 16384.
 int launch_fps_bucket(const float *xyz, int B, int N, int M, int32_t *idx, void *workspace, hipStream_t st) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&fps_sort_kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-        attr_set = true;
-    }
+    static std::atomic<uint64_t> attr_done{0};
+    lds_attr_once(attr_done, reinterpret_cast<const void *>(&fps_sort_kernel), 80 * 1024);
     int *perm = (int *)workspace;
     hipLaunchKernelGGL(fps_sort_kernel, dim3(B), dim3(SORT_T), sizeof(int) * SORT_CELLS, st, xyz, N, perm);
     if (int e = check_launch("sad_fps_f32 (sort)")) return e;

@@ -107,15 +107,9 @@ int launch_group(const void *feat, const int32_t *idx, int B, int C, int N, long
     int chl = (int)(slab_budget / ((size_t)N * sizeof(T)));
     chl = chl > 8 ? 8 : chl;
     if (vec && chl >= 1 && MS >= 4 * (long long)N && MS >= 8192 && sad::get_option(sad::OPT_GROUP_VARIANT) != 1) {
-        static bool attr_set = false;
-        if (!attr_set) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void *>(&group_lds_kernel<uint32_t>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
-                hipFuncSetAttribute(reinterpret_cast<const void *>(&group_lds_kernel<uint16_t>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-                (void)hipGetLastError();
-            attr_set = true;
-        }
+        static std::atomic<uint64_t> attr_done32{0}, attr_done16{0};
+        sad::lds_attr_once(attr_done32, reinterpret_cast<const void *>(&group_lds_kernel<uint32_t>), 160 * 1024);
+        sad::lds_attr_once(attr_done16, reinterpret_cast<const void *>(&group_lds_kernel<uint16_t>), 160 * 1024);
         if (chl > C) chl = C;
         const int cblocks = (C + chl - 1) / chl;
         // enough workgroups for ~4 per CU, each with at least 4096 outputs per channel

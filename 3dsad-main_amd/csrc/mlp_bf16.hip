@@ -586,14 +586,9 @@ static int prepare_bf16(const sad_mlp_bf16_args *a, sad_stream_t stream, BfPrepa
 }
 
 static void bf16_attrs() {
-    static bool attr_set = false;
-    if (attr_set) return;
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&mlp_bf16_kernel),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void *>(&mlp_bf16_multi_kernel),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-        (void)hipGetLastError();
-    attr_set = true;
+    static std::atomic<uint64_t> attr_done1{0}, attr_done2{0};
+    sad::lds_attr_once(attr_done1, reinterpret_cast<const void *>(&mlp_bf16_kernel), 160 * 1024);
+    sad::lds_attr_once(attr_done2, reinterpret_cast<const void *>(&mlp_bf16_multi_kernel), 160 * 1024);
 }
 
 SAD_API int sad_mlp_chain_bf16(const sad_mlp_bf16_args *a, sad_stream_t stream) {

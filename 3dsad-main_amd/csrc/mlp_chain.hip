@@ -999,13 +999,8 @@ int check_dims(const char *fn, int L, const int *dims) {
 
 template <int W, int RW>
 int launch_mlp(const MlpParams &p, size_t lds, long long nblocks, hipStream_t st) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&mlp_chain_kernel<W, RW>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-            (void)hipGetLastError();   // do not let a refused attribute poison the launch check
-        attr_set = true;
-    }
+    static std::atomic<uint64_t> attr_done{0};   // one mask per template instantiation
+    sad::lds_attr_once(attr_done, reinterpret_cast<const void *>(&mlp_chain_kernel<W, RW>), 160 * 1024);
     hipLaunchKernelGGL((mlp_chain_kernel<W, RW>), dim3((unsigned)nblocks), dim3(W * 64), lds, st, p);
     return sad::check_launch("sad_mlp_chain_f32");
 }
@@ -1097,6 +1092,11 @@ static int prepare_chain(const sad_mlp_args *a, sad_stream_t stream, Prepared &q
         SAD_REQUIRE(a->N >= 1 && a->S >= 1 && a->S <= 64, "sad_mlp_chain_f32: need N>=1, 1<=S<=64 (S=%d)", a->S);
         SAD_REQUIRE(a->dims[0] == a->C + 3, "sad_mlp_chain_f32: dims[0]=%d != C+3=%d", a->dims[0], a->C + 3);
         SAD_REQUIRE((long long)a->B * a->N < (1LL << 31), "sad_mlp_chain_f32: B*N too large");
+        SAD_REQUIRE((long long)a->B * a->M * a->S < (1LL << 31), "sad_mlp_chain_f32: B*M*S too large (row numbers are 32-bit)");
+        // straddling groups are merged with an unsigned atomic max into a zero-initialised buffer:
+        // only valid for non-negative outputs, i.e. a ReLU after every layer (SPEC.md §6 grouped chains)
+        SAD_REQUIRE((a->relu_mask & ((1 << a->L) - 1)) == (1 << a->L) - 1,
+                    "sad_mlp_chain_f32: grouped chains need a ReLU after every layer (relu_mask=0x%x, L=%d)", a->relu_mask, a->L);
     } else {
         SAD_REQUIRE(a->S == 1, "sad_mlp_chain_f32: plain mode needs S == 1");
         SAD_REQUIRE(a->C >= 1 && a->dims[0] == a->C, "sad_mlp_chain_f32: dims[0]=%d != C=%d", a->dims[0], a->C);
@@ -1292,13 +1292,8 @@ static int prepare_chain(const sad_mlp_args *a, sad_stream_t stream, Prepared &q
 namespace {
 template <int W>
 int launch_mlp2(const MlpParams &p, size_t lds, long long nblocks, hipStream_t st) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&mlp_chain2_kernel<W>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-            (void)hipGetLastError();
-        attr_set = true;
-    }
+    static std::atomic<uint64_t> attr_done{0};
+    sad::lds_attr_once(attr_done, reinterpret_cast<const void *>(&mlp_chain2_kernel<W>), 160 * 1024);
     hipLaunchKernelGGL((mlp_chain2_kernel<W>), dim3((unsigned)nblocks), dim3(W * 64), lds, st, p);
     return sad::check_launch("sad_mlp_chain_f32");
 }
@@ -1324,13 +1319,8 @@ int launch_prepared(const Prepared &q, hipStream_t st) {
 
 template <int W, int RWMAX, bool CW2>
 int launch_multi(const MultiParams &mp, size_t lds, hipStream_t st) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&mlp_multi_kernel<W, RWMAX, CW2>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-            (void)hipGetLastError();
-        attr_set = true;
-    }
+    static std::atomic<uint64_t> attr_done{0};
+    sad::lds_attr_once(attr_done, reinterpret_cast<const void *>(&mlp_multi_kernel<W, RWMAX, CW2>), 160 * 1024);
     hipLaunchKernelGGL((mlp_multi_kernel<W, RWMAX, CW2>), dim3((unsigned)mp.first[mp.n]), dim3(W * 64), lds, st, mp);
     return sad::check_launch("sad_mlp_chain_multi_f32");
 }

@@ -83,16 +83,22 @@ class SADDetector(nn.Module):
     def submit(self, points: torch.Tensor, post=None):
         """Throughput entry point: enqueue one batch on the next main stream (round-robin) and
         return (result, done_event) without waiting.  ``points`` must already be resident and not
-        be written by queued work (same promise as ``input_ready=True``).  ``post(boxes)`` runs on
-        the same stream (e.g. the all_gather of a sharded job)."""
+        be written by queued work (same promise as ``input_ready=True``).  ``post(boxes)`` is called
+        with that stream current (e.g. the all_gather of a sharded job).  ``done_event`` covers
+        everything that produces ``result``: when the hook moves work to a stream of its own and
+        exposes its completion as ``post.event`` (``dist.AsyncBoxGather``), that event is returned,
+        otherwise one recorded on the main stream behind the hook."""
         st = self._mains[self._submits % len(self._mains)]
         self._submits += 1
         with torch.cuda.stream(st):
             out = self.forward(points, input_ready=True)
+            ev = None
             if post is not None:
                 out = post(out)
-            ev = torch.cuda.Event()
-            ev.record(st)
+                ev = getattr(post, "event", None)
+            if ev is None:
+                ev = torch.cuda.Event()
+                ev.record(st)
         return out, ev
 
     def autotune(self, points: torch.Tensor) -> dict:

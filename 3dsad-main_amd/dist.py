@@ -37,14 +37,20 @@ class AsyncBoxGather:
     """``post`` hook for ``SADDetector.submit``: the all_gather of a step's boxes runs on its own
     stream behind an event, so the compute streams never wait for the other ranks — a straggler
     delays only the collective, not the next batch's kernels.  The returned tensor is valid once
-    the communication stream (``.stream``) has been synchronised (``wait()``)."""
+    ``.event`` (recorded on the communication stream right behind the collective; ``None`` when no
+    collective ran) has completed, or after ``wait()``.  ``SADDetector.submit`` returns that event,
+    so ``ev.wait()`` / ``ev.synchronize()`` on the submit result covers the gather too.  The gathered
+    tensor is allocated on the communication stream: a consumer on another stream waits for the
+    event and calls ``out.record_stream(its_stream)``."""
 
     def __init__(self, device, group=None):
         self.stream = torch.cuda.Stream(device=device)
         self.group = group
+        self.event = None       # completion of the most recent collective (None: nothing in flight)
 
     def __call__(self, local_boxes: torch.Tensor) -> torch.Tensor:
         if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(self.group) == 1:
+            self.event = None
             return local_boxes
         cur = torch.cuda.current_stream()
         ev = torch.cuda.Event()
@@ -52,6 +58,9 @@ class AsyncBoxGather:
         with torch.cuda.stream(self.stream):
             self.stream.wait_event(ev)
             out = all_gather_boxes(local_boxes, self.group)
+            done = torch.cuda.Event()
+            done.record(self.stream)
+        self.event = done
         local_boxes.record_stream(self.stream)
         return out
 

@@ -57,11 +57,21 @@ class _timed:
         return False
 
 
+def _on_current_device(t: torch.Tensor, name: str) -> None:
+    """The C-ABI launches on the CURRENT device's stream ("device chosen by caller"):
+    a tensor that lives on another GPU would be dereferenced by a kernel running on the wrong one."""
+    cur = torch.cuda.current_device()
+    if t.device.index != cur:
+        raise RuntimeError(f"{name}: tensor is on {t.device} but the current device is cuda:{cur}; "
+                           f"wrap the call in `with torch.cuda.device({t.device.index}):`")
+
+
 def _need(t: torch.Tensor, name: str, dtype, ndim: int) -> torch.Tensor:
     if not isinstance(t, torch.Tensor):
         raise TypeError(f"{name}: expected a torch.Tensor")
     if not t.is_cuda:
         raise RuntimeError(f"{name}: expected a GPU tensor (sad_amd has no CPU path)")
+    _on_current_device(t, name)
     if dtype is not None and t.dtype != dtype:
         raise TypeError(f"{name}: expected dtype {dtype}, got {t.dtype}")
     if t.dim() != ndim:
@@ -435,6 +445,7 @@ class PackedMLP:
             raise RuntimeError("this PackedMLP was packed with the xyz prefix")
         if not x.is_cuda or x.dtype != torch.float32:
             raise TypeError("x: expected a GPU float32 tensor")
+        _on_current_device(x, "x")
         C = x.shape[-1]
         if C != self.dims[0]:
             raise ValueError(f"MLP expects {self.dims[0]} channels, got {C}")

@@ -14,7 +14,9 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "libsad_oracle.so")
+# SAD_ORACLE_LIB: an alternative build of the same oracle (the -fsanitize=address,undefined one,
+# oracle/Makefile target `asan`, loaded by tests/test_oracle_sanitizers.py in a child process)
+_SO = os.environ.get("SAD_ORACLE_LIB") or os.path.join(_HERE, "libsad_oracle.so")
 _lib = None
 
 _f32p = ctypes.POINTER(ctypes.c_float)
@@ -24,6 +26,8 @@ _i32p = ctypes.POINTER(ctypes.c_int32)
 def build(force: bool = False) -> str:
     """Compile the oracle with gcc (oracle/Makefile).  Returns the path of the shared library."""
     src = os.path.join(_HERE, "sad_oracle.c")
+    if os.environ.get("SAD_ORACLE_LIB"):
+        return _SO
     if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
         subprocess.check_call(["make", "-C", _HERE, "-B", "libsad_oracle.so"],
                               stdout=subprocess.DEVNULL)
@@ -164,9 +168,11 @@ def mlp_rows(x, layers, relu_mask=None, out=None, col_off=0):
     return out
 
 
-def sa_group_mlp_max(xyz, feat_pm, new_xyz, idx, layers, out=None, col_off=0):
+def sa_group_mlp_max(xyz, feat_pm, new_xyz, idx, layers, out=None, col_off=0, skip_padding=False):
     """SPEC.md §6 fused.  xyz [B,N,3]; feat_pm [B,N,C] point-major or None; new_xyz [B,M,3];
-    idx [B,M,S]; -> out [B,M,C_out] (or writes at channel offset col_off of a wider buffer)."""
+    idx [B,M,S]; -> out [B,M,C_out] (or writes at channel offset col_off of a wider buffer).
+    ``skip_padding``: do not compute the trailing rows of a group that repeat its first sample
+    (same bits — a duplicate row cannot change a max; used by bench.py's like-for-like CPU leg)."""
     xyz, px = _f(xyz)
     new_xyz, pn = _f(new_xyz)
     idx, pi = _i(idx)
@@ -184,8 +190,8 @@ def sa_group_mlp_max(xyz, feat_pm, new_xyz, idx, layers, out=None, col_off=0):
     if out is None:
         out = np.empty((B, M, cout), np.float32)
     assert out.dtype == np.float32 and out.flags.c_contiguous and out.shape[:2] == (B, M)
-    lib().orc_sa_group_mlp_max(px, pf, pn, pi, B, N, M, S, C, L, dims, Wp, bp,
-                               out.ctypes.data_as(_f32p), out.shape[2], col_off)
+    fn = lib().orc_sa_group_mlp_max_skip if skip_padding else lib().orc_sa_group_mlp_max
+    fn(px, pf, pn, pi, B, N, M, S, C, L, dims, Wp, bp, out.ctypes.data_as(_f32p), out.shape[2], col_off)
     return out
 
 
@@ -286,7 +292,7 @@ def nms_bev(boxes, iou_thr, score_thr=0.0):
 # ----------------------------------------------------------------------------------------------
 # Model-level restatement (SPEC.md §7-§9): the CPU path the GPU detector is compared with.
 # ----------------------------------------------------------------------------------------------
-def sa_module(xyz, feat_pm, stage, weights, name, trace=None):
+def sa_module(xyz, feat_pm, stage, weights, name, trace=None, skip_padding=False):
     """SPEC.md §7 with point-major features.  xyz [B,N,3], feat_pm [B,N,C] or None.
     weights[name+'.b<i>'] per branch, weights[name+'.agg'] if stage.agg.
     Returns (new_xyz [B,M,3], new_feat_pm [B,M,C'])."""
@@ -301,7 +307,8 @@ def sa_module(xyz, feat_pm, stage, weights, name, trace=None):
     for bi, (r, s, mlp) in enumerate(zip(stage.radii, stage.nsamples, stage.mlps)):
         idx = ball_query(r, s, xyz, new_xyz)
         idxs.append(idx)
-        sa_group_mlp_max(xyz, feat_pm, new_xyz, idx, weights[f"{name}.b{bi}"], out=buf, col_off=off)
+        sa_group_mlp_max(xyz, feat_pm, new_xyz, idx, weights[f"{name}.b{bi}"], out=buf, col_off=off,
+                         skip_padding=skip_padding)
         off += mlp[-1]
     if stage.agg:
         out = mlp_rows(buf.reshape(B * M, cat), weights[f"{name}.agg"]).reshape(B, M, stage.agg)
@@ -312,14 +319,15 @@ def sa_module(xyz, feat_pm, stage, weights, name, trace=None):
     return new_xyz, out
 
 
-def detector_forward(points, cfg, weights, trace=None):
-    """SPEC.md §7-§9: points [B,N,3+in_feat] -> boxes [B,K,9]."""
+def detector_forward(points, cfg, weights, trace=None, skip_padding=False):
+    """SPEC.md §7-§9: points [B,N,3+in_feat] -> boxes [B,K,9].  ``skip_padding``: see
+    ``sa_group_mlp_max`` (identical boxes, fewer MLP rows)."""
     points = np.ascontiguousarray(points, np.float32)
     B = points.shape[0]
     xyz = np.ascontiguousarray(points[:, :, :3])
     feat = np.ascontiguousarray(points[:, :, 3:]) if points.shape[2] > 3 else None
     for si, st in enumerate(cfg.stages):
-        xyz, feat = sa_module(xyz, feat, st, weights, f"sa{si + 1}", trace)
+        xyz, feat = sa_module(xyz, feat, st, weights, f"sa{si + 1}", trace, skip_padding)
     K = cfg.n_cand
     C3 = feat.shape[2]
     cand_feat = np.ascontiguousarray(feat[:, :K, :]).reshape(B * K, C3)
@@ -334,7 +342,8 @@ def detector_forward(points, cfg, weights, trace=None):
         r = (np.float32(sc) * rad).astype(np.float32)
         idx = ball_query(r, s, xyz, cand)
         cidx.append(idx)
-        sa_group_mlp_max(xyz, feat, cand, idx, weights[f"cluster.b{bi}"], out=buf, col_off=off)
+        sa_group_mlp_max(xyz, feat, cand, idx, weights[f"cluster.b{bi}"], out=buf, col_off=off,
+                         skip_padding=skip_padding)
         off += mlp[-1]
     cfeat = mlp_rows(buf.reshape(B * K, cat), weights["cluster.agg"])
     Lh = len(weights["head"])

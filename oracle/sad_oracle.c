@@ -285,10 +285,10 @@ ORC_API void orc_mlp_rows(const float *x, int64_t R, int L, const int *dims, con
  * dims[0] must equal 3 + C; all L layers carry ReLU.
  * out[(b*M+m)*ld_out + col_off + o] = max_s y_L[o] (point-major rows, so branches concatenate by
  * writing at different col_off into one [B,M,ld_out] buffer). */
-ORC_API void orc_sa_group_mlp_max(const float *xyz, const float *feat_pm, const float *new_xyz,
-                                  const int32_t *idx, int B, int N, int M, int S, int C, int L,
+static void sa_group_mlp_max_impl(const float *xyz, const float *feat_pm, const float *new_xyz,
+                                  const int32_t *idx, int B, int N, int M, int S_all, int C, int L,
                                   const int *dims, const float *const *W, const float *const *bias,
-                                  float *out, int ld_out, int col_off) {
+                                  float *out, int ld_out, int col_off, int skip_padding) {
     float *wT[8];
     int maxc = dims[0];
     for (int l = 0; l < L; ++l) {
@@ -298,13 +298,22 @@ ORC_API void orc_sa_group_mlp_max(const float *xyz, const float *feat_pm, const 
     const int Cin = dims[0], Cout = dims[L];
 #pragma omp parallel
     {
-        float *buf0 = (float *)malloc(sizeof(float) * (size_t)S * maxc);
-        float *buf1 = (float *)malloc(sizeof(float) * (size_t)S * maxc);
-#pragma omp for collapse(2) schedule(static)
+        float *buf0 = (float *)malloc(sizeof(float) * (size_t)S_all * maxc);
+        float *buf1 = (float *)malloc(sizeof(float) * (size_t)S_all * maxc);
+#pragma omp for collapse(2) schedule(dynamic, 16)
         for (int b = 0; b < B; ++b)
             for (int m = 0; m < M; ++m) {
                 const float *c = new_xyz + ((size_t)b * M + m) * 3;
-                const int32_t *ix = idx + ((size_t)b * M + m) * S;
+                const int32_t *ix = idx + ((size_t)b * M + m) * S_all;
+                /* skip_padding: only the leading rows up to the last sample that differs from the
+                 * first are computed.  Every dropped row repeats sample 0 (SPEC.md §3 padding), and a
+                 * duplicate row cannot change a max — the same exact rule the HIP kernel applies. */
+                int S = S_all;
+                if (skip_padding) {
+                    S = 1;
+                    for (int s = 1; s < S_all; ++s)
+                        if (ix[s] != ix[0]) S = s + 1;
+                }
                 for (int s = 0; s < S; ++s) {
                     const float *p = xyz + ((size_t)b * N + ix[s]) * 3;
                     float *g = buf0 + (size_t)s * Cin;
@@ -333,6 +342,22 @@ ORC_API void orc_sa_group_mlp_max(const float *xyz, const float *feat_pm, const 
         free(buf1);
     }
     for (int l = 0; l < L; ++l) free(wT[l]);
+}
+
+ORC_API void orc_sa_group_mlp_max(const float *xyz, const float *feat_pm, const float *new_xyz,
+                                  const int32_t *idx, int B, int N, int M, int S, int C, int L,
+                                  const int *dims, const float *const *W, const float *const *bias,
+                                  float *out, int ld_out, int col_off) {
+    sa_group_mlp_max_impl(xyz, feat_pm, new_xyz, idx, B, N, M, S, C, L, dims, W, bias, out, ld_out, col_off, 0);
+}
+
+/* The same result with the ball-query padding rows not computed (bench.py's like-for-like CPU leg:
+ * the HIP kernel skips exactly these rows).  Bit-identical to orc_sa_group_mlp_max. */
+ORC_API void orc_sa_group_mlp_max_skip(const float *xyz, const float *feat_pm, const float *new_xyz,
+                                       const int32_t *idx, int B, int N, int M, int S, int C, int L,
+                                       const int *dims, const float *const *W, const float *const *bias,
+                                       float *out, int ld_out, int col_off) {
+    sa_group_mlp_max_impl(xyz, feat_pm, new_xyz, idx, B, N, M, S, C, L, dims, W, bias, out, ld_out, col_off, 1);
 }
 
 /* SPEC.md §8 steps 2-4 — candidate centres and per-candidate adaptive radius.

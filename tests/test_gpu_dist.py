@@ -30,12 +30,23 @@ pts = torch.from_numpy(synth.make_tiny_batch(0, 4, cfg.n_points)).to(dev)
 lo, hi = shard_range(4, rank, world)
 gather = AsyncBoxGather(dev)
 outs = []
+consumer = torch.cuda.Stream(device=dev)
+copies = []
 for step in range(3):                      # several steps in flight, as in bench.py
     out, ev = det.submit(pts[lo:hi].contiguous(), post=gather)
+    assert gather.event is not None and ev is gather.event    # the returned event covers the collective
+    # a consumer that follows the submit() docstring: waits on ev ONLY, then reads `out` elsewhere
+    with torch.cuda.stream(consumer):
+        consumer.wait_event(ev)
+        out.record_stream(consumer)
+        copies.append(out.clone())
     outs.append(out)
+consumer.synchronize()
+assert copies[-1].shape[0] == 4
 gather.wait()
 torch.cuda.synchronize()
 assert all(torch.equal(o, outs[0]) for o in outs)
+assert all(torch.equal(c, outs[0]) for c in copies), "out read after ev.wait() differs: event does not cover the gather"
 if rank == 0:
     np.save(os.environ["SAD_OUT"], outs[-1].cpu().numpy())
 dist.barrier()
