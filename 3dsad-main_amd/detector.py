@@ -90,6 +90,7 @@ class SADDetector(nn.Module):
         otherwise one recorded on the main stream behind the hook."""
         st = self._mains[self._submits % len(self._mains)]
         self._submits += 1
+        self.last_stream = st
         with torch.cuda.stream(st):
             out = self.forward(points, input_ready=True)
             ev = None
@@ -111,11 +112,33 @@ class SADDetector(nn.Module):
             torch.cuda.synchronize()
         finally:
             ops.AUTOTUNE, self.overlap_fps = prev, ov
-        mlps = [b for m in self.stages for b in m.branches] + [m.agg for m in self.stages if m.agg]
-        mlps += [self.cand_mlp, self.cluster_agg, self.head] + self.cluster_branches
-        if self.agg_head is not None:      # (tuned by the forward pass above, which runs the fused chain)
-            mlps.append(self.agg_head)
-        return {m.name: list(m._geom.values())[-1] for m in mlps if m._geom}
+        return self.geometry()
+
+    def mlps(self) -> list:
+        """Every packed MLP chain of the detector (branches, aggregations, candidate MLP, head, fused chain)."""
+        out = [b for m in self.stages for b in m.branches] + [m.agg for m in self.stages if m.agg]
+        out += [self.cand_mlp, self.cluster_agg, self.head] + self.cluster_branches
+        if self.agg_head is not None:      # (tuned by autotune's forward pass, which runs the fused chain)
+            out.append(self.agg_head)
+        return out
+
+    def geometry(self) -> dict:
+        """{launch name: workgroup geometry code} of every chain that has one (tuned or loaded)."""
+        g = {}
+        for m in self.mlps():
+            code = list(m._geom.values())[-1] if m._geom else m.default_geometry
+            if code:
+                g[m.name] = int(code)
+        return g
+
+    def set_geometry(self, geometry: dict) -> None:
+        """Use a saved ``geometry()`` / ``autotune()`` result instead of measuring again (reproducible
+        runs: rocprofv3 then sees steady-state launches only).  Codes are validated by the C-ABI at
+        launch time (an unusable code raises, it is never silently replaced)."""
+        for m in self.mlps():
+            if m.name in geometry:
+                m._geom.clear()
+                m.default_geometry = int(geometry[m.name])
 
     def _sample_stage(self, si: int, cur: torch.Tensor) -> torch.Tensor:
         """Centroids of stage si from the previous stage's centroids (or the scene for si = 0).

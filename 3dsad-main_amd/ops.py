@@ -282,7 +282,8 @@ class PackedMLP:
     def __init__(self, layers, first_has_xyz: bool, device, relu_mask: Optional[int] = None,
                  name: str = ""):
         self.name = name
-        self._geom = {}
+        self._geom = {}              # shape key -> geometry picked by the autotuner
+        self.default_geometry = 0    # used for shapes never tuned (0 = built-in heuristic); see SADDetector.set_geometry
         if not 1 <= len(layers) <= _lib.MAX_LAYERS:
             raise ValueError(f"1..{_lib.MAX_LAYERS} layers supported")
         self.device = torch.device(device)
@@ -325,7 +326,7 @@ class PackedMLP:
         if geom is None and AUTOTUNE:
             geom = self._tune(a)
             self._geom[key] = geom
-        a.geometry = geom or 0
+        a.geometry = geom or self.default_geometry
         with _timed("mlp", self.name):
             check(lib().sad_mlp_chain_f32(ctypes.byref(a), _stream()), "sad_mlp_chain_f32")
 
@@ -435,7 +436,7 @@ class PackedMLP:
             keep += [cnt, ws]
         a.B, a.N, a.M, a.S, a.C = B, N, M, S, C
         a.out, a.ld_out, a.col_off = out.data_ptr(), out.stride(-2), col_off
-        a.geometry = self._geom.get((bool(a.idx), a.B, a.N, a.M, a.S, a.ld_out)) or 0
+        a.geometry = self._geom.get((bool(a.idx), a.B, a.N, a.M, a.S, a.ld_out)) or self.default_geometry
         return a, out, keep
 
     def rows(self, x: torch.Tensor, out: Optional[torch.Tensor] = None, col_off: int = 0
@@ -530,6 +531,7 @@ class PackedMLPBf16:
         n = lib().sad_mlp_packed_bytes_bf16(self.L, dims_c, int(self.first_has_xyz))
         self.packed = torch.empty((n,), dtype=torch.uint8, device=self.device)
         self._geom = {}      # (mode, B, N, M, S, ld_out) -> rows per tile picked by the autotuner
+        self.default_geometry = 0
         w_arr = (vp * self.L)(*[w.data_ptr() for w in ws])
         b_arr = (vp * self.L)(*[b.data_ptr() for b in bs])
         with torch.cuda.device(self.device):
@@ -601,7 +603,7 @@ class PackedMLPBf16:
             ws = torch.empty((lib().sad_mlp_workspace_bytes(B, M, S),), dtype=torch.uint8, device=xyz.device)
             a.cnt, a.workspace = cnt.data_ptr(), ws.data_ptr()
             keep += [cnt, ws]
-        a.geometry = self._geom.get((bool(a.idx), a.B, a.N, a.M, a.S, a.ld_out)) or 0
+        a.geometry = self._geom.get((bool(a.idx), a.B, a.N, a.M, a.S, a.ld_out)) or self.default_geometry
         return a, out, keep
 
     def _launch(self, a) -> None:
@@ -630,7 +632,7 @@ class PackedMLPBf16:
                     best, best_ms = code, ms_best
             geom = best
             self._geom[key] = geom
-        a.geometry = geom or 0
+        a.geometry = geom or self.default_geometry
         with _timed("mlp", self.name):
             check(lib().sad_mlp_chain_bf16(ctypes.byref(a), _stream()), "sad_mlp_chain_bf16")
 

@@ -54,6 +54,13 @@ def make_tiny_batch(first_scene: int, batch: int, n_points: int = 2048) -> np.nd
     return make_batch(first_scene, batch, n_points, extent=(0.0, 20.0, -10.0, 10.0), n_boxes=6)
 
 
+def make_dense_batch(first_scene: int, batch: int, n_points: int = 16384) -> np.ndarray:
+    """Dense-occupancy variant of the KITTI-shaped workload (bench.py ``--scene dense``): the same
+    16 384 points on the TINY extents (20 m x 20 m, 6 boxes), ~40 points per square metre instead of
+    ~3, so the wider ball queries find nsample neighbours and few grouped rows are padding."""
+    return make_batch(first_scene, batch, n_points, extent=(0.0, 20.0, -10.0, 10.0), n_boxes=6)
+
+
 def make_unit_cube(scene_id: int, n_points: int = 1024) -> np.ndarray:
     """BASELINE.json configs[0] input: float32 [n_points, 3] uniform in the unit cube."""
     rng = np.random.default_rng(1234 + scene_id)

@@ -11,14 +11,21 @@ cluster layer -> box/cls head -> boxes[32,256,9]; with N > 1 every rank processe
 Inputs are already in HBM when the timed region starts.
 
 One JSON line on rank 0: the contract fields plus
-  roofline     — the dominant kernel (mlp_chain_kernel: every fused gather+MLP+max / MLP launch of a
-                 step) against the dense f32 MFMA peak, timed with HIP events on its own stream
-                 inside the timed region;
-  kernels      — the same for fps / ball_query (against the HBM roofline, algorithmic bytes);
-  cpu_baseline — this repository's CPU spec-oracle (kind "port": the upstream reference ships no
-                 CPU path) on a bounded sample of the same scenes, same host.
+  parity_check — the boxes of the timed configuration (last timed step) against the CPU spec-oracle
+                 on the same scenes (<= 1e-4, labels exact); a failure makes the exit code non-zero;
+  roofline     — the dominant kernel (the fused gather+MLP+max / MLP launches of a step) against the
+                 dense f32 MFMA peak on EXECUTED flops, timed with HIP events on the launching stream
+                 in a non-overlapped pass (one stream, no sibling batch), so that every interval is a
+                 kernel duration; the overlapped sums of the timed region are kept as a note;
+  kernels      — fps / ball_query (HBM roofline on algorithmic bytes) from the same serial pass;
+  dense_leg    — the same detector with the padding skip switched off (every grouped row computed):
+                 the throughput floor on scenes whose neighbourhoods are all full;
+  cpu_baseline — this repository's CPU spec-oracle (the upstream reference ships no CPU path) on a
+                 bounded sample of the same scenes, same host: dense SPEC path and padding-skipped.
+Parity is against this repo's spec-oracle; the reference (README-only) ships no implementation.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -26,14 +33,16 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-# HIP multiplexes streams onto 4 hardware queues by default; this pipeline uses the main stream,
-# three sampling streams and two branch streams, and a 7 ms FPS kernel sharing a queue with MLP
-# launches would serialise them.  Must be set before the runtime initialises.
+# HIP multiplexes streams onto 4 hardware queues by default; this pipeline uses two main streams and
+# four sampling streams, and a 3 ms FPS kernel sharing a queue with MLP launches would serialise
+# them.  Must be set before the runtime initialises.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 PEAK_MFMA_F32_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: dense f32 MFMA
 PEAK_MFMA_BF16_TFLOPS = 2500.0 # same guide: dense bf16 MFMA (not the 2:1-sparsity headline)
 PEAK_HBM_GBPS = 8000.0         # HBM3E spec
+PARITY_TOL = 1e-4              # BASELINE.json north_star: fp32 boxes within 1e-4
+TRAFFIC_FILE = "r02_pmc_traffic.json"   # profiles/: HBM bytes of the MLP dispatches (rocprofv3 --pmc passes)
 
 
 def usable_cores() -> int:
@@ -47,23 +56,49 @@ def usable_cores() -> int:
     return n
 
 
-def cpu_baseline(cfg, weights, scenes: int, repeats: int = 2):
-    """Oracle forward on `scenes` scenes of the same workload; best of `repeats`."""
+def cpu_baseline(cfg, weights, pts, repeats: int = 2):
+    """Oracle forward on the scenes ``pts``; best of ``repeats`` for the dense SPEC path and for the
+    padding-skipped variant (same boxes; the arithmetic the HIP path executes).  Returns
+    (record, boxes)."""
     import oracle
-    from sad_amd import synth
     cores = usable_cores()
     os.environ["OMP_NUM_THREADS"] = str(cores)
     oracle.build()
-    pts = synth.make_batch(0, scenes, cfg.n_points)
-    best = None
-    for _ in range(repeats):
-        t0 = time.perf_counter()
-        oracle.detector_forward(pts, cfg, weights)
-        dt = time.perf_counter() - t0
-        best = dt if best is None else min(best, dt)
-    return {"value": round(scenes / best, 4), "unit": "scenes/s", "cores": cores, "kind": "port",
-            "sample": f"{scenes} scenes of the same 16384-pt batch through oracle.detector_forward "
-                      f"(C + OpenMP, {cores} threads), best of {repeats}; the upstream reference has no CPU path"}
+    scenes = pts.shape[0]
+    best = {}
+    boxes = None
+    for skip in (False, True):
+        for _ in range(repeats):
+            t0 = time.perf_counter()
+            out = oracle.detector_forward(pts, cfg, weights, skip_padding=skip)
+            dt = time.perf_counter() - t0
+            best[skip] = dt if skip not in best else min(best[skip], dt)
+        if boxes is None:
+            boxes = out
+        else:
+            assert (boxes == out).all(), "oracle: padding-skipped boxes differ from the dense path"
+    rec = {"value": round(scenes / best[False], 4), "unit": "scenes/s", "cores": cores,
+           "kind": "port (self-authored spec-oracle: the upstream reference is a 2-line README with no CPU path)",
+           "value_padding_skipped": round(scenes / best[True], 4),
+           "sample": f"{scenes} scenes of the same batch through oracle.detector_forward (C + AVX2 fmaf chains + "
+                     f"OpenMP, {cores} threads, brute-force FPS / ball query), best of {repeats}.  `value` computes "
+                     "every grouped row (dense SPEC path, ~13x the MLP rows the HIP path executes on these sparse "
+                     "scenes); `value_padding_skipped` skips the ball-query padding rows exactly as the HIP kernels do "
+                     "(identical boxes) - that is the like-for-like CPU figure"}
+    return rec, boxes
+
+
+def parity_check(got, want):
+    """Boxes of the timed configuration vs the oracle: max relative difference and label equality."""
+    import numpy as np
+    n = min(got.shape[0], want.shape[0])
+    g, w = got[:n].astype(np.float64), want[:n].astype(np.float64)
+    rel = float((np.abs(g - w) / (1.0 + np.abs(w))).max())
+    labels = bool(np.array_equal(got[:n, :, 8], want[:n, :, 8]))
+    return {"scenes": int(n), "max_rel": float(f"{rel:.3e}"), "tol": PARITY_TOL, "labels_equal": labels,
+            "ok": bool(rel <= PARITY_TOL and labels),
+            "against": "CPU spec-oracle (oracle/sad_oracle.c) on the same scenes; parity with the upstream "
+                       "reference is unpinned (README-only, no implementation)"}
 
 
 def executed_flops(det, points, cfg, dense=False):
@@ -86,13 +121,13 @@ def executed_flops(det, points, cfg, dense=False):
         return 2 * sum(a * b for a, b in zip(d[:-1], d[1:]))
 
     def rows_of(idx):
-        if dense:                 # the bf16 path computes every row of every group
+        if dense:                 # every row of every group
             return idx.numel()
         diff = idx != idx[..., :1]
         pos = torch.arange(1, idx.shape[-1] + 1, device=idx.device)
         return int(torch.clamp((diff * pos).amax(-1), min=1).sum().item())
 
-    ex, dense_rows, exec_rows = 0, 0, 0
+    dense_rows, exec_rows = 0, 0
     per = {}
     for si, st in enumerate(cfg.stages):
         name = f"sa{si + 1}"
@@ -111,27 +146,37 @@ def executed_flops(det, points, cfg, dense=False):
     K = cfg.n_cand
     for n in ("cand", "cluster.agg", "head"):
         per[n] = B * K * chain(dims[n])
-    per["cluster.agg+head"] = 0      # the fused chain is named "cluster.agg+head": fl() sums its parts
-    ex = sum(per.values())
-    return ex, exec_rows / max(1, dense_rows), per
+    return sum(per.values()), exec_rows / max(1, dense_rows), per
+
+
+def flops_of(name, per_flops):
+    """A merged dispatch is named "a+b+c" (fused chain: "cluster.agg+head")."""
+    return sum(per_flops.get(x, 0) for x in name.split("+"))
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
-    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=32, help="scenes per GPU per step")
     ap.add_argument("--no-overlap", action="store_true", help="run FPS on the main stream")
     ap.add_argument("--fps-streams", type=int, default=4, help="sampling streams used round-robin")
     ap.add_argument("--main-streams", type=int, default=2, help="main streams used round-robin by consecutive steps")
-    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg (parity_check then uses 4 scenes)")
     ap.add_argument("--cpu-scenes", type=int, default=32)
-    ap.add_argument("--no-launch-timing", action="store_true")
+    ap.add_argument("--no-launch-timing", action="store_true", help="skip the per-launch event passes (roofline / kernels)")
+    ap.add_argument("--no-dense-leg", action="store_true")
     ap.add_argument("--no-autotune", action="store_true", help="use the built-in geometry heuristic")
+    ap.add_argument("--geometry-file", default=None,
+                    help="JSON {launch name: geometry code} from --save-geometry: no autotune launches (rocprof runs)")
+    ap.add_argument("--save-geometry", default=None, help="write the geometry in use to this JSON file")
     ap.add_argument("--config", choices=("kitti", "nuscenes"), default="kitti",
                     help="nuscenes = BASELINE configs[4] shape (65536-pt scenes, 4 extra channels); secondary, "
                          "use with --dtype bf16 --batch 8 --no-cpu; the headline metric is the kitti default")
+    ap.add_argument("--scene", choices=("kitti", "dense"), default="kitti",
+                    help="dense = the same 16384 points on 20 m x 20 m (most neighbourhoods full): the dense-occupancy "
+                         "floor of the same kernels; secondary, the headline is the KITTI-shaped default")
     ap.add_argument("--dtype", choices=("f32", "bf16"), default="f32",
                     help="bf16 = SPEC.md 14 mode (configs[4]): MLPs on the bf16 matrix cores, dense rows; "
                          "the headline metric is the f32 default")
@@ -158,6 +203,7 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    backend = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = os.environ.get("SAD_BENCH_BACKEND", "nccl")       # "nccl" is RCCL on ROCm
@@ -177,20 +223,34 @@ def main():
     PEAK = PEAK_MFMA_F32_TFLOPS if args.dtype == "f32" else PEAK_MFMA_BF16_TFLOPS
     gather = AsyncBoxGather(dev)       # the step's one collective, off the compute streams
     B = args.batch
-    make = synth.make_batch if args.config == "kitti" else synth.make_nuscenes_batch
-    points = torch.from_numpy(make(rank * B, B, cfg.n_points)).to(dev)
+    if args.config == "nuscenes":
+        make = synth.make_nuscenes_batch
+    else:
+        make = synth.make_batch if args.scene == "kitti" else synth.make_dense_batch
+    points_np = make(rank * B, B, cfg.n_points)
+    points = torch.from_numpy(points_np).to(dev)
     torch.cuda.synchronize()
 
     if os.environ.get("SAD_NO_MERGE_BF16"):
         ops.MERGE_BF16 = False
-    tuned = None if args.no_autotune else det.autotune(points)
+    if args.geometry_file:
+        det.set_geometry(json.load(open(args.geometry_file)))
+        tuned = det.geometry()
+        geometry_source = f"file:{os.path.basename(args.geometry_file)}"
+    elif args.no_autotune:
+        tuned, geometry_source = {}, "heuristic"
+    else:
+        tuned, geometry_source = det.autotune(points), "autotuned on this batch"
+    if args.save_geometry and rank == 0:
+        json.dump(tuned, open(args.save_geometry, "w"), indent=1, sort_keys=True)
+    geom_hash = hashlib.sha256(json.dumps(tuned, sort_keys=True).encode()).hexdigest()[:12]
 
     def step():
-        out, _ = det.submit(points, post=gather)
-        return out
+        out, ev = det.submit(points, post=gather)
+        return out, ev
 
     for _ in range(args.warmup):
-        out = step()
+        out, _ = step()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -199,33 +259,54 @@ def main():
     # packets between kernels cost a few per cent of throughput when every launch carries them)
     log = None if args.no_launch_timing else []
     timed_steps = 0
+    step_marks = []                      # one timing event per step on the stream the step ran on
     t0 = time.perf_counter()
     for i in range(args.steps):
         sample = log is not None and i % 8 == 4
         ops.LAUNCH_LOG = log if sample else None
         timed_steps += int(sample)
-        out = step()
-    ops.LAUNCH_LOG = None
+        out, _ = step()
+        ops.LAUNCH_LOG = None
+        mk = torch.cuda.Event(enable_timing=True)
+        mk.record(det.last_stream)
+        step_marks.append(mk)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
         torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+    elapsed_local = time.perf_counter() - t0
+    elapsed = elapsed_local
     assert out.shape == (world * B, cfg.n_cand, 9) and bool(torch.isfinite(out).all())
+    rank_info = None
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        # per-rank view (who is the straggler, which device, which geometry): one small all_gather
+        mine = torch.tensor([B * args.steps / elapsed_local, float(torch.cuda.current_device()),
+                             float(int(geom_hash[:6], 16))], dtype=torch.float64, device=dev)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = [r.cpu().tolist() for r in allr]
+        rank_info = {"backend": dist.get_backend(), "ranks_seen": dist.get_world_size(),
+                     "scenes_per_s_per_rank": {"min": round(min(p[0] for p in per_rank), 1),
+                                               "max": round(max(p[0] for p in per_rank), 1),
+                                               "all": [round(p[0], 1) for p in per_rank]},
+                     "device_index_per_rank": [int(p[1]) for p in per_rank],
+                     "geometry_hash_per_rank": [f"{int(p[2]):06x}" for p in per_rank],
+                     "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
+                     "note": "each rank autotunes its own geometry (same kernels, same bits; picks may differ "
+                             "by a few per cent in speed); elapsed is the MAX over ranks between two barriers"}
 
+    rc = 0
     if rank == 0:
         work = config.work_per_scene(cfg)
-        per_kind = {}
-        per_name = {}
-        for kind, name, e0, e1 in (log or []):
-            ms = e0.elapsed_time(e1)
-            per_kind[kind] = per_kind.get(kind, 0.0) + ms
-            per_name[(kind, name)] = per_name.get((kind, name), 0.0) + ms
         steps = args.steps
+        # completion-to-completion intervals of consecutive steps (steps alternate between the main
+        # streams; an interval between steps on different streams can be ~0 or ~2 steps: use pairs)
+        nm = max(1, args.main_streams)
+        gaps = [step_marks[i].elapsed_time(step_marks[i + nm]) / nm for i in range(0, len(step_marks) - nm)]
+        gaps.sort()
         res = {
             "metric": ("scenes/sec (16384-pt KITTI-shaped) through SA+cluster path" if args.config == "kitti" else
                        "scenes/sec (65536-pt nuScenes-shaped, configs[4]) through SA+cluster path"),
@@ -236,77 +317,108 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"{'configs[1-2]' if args.config == 'kitti' else 'configs[4]'}: batch {B} x {cfg.n_points}-pt "
-                                   f"{'KITTI' if args.config == 'kitti' else 'nuScenes'}-shaped scenes per GPU, "
+                                   f"{'KITTI' if args.config == 'kitti' else 'nuScenes'}-shaped scenes per GPU"
+                                   f"{' (DENSE variant: 20 m x 20 m extents)' if args.scene == 'dense' else ''}, "
                                    f"3-stage multi-radius SA backbone {'fp32' if args.dtype == 'f32' else 'bf16 (SPEC 14)'} + size-adaptive cluster layer + box head",
-                       "scenes_per_gpu": B, "global_batch": world * B, "n_points": cfg.n_points,
+                       "scenes_per_gpu": B, "global_batch": world * B, "n_points": cfg.n_points, "scene": args.scene,
                        "parallelism": f"batch-sharded x{world}, one all_gather of boxes",
                        "fps_overlap": not args.no_overlap, "fps_streams": args.fps_streams, "main_streams": args.main_streams, "opts": args.opt,
-                       "mlp_geometry": tuned if tuned is not None else "heuristic"},
+                       "mlp_geometry": tuned if tuned else "heuristic", "mlp_geometry_source": geometry_source,
+                       "mlp_geometry_hash": geom_hash},
         }
+        if gaps:
+            res["step_ms"] = {"p50": round(gaps[len(gaps) // 2], 3), "min": round(gaps[0], 3), "max": round(gaps[-1], 3),
+                              "note": f"completion-to-completion over {nm} consecutive steps / {nm} (HIP events on the main streams)"}
+        if rank_info is not None:
+            res["ranks"] = rank_info
+        elif world == 1:
+            res["ranks"] = {"backend": None, "ranks_seen": 1, "note": "N = 1: no process group, no collective; "
+                            "the RCCL path (N > 1) is unmeasured until the driver has a multi-GPU node"}
+        got_boxes = out[:B].cpu().numpy()          # rank 0's own scenes come first in the gathered tensor
+
         if log:
             tsteps = max(1, timed_steps)
-            mlp_ms = per_kind.get("mlp", 0.0) / tsteps
-            flops = work["mlp_flops"] * B                      # dense definition (SPEC.md §6)
-            exec_flops, row_frac, per_flops = executed_flops(det, points, cfg)
-            ach = exec_flops / (mlp_ms * 1e-3) / 1e12 if mlp_ms > 0 else 0.0
+            per_kind, per_name = {}, {}
+            for kind, name, e0, e1 in log:
+                ms = e0.elapsed_time(e1)
+                per_kind[kind] = per_kind.get(kind, 0.0) + ms
+                per_name[(kind, name)] = per_name.get((kind, name), 0.0) + ms
+            exec_flops, row_frac, per_flops = executed_flops(det, points, cfg, dense=(args.dtype == "bf16" and False))
             n_mlp = sum(1 for k, _, _, _ in log if k == "mlp") // tsteps
-            # the same launches without a sibling main stream (kernel durations are then not stretched
-            # by the other batch's kernels): one main stream, sampling streams still overlapped
-            ops.LAUNCH_LOG = []
-            for _ in range(5):
-                det(points, input_ready=True)
-            torch.cuda.synchronize()
-            iso_log, ops.LAUNCH_LOG = ops.LAUNCH_LOG, None
-            iso_ms = sum(e0.elapsed_time(e1) for k, _, e0, e1 in iso_log if k == "mlp") / 5
-            iso = exec_flops / (iso_ms * 1e-3) / 1e12 if iso_ms > 0 else 0.0
-            iso_name = {}
-            for k, n, e0, e1 in iso_log:
-                if k == "mlp":
-                    iso_name[n] = iso_name.get(n, 0.0) + e0.elapsed_time(e1) / 5
+            # ---- serial pass: ONE stream, sampling not overlapped, no sibling batch: every event
+            # interval is the duration of that launch's kernels (plus sub-microsecond packet gaps)
+            NSER = 5
+            det.overlap_fps, ov = False, det.overlap_fps
+            try:
+                det(points)
+                torch.cuda.synchronize()
+                ops.LAUNCH_LOG = []
+                for _ in range(NSER):
+                    det(points)
+                torch.cuda.synchronize()
+                ser_log, ops.LAUNCH_LOG = ops.LAUNCH_LOG, None
+            finally:
+                det.overlap_fps = ov
+                ops.LAUNCH_LOG = None
+            ser_kind, ser_name = {}, {}
+            for k, n, e0, e1 in ser_log:
+                ms = e0.elapsed_time(e1) / NSER
+                ser_kind[k] = ser_kind.get(k, 0.0) + ms
+                ser_name[(k, n)] = ser_name.get((k, n), 0.0) + ms
+            mlp_ms = ser_kind.get("mlp", 0.0)
+            ach = exec_flops / (mlp_ms * 1e-3) / 1e12 if mlp_ms > 0 else 0.0
             traffic = None
-            tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_v12_pmc_traffic.json")
-            if args.dtype == "f32" and args.config == "kitti" and os.path.exists(tpath):
+            tpath = os.path.join(ROOT, "profiles", TRAFFIC_FILE)
+            if args.dtype == "f32" and args.config == "kitti" and args.scene == "kitti" and os.path.exists(tpath):
                 # HBM bytes of the same launches from the committed rocprofv3 --pmc passes (bench.py cannot
                 # collect PMC counters itself): corrected FETCH_SIZE + WRITE_SIZE, per step like `achieved`
                 tj = json.load(open(tpath))
                 traffic = tj["fetch_bytes_per_step"] + tj["write_bytes_per_step"]
+            ov_ms = per_kind.get("mlp", 0.0) / tsteps
             res["roofline"] = {
-                "kernel": f"{'mlp_chain_kernel' if args.dtype == 'f32' else 'mlp_bf16_kernel'} ({n_mlp} launches per step, summed)",
+                "kernel": f"{'mlp_chain / mlp_multi kernels' if args.dtype == 'f32' else 'mlp_bf16_kernel'} ({n_mlp} launches per step, summed)",
                 "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK,
                 "unit": "TFLOP/s", "frac": round(ach / PEAK, 4), "traffic": traffic,
-                "traffic_note": "bytes per step from profiles/r01_v12_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, "
-                                "the step's MLP dispatches summed); ~1.1 GB per 2.8 ms = 0.4 TB/s: the kernel is MFMA-bound, not HBM-bound",
-                "flop_per_step": exec_flops, "ms_per_step": round(mlp_ms, 3), "sampled_steps": tsteps,
-                "note": "durations are HIP-event intervals on the launching stream inside the timed region, where "
-                        "two main streams run consecutive batches side by side (kernels share the chip, so "
-                        "their intervals stretch); achieved counts the flops the kernel EXECUTES: grouped rows that only repeat a "
-                        "group's first neighbour (ball-query padding) are skipped exactly (a duplicate "
-                        "row cannot change the max-pool), so executed < dense",
-                "single_main_stream": {"ms_per_step": round(iso_ms, 3), "achieved": round(iso, 2),
-                                       "frac": round(iso / PEAK, 4),
-                                       "note": "same launches, consecutive batches NOT overlapped on a second main stream"},
-                "dense_flop_per_step": flops, "executed_row_fraction": round(row_frac, 4),
-                "dense_equivalent_tflops": round(flops / (mlp_ms * 1e-3) / 1e12, 2) if mlp_ms > 0 else 0.0}
+                "traffic_note": f"HBM bytes per step of the step's MLP dispatches from profiles/{TRAFFIC_FILE} (rocprofv3 --pmc, "
+                                "FETCH_SIZE and WRITE_SIZE in separate passes, gfx950 corrections of MI355X_MICROARCH.md); "
+                                "the kernel is MFMA-bound, not HBM-bound" if traffic else None,
+                "flop_per_step": exec_flops, "ms_per_step": round(mlp_ms, 3),
+                "note": "achieved = flops the kernels EXECUTE per step / the summed duration of the step's MLP launches, "
+                        "HIP events on the launching stream in a serial pass (one stream, nothing overlapped), mean of "
+                        f"{NSER} passes right after the timed region.  Grouped rows that only repeat a group's first neighbour "
+                        "(ball-query padding) are skipped exactly (a duplicate row cannot change the max-pool), so executed "
+                        "flops < SPEC-dense flops; tools/roofline_from_profiles.py recomputes the same fraction from the "
+                        "committed rocprofv3 kernel trace",
+                "executed_row_fraction": round(row_frac, 4), "spec_dense_flop_per_step": work["mlp_flops"] * B,
+                "in_timed_region": {"ms_per_step_summed": round(ov_ms, 3), "sampled_steps": tsteps,
+                                    "note": "the same launches inside the timed region, where two main streams run consecutive "
+                                            "batches side by side: intervals stretch (kernels share the chip) and their sum may "
+                                            "exceed ms_per_step; not a kernel-quality figure"}}
             kern = []
-            fps_ms = per_kind.get("fps", 0.0) / tsteps
+            fps_ms = ser_kind.get("fps", 0.0)
             if fps_ms > 0:
                 nested = getattr(det, "nested_fps_shortcut", True)
                 serial = cfg.stages[0].npoint if nested else work["fps_steps"]
-                kern.append({"kernel": "fps_sort_kernel + fps_cell_kernel (sampling streams; "
+                kern.append({"kernel": "fps_sort_kernel + fps_cell_kernel ("
                                        + ("stage 1 only: stages 2-3 reuse its prefix, proven identical)" if nested else "3 stages)"),
                              "ms_per_step": round(fps_ms, 3),
                              "updates_per_s": round(work["fps_updates"] * B / (fps_ms * 1e-3) / 1e9, 2),
                              "unit": "G distance-updates/s (plain-scan equivalent; most are skipped exactly)",
                              "serial_steps": serial,
                              "us_per_serial_step": round(1e3 * fps_ms / serial, 3),
-                             "bound": "serial latency (neither HBM nor MFMA)"})
-            bq_ms = per_kind.get("ball_query", 0.0) / tsteps
+                             "bound": "serial latency (neither HBM nor MFMA); in the timed region it runs on sampling streams under the MLP kernels"})
+            bq_ms = ser_kind.get("ball_query", 0.0)
             if bq_ms > 0:
                 gbps = work["ball_query_bytes"] * B / (bq_ms * 1e-3) / 1e9
-                kern.append({"kernel": "ball_query_kernel (4 launches per step)", "ms_per_step": round(bq_ms, 3),
+                kern.append({"kernel": "ball query: grid_build/grid_query (SA1, SA2) + ball_query_kernel scan (SA3, adaptive cluster query)",
+                             "ms_per_step": round(bq_ms, 3),
+                             "per_launch_ms": {n: round(v, 4) for (k, n), v in sorted(ser_name.items()) if k == "ball_query"},
                              "bound": "hbm", "achieved": round(gbps, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
-                             "frac": round(gbps / PEAK_HBM_GBPS, 5),
-                             "pair_tests_per_s": round(work["pair_tests"] * B / (bq_ms * 1e-3) / 1e12, 3)})
+                             "frac": round(gbps / PEAK_HBM_GBPS, 5), "algorithmic_bytes_per_step": work["ball_query_bytes"] * B,
+                             "pair_tests_per_s": round(work["pair_tests"] * B / (bq_ms * 1e-3) / 1e12, 3),
+                             "note": "serial pass, HIP events per launch.  BASELINE's >= 70 % of HBM peak is not reachable: the "
+                                     "PMC traffic equals the algorithmic bytes (nothing is re-read), the kernels are bound by the "
+                                     "latency of the per-centroid dependent instruction chain (LDS bitmap restore of index order), not by bytes"})
             # the unfused group_points operator (not on the fused path; part of the drop-in surface):
             # an HBM-bound gather, timed here on the SA2 branch shape with its own HIP events
             gC, gN, gM, gS = 64, 4096, 1024, 32
@@ -328,19 +440,58 @@ def main():
                          "frac": round(g_bytes / (g_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4),
                          "algorithmic_bytes": g_bytes})
             res["kernels"] = kern
-            def fl(n):      # a merged dispatch is named "a+b+c"
-                return sum(per_flops.get(x, 0) for x in n.split("+")) if "+" in n else per_flops.get(n, 0)
-            res["mlp_launches"] = {n: {"ms": round(v / tsteps, 3), "executed_gflop": round(fl(n) / 1e9, 1),
-                                       "tflops": round(fl(n) / (v / tsteps * 1e-3) / 1e12, 1),
-                                       "ms_single_stream": round(iso_name.get(n, 0.0), 3),
-                                       "tflops_single_stream": round(fl(n) / (iso_name[n] * 1e-3) / 1e12, 1) if iso_name.get(n) else None}
-                                   for (k, n), v in sorted(per_name.items()) if k == "mlp"}
+            res["mlp_launches"] = {n: {"ms": round(v, 4), "executed_gflop": round(flops_of(n, per_flops) / 1e9, 2),
+                                       "tflops": round(flops_of(n, per_flops) / (v * 1e-3) / 1e12, 1) if v > 0 else None,
+                                       "frac": round(flops_of(n, per_flops) / (v * 1e-3) / 1e12 / PEAK, 3) if v > 0 else None,
+                                       "ms_in_timed_region": round(per_name.get(("mlp", n), 0.0) / tsteps, 4)}
+                                   for (k, n), v in sorted(ser_name.items()) if k == "mlp"}
+            res["mlp_launch_order"] = [n for k, n, _, _ in ser_log[:len(ser_log) // NSER] if k == "mlp"]
+
+        # ---- dense leg: the same kernels with the padding skip off (every grouped row computed) ----
+        if not args.no_dense_leg and args.dtype == "f32" and world == 1:
+            _lib.set_option("mlp_nodedup", 1)
+            try:
+                for _ in range(2):
+                    det.submit(points)
+                torch.cuda.synchronize()
+                nd = 8
+                td = time.perf_counter()
+                for _ in range(nd):
+                    dout, _ = det.submit(points)
+                torch.cuda.synchronize()
+                dd = time.perf_counter() - td
+            finally:
+                _lib.set_option("mlp_nodedup", 0)
+            res["dense_leg"] = {"value": round(B * nd / dd, 1), "unit": "scenes/s", "steps": nd,
+                                "tflops_spec_dense": round(work["mlp_flops"] * B * nd / dd / 1e12, 1),
+                                "same_boxes": bool(torch.equal(dout, out[:B])),
+                                "note": "sad_set_option(mlp_nodedup=1): every padded grouped row is computed (SPEC-dense flops, "
+                                        "geometry tuned for the sparse rows) - the floor for scenes whose neighbourhoods are all "
+                                        "full; the headline's 13x fewer rows are a property of the KITTI-shaped scene density "
+                                        "(~3 points per square metre), not of the kernels"}
+
+        want = None
         if not args.no_cpu and world == 1:
-            res["cpu_baseline"] = cpu_baseline(cfg, weights, args.cpu_scenes)
+            n_cpu = max(1, min(B, args.cpu_scenes))
+            res["cpu_baseline"], want = cpu_baseline(cfg, weights, points_np[:n_cpu])
+        else:
+            import oracle
+            oracle.build()
+            want = oracle.detector_forward(points_np[:min(B, 4)], cfg, weights, skip_padding=True)
+        if args.dtype == "f32":
+            res["parity_check"] = parity_check(got_boxes, want)
+            if not res["parity_check"]["ok"]:
+                rc = 1
+        else:
+            res["parity_check"] = {"ok": None, "note": "bf16 mode (SPEC 14) is verified stage by stage with teacher forcing in "
+                                                       "tests/test_gpu_bf16.py; an end-to-end box comparison is not meaningful "
+                                                       "(one rounding flip may move an index decision)"}
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if rc:
+        raise SystemExit(rc)
 
 
 if __name__ == "__main__":

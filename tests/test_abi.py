@@ -98,3 +98,57 @@ def test_synth_is_deterministic(sad):
     np.testing.assert_array_equal(a, b)
     assert not np.array_equal(a, synth.make_scene(4))
     assert a[:, 0].min() >= 0 and a[:, 0].max() <= 70.4 and abs(a[:, 1]).max() <= 40
+
+
+def test_boundary_is_reentrant_across_threads(sad):
+    """SURVEY.md §8(b) "re-entrant, no global mutable state": sad_last_error is thread-local, the
+    tuning knobs are atomics and the argument-error paths share nothing — four threads hammering
+    different failing calls (ctypes releases the GIL around each call) always read back their OWN
+    message, while a fifth flips an option the whole time."""
+    import threading
+    from sad_amd import _lib
+    L = _lib.lib()
+    buf = ctypes.create_string_buffer(64)
+    p = ctypes.cast(buf, ctypes.c_void_p)
+    cases = [
+        (lambda: L.sad_set_option(b"bogus_alpha", 1), b"bogus_alpha"),
+        (lambda: L.sad_set_option(b"bogus_beta", 1), b"bogus_beta"),
+        (lambda: L.sad_fps_f32(None, 1, 8, 4, None, None, None), b"sad_fps_f32"),
+        (lambda: L.sad_knn_f32(p, p, 1, 8, 2, 65, p, None), b"sad_knn_f32"),
+    ]
+    errors = []
+    stop = threading.Event()
+
+    def flipper():
+        v = 0
+        while not stop.is_set():
+            L.sad_set_option(b"mlp_noxcd", v & 1)
+            v += 1
+        L.sad_set_option(b"mlp_noxcd", 0)
+
+    def worker(call, needle):
+        for _ in range(3000):
+            if call() != -1:
+                errors.append((needle, "return code"))
+                return
+            msg = L.sad_last_error()
+            if needle not in msg:
+                errors.append((needle, msg))
+                return
+
+    f = threading.Thread(target=flipper)
+    f.start()
+    ts = [threading.Thread(target=worker, args=c) for c in cases]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    stop.set()
+    f.join()
+    assert not errors, errors[:3]
+    # a thread that never failed sees an empty message, whatever the others did
+    seen = []
+    t = threading.Thread(target=lambda: seen.append(L.sad_last_error()))
+    t.start()
+    t.join()
+    assert seen == [b""]
