@@ -347,22 +347,27 @@ def main():
             n_mlp = sum(1 for k, _, _, _ in log if k == "mlp") // tsteps
             # ---- serial pass: ONE stream, sampling not overlapped, no sibling batch: every event
             # interval is the duration of that launch's kernels (plus sub-microsecond packet gaps)
-            NSER = 5
+            # (a pass is synchronised before the next starts and the per-launch MEDIAN over the passes is
+            # used: an interval also contains any time the stream waited for the host, e.g. one allocator miss)
+            NSER = 7
             det.overlap_fps, ov = False, det.overlap_fps
+            passes = []
             try:
                 det(points)
                 torch.cuda.synchronize()
-                ops.LAUNCH_LOG = []
                 for _ in range(NSER):
+                    ops.LAUNCH_LOG = []
                     det(points)
-                torch.cuda.synchronize()
-                ser_log, ops.LAUNCH_LOG = ops.LAUNCH_LOG, None
+                    torch.cuda.synchronize()
+                    passes.append(ops.LAUNCH_LOG)
+                    ops.LAUNCH_LOG = None
             finally:
                 det.overlap_fps = ov
                 ops.LAUNCH_LOG = None
+            ser_log = passes[0]
             ser_kind, ser_name = {}, {}
-            for k, n, e0, e1 in ser_log:
-                ms = e0.elapsed_time(e1) / NSER
+            for li, (k, n, _, _) in enumerate(ser_log):
+                ms = sorted(p[li][2].elapsed_time(p[li][3]) for p in passes)[NSER // 2]
                 ser_kind[k] = ser_kind.get(k, 0.0) + ms
                 ser_name[(k, n)] = ser_name.get((k, n), 0.0) + ms
             mlp_ms = ser_kind.get("mlp", 0.0)
@@ -384,7 +389,7 @@ def main():
                                 "the kernel is MFMA-bound, not HBM-bound" if traffic else None,
                 "flop_per_step": exec_flops, "ms_per_step": round(mlp_ms, 3),
                 "note": "achieved = flops the kernels EXECUTE per step / the summed duration of the step's MLP launches, "
-                        "HIP events on the launching stream in a serial pass (one stream, nothing overlapped), mean of "
+                        "HIP events on the launching stream in a serial pass (one stream, nothing overlapped), per-launch median of "
                         f"{NSER} passes right after the timed region.  Grouped rows that only repeat a group's first neighbour "
                         "(ball-query padding) are skipped exactly (a duplicate row cannot change the max-pool), so executed "
                         "flops < SPEC-dense flops; tools/roofline_from_profiles.py recomputes the same fraction from the "
@@ -445,7 +450,7 @@ def main():
                                        "frac": round(flops_of(n, per_flops) / (v * 1e-3) / 1e12 / PEAK, 3) if v > 0 else None,
                                        "ms_in_timed_region": round(per_name.get(("mlp", n), 0.0) / tsteps, 4)}
                                    for (k, n), v in sorted(ser_name.items()) if k == "mlp"}
-            res["mlp_launch_order"] = [n for k, n, _, _ in ser_log[:len(ser_log) // NSER] if k == "mlp"]
+            res["mlp_launch_order"] = [n for k, n, _, _ in ser_log if k == "mlp"]
 
         # ---- dense leg: the same kernels with the padding skip off (every grouped row computed) ----
         if not args.no_dense_leg and args.dtype == "f32" and world == 1:
