@@ -18,6 +18,29 @@ int launch_rowscan(const int32_t *cnt, int ngroups, int S, int R, int *tab, hipS
                    const int32_t *idx = nullptr, int N = 0, int M = 1);
 int launch_fps_cellg(const float *xyz, int B, int N, int M, int32_t *idx, void *workspace, hipStream_t st);
 int launch_fps_bucket(const float *xyz, int B, int N, int M, int32_t *idx, void *workspace, hipStream_t st);
+// Register-resident chain kernel (csrc/mlp_reg.hip): one chain of a dispatch / a dispatch of up to
+// REG_MAX_CHAINS chains of one shape family (prepared in mlp_chain.hip, launched by launch_reg).
+constexpr int REG_MAX_CHAINS = 3;
+struct RegChain {
+    const float *xyz, *new_xyz, *feat, *packed;
+    float *out;
+    const int *rowtab;             // hdr of the row-packing table: [0] = packed rows
+    const int *row_src, *row_gid;  // row map (see rowscan_kernel)
+    long long off[3];              // float offset of layer l inside `packed` (bias block, then A fragments)
+    int np[3];                     // padded output channels of layer l
+    int ld_feat, C, cpr;           // cpr = C / 4 when feature rows are read as 16-byte chunks, else 0
+    int ld_out, col_off, cout_last, vec_out;
+};
+struct RegMulti {
+    RegChain c[REG_MAX_CHAINS];
+    int shape[REG_MAX_CHAINS];
+    int n;
+    int *counter;                  // zeroed work counter (tiles of all chains form one list)
+    long long max_tiles;           // upper bound of the tile count (grid sizing)
+};
+int reg_shape_id(int L, const int *kp, const int *np);   // -1: no compiled shape
+int reg_family(int shape);
+int launch_reg(const RegMulti &mp, hipStream_t st);
 enum { OPT_FPS_DPP = 0, OPT_MLP_RW = 1, OPT_MLP_BUDGET_KB = 2, OPT_BQ_VARIANT = 3, OPT_FPS_VARIANT = 4, OPT_MLP_FORCE = 5, OPT_MLP_DEDUP_F = 6, OPT_MLP_NODEDUP = 7, OPT_FPS_THREADS = 8, OPT_MLP_STATIC = 9, OPT_GROUP_VARIANT = 10, OPT_MLP_DYN_SLOTS = 11, OPT_MLP_NOXCD = 12, OPT_COUNT };
 
 inline int fail(int code, const char *fmt, ...) {

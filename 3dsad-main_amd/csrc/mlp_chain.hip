@@ -1073,6 +1073,10 @@ struct Prepared {
     long long nblocks;
     int W, RW, CW;
     bool launched;      // the VALU kernel was launched instead (nothing left to do)
+    bool reg;           // geometry 2: register-resident chain kernel (csrc/mlp_reg.hip); `rc` is filled, p is not
+    sad::RegChain rc;
+    int reg_shape;
+    long long reg_tiles;   // upper bound of the tile count
 };
 int launch_prepared(const Prepared &q, hipStream_t st);
 }  // namespace
@@ -1080,6 +1084,7 @@ int launch_prepared(const Prepared &q, hipStream_t st);
 // Validation, geometry choice and the row-packing scan of one chain; fills `q` for the launch.
 static int prepare_chain(const sad_mlp_args *a, sad_stream_t stream, Prepared &q) {
     q.launched = false;
+    q.reg = false;
     SAD_REQUIRE(a, "sad_mlp_chain_f32: NULL args");
     if (int e = check_dims("sad_mlp_chain_f32", a->L, a->dims)) return e;
     const bool grouped = a->idx != nullptr;
@@ -1139,6 +1144,33 @@ static int prepare_chain(const sad_mlp_args *a, sad_stream_t stream, Prepared &q
         p.cshift = cs;
     } else {
         p.cpr = 0; p.cshift = 0;
+    }
+    // ---- geometry 2: register-resident chain (one wave per 32-row tile, no LDS round trips, no barriers) ----
+    if (geom_wg == 2) {
+        const int shape = grouped ? sad::reg_shape_id(a->L, g.kp, g.np) : -1;
+        const bool all_relu = (a->relu_mask & ((1 << a->L) - 1)) == (1 << a->L) - 1;
+        const bool feat_ok = a->C == 0 || a->C == 1 || p.cpr > 0;
+        if (shape < 0 || !all_relu || !feat_ok || !a->cnt || !a->workspace)
+            return sad::fail(SAD_EUNSUPPORTED, "sad_mlp_chain_f32: geometry 2 (register-resident chain) needs a compiled 3-layer shape, "
+                                               "cnt + workspace and 16-byte feature rows");
+        SAD_REQUIRE((uintptr_t)a->workspace % 16 == 0, "sad_mlp_chain_f32: workspace must be 16-byte aligned");
+        SAD_REQUIRE(p.total_groups < (1LL << 30), "sad_mlp_chain_f32: too many groups");
+        int *tab = (int *)a->workspace;
+        if (int e = sad::launch_rowscan(a->cnt, (int)p.total_groups, a->S, 32, tab, (hipStream_t)stream,
+                                        sad::get_option(sad::OPT_MLP_NODEDUP), a->idx, a->N, a->M)) return e;
+        sad::RegChain &rc = q.rc;
+        rc.xyz = a->xyz; rc.new_xyz = a->new_xyz; rc.feat = a->feat; rc.packed = a->packed; rc.out = a->out;
+        rc.rowtab = tab;
+        rc.row_src = tab + 4 + (p.total_groups + 1) + (p.total_groups * a->S / 32 + 2) + (p.total_groups / 1024 + 2);
+        rc.row_gid = rc.row_src + p.total_groups * a->S;
+        for (int l = 0; l < 3; ++l) { rc.off[l] = g.off[l]; rc.np[l] = g.np[l]; }
+        rc.ld_feat = a->ld_feat; rc.C = a->C; rc.cpr = p.cpr;
+        rc.ld_out = a->ld_out; rc.col_off = a->col_off; rc.cout_last = cout; rc.vec_out = p.vec_out;
+        q.reg = true;
+        q.reg_shape = shape;
+        q.reg_tiles = (p.total_groups * a->S + 31) / 32;
+        q.W = -1;
+        return SAD_OK;
     }
     // ---- narrow 3-layer grouped chains can run on the vector ALU (geometry 1; autotune tries it) ----
     {
@@ -1298,7 +1330,24 @@ int launch_mlp2(const MlpParams &p, size_t lds, long long nblocks, hipStream_t s
     return sad::check_launch("sad_mlp_chain_f32");
 }
 
+int launch_reg_chains(const Prepared *const *qs, int n, hipStream_t st) {
+    sad::RegMulti mp{};
+    mp.n = n;
+    mp.max_tiles = 0;
+    for (int i = 0; i < n; ++i) {
+        mp.c[i] = qs[i]->rc;
+        mp.shape[i] = qs[i]->reg_shape;
+        mp.max_tiles += qs[i]->reg_tiles;
+    }
+    mp.counter = const_cast<int *>(mp.c[0].rowtab) + 2;      // zeroed by chain 0's rowscan
+    return sad::launch_reg(mp, st);
+}
+
 int launch_prepared(const Prepared &q, hipStream_t st) {
+    if (q.reg) {
+        const Prepared *one = &q;
+        return launch_reg_chains(&one, 1, st);
+    }
     const MlpParams &p = q.p;
     const size_t lds = q.lds;
     const long long nblocks = q.nblocks;
@@ -1344,9 +1393,27 @@ SAD_API int sad_mlp_chain_multi_f32(const sad_mlp_args *const *args, int n, sad_
     Prepared q[MULTI_MAX];
     for (int i = 0; i < n; ++i)
         if (int e = prepare_chain(args[i], stream, q[i])) return e;
+    // register-resident chains of one shape family: one dispatch, tiles of the heaviest chain first
+    {
+        bool all_reg = n > 1 && n <= sad::REG_MAX_CHAINS;
+        for (int i = 0; i < n; ++i) all_reg = all_reg && q[i].reg && sad::reg_family(q[i].reg_shape) == sad::reg_family(q[0].reg_shape);
+        if (all_reg) {
+            const Prepared *ord[MULTI_MAX];
+            for (int i = 0; i < n; ++i) ord[i] = &q[i];
+            auto heavy = [&](const Prepared *s) {       // MACs per row x rows (upper bound)
+                double m = 0;
+                for (int l = 0; l < 3; ++l) m += (double)s->rc.np[l] * (l == 0 ? 8.0 * 17 : s->rc.np[l - 1]);
+                return m * (double)s->reg_tiles;
+            };
+            for (int i = 0; i < n; ++i)
+                for (int k = i + 1; k < n; ++k)
+                    if (heavy(ord[k]) > heavy(ord[i])) { const Prepared *t = ord[i]; ord[i] = ord[k]; ord[k] = t; }
+            return launch_reg_chains(ord, n, st);
+        }
+    }
     // one dispatch needs a common wave count and nothing already launched; otherwise one by one
     bool merge = n > 1;
-    for (int i = 0; i < n; ++i) merge = merge && !q[i].launched && q[i].W == q[0].W && q[i].W != 16;
+    for (int i = 0; i < n; ++i) merge = merge && !q[i].launched && !q[i].reg && q[i].W == q[0].W && q[i].W != 16;
     if (!merge) {
         for (int i = 0; i < n; ++i)
             if (!q[i].launched)

@@ -352,12 +352,13 @@ class PackedMLP:
     def _tune(self, a: MlpArgs) -> int:
         stream = torch.cuda.current_stream()
         best, best_ms = 0, None
-        for code in self._CANDIDATES + ([1] if a.idx else []):   # 1 = VALU row-per-lane kernel (narrow chains)
+        # 1 = VALU row-per-lane kernel (narrow chains), 2 = register-resident chain kernel (csrc/mlp_reg.hip)
+        for code in self._CANDIDATES + ([1, 2] if a.idx else []):
             a.geometry = code
             ms = self._time(a, stream)
             if ms is not None and (best_ms is None or ms < best_ms * 0.98):   # prefer earlier entries on ties
                 best, best_ms = code, ms
-        if a.idx:   # second sweep: groups per workgroup (how much padding is expected)
+        if a.idx and best > 2:   # second sweep: groups per workgroup (how much padding is expected)
             base = best
             for f in self._F_CODES:
                 a.geometry = base + 1000 * f

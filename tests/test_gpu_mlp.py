@@ -416,3 +416,76 @@ def test_valu_kernel_parity(orc, sad, dev, mlp):
     finally:
         _lib.set_option("mlp_force", 0)
     assert np.array_equal(got, want) and np.array_equal(got2, want)
+
+
+REG_CASES = [
+    # (B, N, M, S, C, mlp, radius) — every compiled shape of the register-resident chain kernel (geometry 2)
+    (2, 3000, 700, 32, 1, [16, 16, 32], 0.08),        # SA1 narrow branch (single feature channel, strided view)
+    (2, 3000, 700, 64, 1, [32, 32, 64], 0.15),        # SA1 wide branch, nsample 64
+    (2, 3000, 500, 32, 4, [16, 16, 32], 0.1),         # nuScenes SA1 (4 feature channels: one 16-byte chunk)
+    (1, 1024, 256, 32, 0, [64, 64, 128], 0.2),        # BASELINE configs[0] (no features)
+    (2, 2000, 400, 32, 64, [64, 64, 128], 0.2),       # SA2
+    (2, 2000, 400, 64, 64, [64, 96, 128], 0.35),
+    (2, 1024, 300, 32, 128, [128, 128, 256], 0.3),    # SA3
+    (2, 1024, 300, 32, 128, [128, 192, 256], 0.5),
+    (2, 1024, 300, 32, 128, [128, 256, 256], 0.7),
+    (1, 200, 19, 8, 1, [16, 16, 32], 0.5),            # fewer rows than one tile
+]
+
+
+@pytest.mark.parametrize("B,N,M,S,C,mlp,r", REG_CASES)
+def test_register_chain_kernel_parity(orc, sad, dev, B, N, M, S, C, mlp, r):
+    """geometry 2 = one wave carries a 32-row tile through the whole chain in registers (csrc/mlp_reg.hip):
+    bit-identical to the oracle's fmaf chains and to the tiled kernel, with ragged groups, groups that
+    straddle tiles (atomic max merge) and the padding skip both on and off."""
+    import torch
+    from sad_amd import _lib, ops, synth
+    rng = np.random.default_rng(N + M + S + C + sum(mlp))
+    xyz = rng.uniform(0, 1, (B, N, 3)).astype(np.float32)
+    pts4 = rng.uniform(0, 1, (B, N, 4)).astype(np.float32)
+    new_xyz = np.ascontiguousarray(xyz[:, :M])
+    X, Cn = _t(xyz, dev), _t(new_xyz, dev)
+    if C == 1:        # the detector's SA1 input: intensity as a strided view of [B,N,4]
+        P = _t(pts4, dev)
+        F = P[:, :, 3:]
+        feat = np.ascontiguousarray(pts4[:, :, 3:])
+    elif C:
+        feat = rng.normal(size=(B, N, C)).astype(np.float32)
+        F = _t(feat, dev)
+    else:
+        feat, F = None, None
+    idxs, cnts = ops.ball_query_multi((r,), (S,), X, Cn, return_counts=True)
+    layers = synth.make_mlp_weights([C + 3] + mlp, rng)
+    want = orc.sa_group_mlp_max(xyz, feat, new_xyz, idxs[0].cpu().numpy(), layers)
+    net = ops.PackedMLP(layers, True, dev)
+    tiled = net.grouped(X, F, Cn, idxs[0], cnt=cnts[0]).cpu().numpy()
+    assert np.array_equal(tiled, want)
+    _lib.set_option("mlp_force", 2)
+    try:
+        got = net.grouped(X, F, Cn, idxs[0], cnt=cnts[0]).cpu().numpy()
+        _lib.set_option("mlp_nodedup", 1)
+        dense = net.grouped(X, F, Cn, idxs[0], cnt=cnts[0]).cpu().numpy()
+    finally:
+        _lib.set_option("mlp_force", 0)
+        _lib.set_option("mlp_nodedup", 0)
+    rows = int(cnts[0].clamp(min=1).sum().item())
+    print(f"[parity] register chain {[C + 3] + mlp} S={S}: {rows} packed rows, bit-exact={np.array_equal(got, want)}")
+    assert np.array_equal(got, want), f"max diff {np.abs(got - want).max():.3e}"
+    assert np.array_equal(dense, want), "padding skip off: different result"
+
+
+def test_register_chain_refuses_other_shapes(orc, sad, dev):
+    """A chain without a compiled shape is refused with SAD_EUNSUPPORTED (autotuners skip it), never wrong."""
+    from sad_amd import _lib, ops, synth
+    rng = np.random.default_rng(5)
+    xyz = rng.uniform(0, 1, (1, 500, 3)).astype(np.float32)
+    X = _t(xyz, dev)
+    Cn = X[:, :50].contiguous()
+    idxs, cnts = ops.ball_query_multi((0.3,), (16,), X, Cn, return_counts=True)
+    net = ops.PackedMLP(synth.make_mlp_weights([3, 24, 40], rng), True, dev)
+    _lib.set_option("mlp_force", 2)
+    try:
+        with pytest.raises(RuntimeError, match=r"\(-2\)"):
+            net.grouped(X, None, Cn, idxs[0], cnt=cnts[0])
+    finally:
+        _lib.set_option("mlp_force", 0)

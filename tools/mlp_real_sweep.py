@@ -7,6 +7,9 @@ import sad_amd
 from sad_amd import config, ops, synth, _lib
 from sad_amd.detector import SADDetector
 dev = torch.device("cuda:0")
+for kv in filter(None, os.environ.get("SAD_OPTS", "").split(",")):      # e.g. SAD_OPTS=mlp_dyn_slots=1
+    k, v = kv.split("=")
+    _lib.set_option(k, int(v))
 name = sys.argv[1]
 codes = [int(c) for c in sys.argv[2:]] or [0]
 cfg = config.KITTI
