@@ -14,6 +14,15 @@ namespace sad {
 
 void set_error(const char *fmt, ...);
 int get_option(int which);
+// row-packing scan of one chain / of up to three chains in the same two launches (csrc/mlp_chain.hip)
+struct ScanJob {
+    const int32_t *cnt, *idx;
+    int *tab, *blk_sum, *row_src, *row_gid;
+    int ngroups, S, N, M, nodedup, R, blk0;
+};
+struct ScanMulti { ScanJob j[3]; int n; };
+ScanJob make_scan_job(const int32_t *cnt, int ngroups, int S, int R, int *tab, int nodedup, const int32_t *idx, int N, int M);
+int launch_rowscan_multi(const ScanJob *jobs, int n, hipStream_t st);
 int launch_rowscan(const int32_t *cnt, int ngroups, int S, int R, int *tab, hipStream_t st, int nodedup = 0,
                    const int32_t *idx = nullptr, int N = 0, int M = 1);
 int launch_fps_cellg(const float *xyz, int B, int N, int M, int32_t *idx, void *workspace, hipStream_t st);

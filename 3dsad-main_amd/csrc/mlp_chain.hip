@@ -227,110 +227,59 @@ __device__ __forceinline__ void mma_ktile2(f32x16 &acc0, f32x16 &acc1, const flo
 }
 
 // ---- global row packing ------------------------------------------------------------------------
-// With per-group counts from the ball query, one workgroup prefix-sums them over ALL groups of the
-// launch, so every pass of R rows is full and passes can be handed out dynamically (perfect balance).
-// Table (ints): hdr[0] = total rows, hdr[1] = passes, hdr[2] = next pass (work counter),
-// row_start[ngroups + 1] from offset 4, then pass_first[p] = group that contains row p*R.
+// With per-group counts from the ball query, the surviving rows of ALL groups of a launch are numbered
+// consecutively (prefix sum of the counts), so every pass / tile of R rows is full.  The table (ints):
+// hdr[0] = total rows, hdr[1] = passes of R rows, hdr[2] = 0 (work counter), then (unused, kept for the
+// layout) row_start / pass_first areas, block sums, and the ROW MAP: for every packed row its source
+// point b*N + idx[g*S + s] and its group g (bit 30 set when the group lies inside one 32-row tile of
+// the packed order) — the MLP kernels find the rows of a tile with two coalesced loads.
+// Two launches serve up to three chains at once (the branches of a stage): block sums, then every
+// block adds the sums of the blocks before it to its own scan and writes its part of the row map
+// COOPERATIVELY by destination row (coalesced; each row finds its group by a binary search of the
+// block's offsets in LDS) — a thread walking its own group's rows wrote 4 bytes per lane per step at
+// scattered addresses and took 22 us for 16 384 groups; this takes ~4.
 constexpr int SCAN_T = 1024;
-// Row map (optional, rowmap != NULL): for every packed row its source point b*N + idx[g*S + s] and
-// its group g (bit 30 set when the group lies inside one 32-row tile of the packed order), so the MLP
-// kernel finds the rows of a pass with two coalesced loads instead of table look-ups and a search.
-struct RowMap {
-    int *src;                 // [total rows] source point
-    int *gid;                 // [total rows] group | WHOLE_BIT
-    const int32_t *idx;       // [ngroups, S]
-    int N, M;
-};
 constexpr int WHOLE_BIT = 1 << 30;
 
-__device__ __forceinline__ void expand_group(const RowMap &rm, int g, int S, int run, int c) {
-    if (!rm.src) return;
-    const long long b = g / rm.M;
-    const int whole = ((run >> 5) == ((run + c - 1) >> 5)) ? WHOLE_BIT : 0;
-    for (int s2 = 0; s2 < c; ++s2) {
-        rm.src[run + s2] = (int)(b * rm.N + rm.idx[(long long)g * S + s2]);
-        rm.gid[run + s2] = g | whole;
-    }
+__device__ __forceinline__ int scan_job_of(const sad::ScanMulti &sm, int block, int &local) {
+    int ji = 0;
+    while (ji + 1 < sm.n && block >= sm.j[ji + 1].blk0) ++ji;
+    local = block - sm.j[ji].blk0;
+    return ji;
 }
 
-__global__ __launch_bounds__(SCAN_T) void rowscan_kernel(const int32_t *__restrict__ cnt, int ngroups, int S,
-                                                         int nodedup, int R, int *__restrict__ tab, RowMap rm) {
-    __shared__ int wsum[16];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    int *row_start = tab + 4;
-    int *pass_first = tab + 4 + ngroups + 1;
-    const int per = (ngroups + SCAN_T - 1) / SCAN_T;
-    const int g_lo = tid * per, g_hi = g_lo + per < ngroups ? g_lo + per : ngroups;
-    int sum = 0;
-    for (int g = g_lo; g < g_hi; ++g) {
-        int c = cnt[g];
-        c = c < 1 ? 1 : (c > S ? S : c);
-        sum += nodedup ? S : c;
-    }
-    int incl = sum;
-    for (int off = 1; off < 64; off <<= 1) {
-        const int v = __shfl_up(incl, off, 64);
-        if (lane >= off) incl += v;
-    }
-    if (lane == 63) wsum[wave] = incl;
-    __syncthreads();
-    int base = incl - sum;
-    for (int w = 0; w < wave; ++w) base += wsum[w];
-    int run = base;
-    for (int g = g_lo; g < g_hi; ++g) {
-        int c = cnt[g];
-        c = c < 1 ? 1 : (c > S ? S : c);
-        c = nodedup ? S : c;
-        row_start[g] = run;
-        // passes whose first row lies inside this group
-        for (int pp = (run + R - 1) / R; pp * R < run + c; ++pp) pass_first[pp] = g;
-        expand_group(rm, g, S, run, c);
-        run += c;
-    }
-    if (tid == SCAN_T - 1) {
-        int total = 0;
-        for (int w = 0; w < 16; ++w) total += wsum[w];
-        row_start[ngroups] = total;
-        tab[0] = total;
-        tab[1] = (total + R - 1) / R;
-        tab[2] = 0;
-    }
+__device__ __forceinline__ int clamp_cnt(const sad::ScanJob &jb, int g) {
+    int c = jb.cnt[g];
+    c = c < 1 ? 1 : (c > jb.S ? jb.S : c);
+    return jb.nodedup ? jb.S : c;
 }
 
-// The same table with two parallel launches (used above 4096 groups, where one workgroup walking
-// 128 groups per thread costs 50-100 us): block sums, then every block adds the sums of the blocks
-// before it to its own in-block scan.
-__global__ __launch_bounds__(SCAN_T) void rowscan_sums_kernel(const int32_t *__restrict__ cnt, int ngroups, int S,
-                                                              int nodedup, int *__restrict__ blk_sum) {
+__global__ __launch_bounds__(SCAN_T) void rowscan_sums_kernel(const sad::ScanMulti sm) {
     __shared__ int wsum[16];
+    int lb;
+    const sad::ScanJob &jb = sm.j[scan_job_of(sm, blockIdx.x, lb)];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int g = blockIdx.x * SCAN_T + tid;
-    int c = 0;
-    if (g < ngroups) {
-        c = cnt[g];
-        c = c < 1 ? 1 : (c > S ? S : c);
-        c = nodedup ? S : c;
-    }
+    const int g = lb * SCAN_T + tid;
+    int c = g < jb.ngroups ? clamp_cnt(jb, g) : 0;
     for (int off = 32; off >= 1; off >>= 1) c += __shfl_xor(c, off, 64);
     if (lane == 0) wsum[wave] = c;
     __syncthreads();
     if (tid == 0) {
         int t = 0;
         for (int w = 0; w < 16; ++w) t += wsum[w];
-        blk_sum[blockIdx.x] = t;
+        jb.blk_sum[lb] = t;
     }
 }
 
-__global__ __launch_bounds__(SCAN_T) void rowscan_write_kernel(const int32_t *__restrict__ cnt, int ngroups, int S,
-                                                               int nodedup, int R, const int *__restrict__ blk_sum,
-                                                               int *__restrict__ tab, RowMap rm) {
+__global__ __launch_bounds__(SCAN_T) void rowscan_write_kernel(const sad::ScanMulti sm) {
     __shared__ int wsum[16];
     __shared__ int s_base;
+    __shared__ int s_start[SCAN_T + 1];          // row offsets of this block's groups, relative to s_base
+    int lb;
+    const sad::ScanJob &jb = sm.j[scan_job_of(sm, blockIdx.x, lb)];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    int *row_start = tab + 4;
-    int *pass_first = tab + 4 + ngroups + 1;
     int part = 0;
-    for (int b = tid; b < (int)blockIdx.x; b += SCAN_T) part += blk_sum[b];
+    for (int b = tid; b < lb; b += SCAN_T) part += jb.blk_sum[b];
     for (int off = 32; off >= 1; off >>= 1) part += __shfl_xor(part, off, 64);
     if (lane == 0) wsum[wave] = part;
     __syncthreads();
@@ -341,13 +290,8 @@ __global__ __launch_bounds__(SCAN_T) void rowscan_write_kernel(const int32_t *__
     }
     __syncthreads();
     const int base = s_base;
-    const int g = blockIdx.x * SCAN_T + tid;
-    int c = 0;
-    if (g < ngroups) {
-        c = cnt[g];
-        c = c < 1 ? 1 : (c > S ? S : c);
-        c = nodedup ? S : c;
-    }
+    const int g = lb * SCAN_T + tid;
+    const int c = g < jb.ngroups ? clamp_cnt(jb, g) : 0;
     int incl = c;
     for (int off = 1; off < 64; off <<= 1) {
         const int v = __shfl_up(incl, off, 64);
@@ -356,19 +300,32 @@ __global__ __launch_bounds__(SCAN_T) void rowscan_write_kernel(const int32_t *__
     __syncthreads();
     if (lane == 63) wsum[wave] = incl;
     __syncthreads();
-    int run = base + incl - c;
+    int run = incl - c;
     for (int w = 0; w < wave; ++w) run += wsum[w];
-    if (g < ngroups) {
-        row_start[g] = run;
-        for (int pp = (run + R - 1) / R; pp * R < run + c; ++pp) pass_first[pp] = g;
-        expand_group(rm, g, S, run, c);
-        if (g == ngroups - 1) {
-            const int total = run + c;
-            row_start[ngroups] = total;
-            tab[0] = total;
-            tab[1] = (total + R - 1) / R;
-            tab[2] = 0;
+    s_start[tid] = run;
+    if (tid == SCAN_T - 1) s_start[SCAN_T] = run + c;
+    __syncthreads();
+    const int blk_rows = s_start[SCAN_T];
+    if (g == jb.ngroups - 1) {
+        const int total = base + run + c;
+        jb.tab[0] = total;
+        jb.tab[1] = (total + jb.R - 1) / jb.R;
+        jb.tab[2] = 0;
+    }
+    if (!jb.row_src) return;
+    // row map of rows [base, base + blk_rows), by destination row
+    for (int q = tid; q < blk_rows; q += SCAN_T) {
+        int lo = 0, hi = SCAN_T;                 // largest gi with s_start[gi] <= q
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (s_start[mid] <= q) lo = mid; else hi = mid;
         }
+        const int gg = lb * SCAN_T + lo;
+        const int r0 = base + s_start[lo], cc = s_start[lo + 1] - s_start[lo];
+        const int whole = ((r0 >> 5) == ((r0 + cc - 1) >> 5)) ? WHOLE_BIT : 0;
+        const long long b = gg / jb.M;
+        jb.row_src[base + q] = (int)(b * jb.N + jb.idx[(long long)gg * jb.S + (q - s_start[lo])]);
+        jb.row_gid[base + q] = gg | whole;
     }
 }
 
@@ -1035,27 +992,39 @@ SAD_API int sad_mlp_pack_f32(int L, const int *dims, int first_has_xyz, const fl
 }
 
 namespace sad {
-// Prefix-sums the per-group row counts into the table described at rowscan_kernel (shared with the
-// bf16 chain, csrc/mlp_bf16.hip).
+// Fills a ScanJob for one chain (table layout: see sad_mlp_workspace_bytes).
+ScanJob make_scan_job(const int32_t *cnt, int ngroups, int S, int R, int *tab, int nodedup, const int32_t *idx, int N, int M) {
+    ScanJob jb{};
+    jb.cnt = cnt; jb.idx = idx; jb.tab = tab; jb.ngroups = ngroups; jb.S = S; jb.N = N; jb.M = M; jb.nodedup = nodedup; jb.R = R;
+    // layout (ints): hdr[4] | row_start[ngroups+1] (unused) | pass_first[ngroups*S/32+2] (unused) | blk_sum[ngroups/1024+2]
+    //                | row map: src[ngroups*S] | gid[ngroups*S]   (only written when idx != NULL)
+    jb.blk_sum = tab + 4 + (ngroups + 1) + ((long long)ngroups * S / 32 + 2);
+    if (idx) {
+        jb.row_src = jb.blk_sum + (ngroups / 1024 + 2);
+        jb.row_gid = jb.row_src + (long long)ngroups * S;
+    }
+    return jb;
+}
+
+// Prefix-sums the per-group row counts of up to three chains with two launches (shared with the bf16 chain).
+int launch_rowscan_multi(const ScanJob *jobs, int n, hipStream_t st) {
+    ScanMulti sm{};
+    sm.n = n;
+    int blocks = 0;
+    for (int i = 0; i < n; ++i) {
+        sm.j[i] = jobs[i];
+        sm.j[i].blk0 = blocks;
+        blocks += (jobs[i].ngroups + SCAN_T - 1) / SCAN_T;
+    }
+    hipLaunchKernelGGL(rowscan_sums_kernel, dim3(blocks), dim3(SCAN_T), 0, st, sm);
+    hipLaunchKernelGGL(rowscan_write_kernel, dim3(blocks), dim3(SCAN_T), 0, st, sm);
+    return check_launch("rowscan");
+}
+
 int launch_rowscan(const int32_t *cnt, int ngroups, int S, int R, int *tab, hipStream_t st, int nodedup,
                    const int32_t *idx, int N, int M) {
-    // layout (ints): hdr[4] | row_start[ngroups+1] | pass_first[ngroups*S/32+2] | blk_sum[ngroups/1024+2]
-    //                | row map: src[ngroups*S] | gid[ngroups*S]   (only written when idx != NULL)
-    int *blk_sum = tab + 4 + (ngroups + 1) + ((long long)ngroups * S / 32 + 2);
-    RowMap rm{};
-    if (idx) {
-        rm.src = blk_sum + (ngroups / 1024 + 2);
-        rm.gid = rm.src + (long long)ngroups * S;
-        rm.idx = idx; rm.N = N; rm.M = M;
-    }
-    if (ngroups <= 4096) {
-        hipLaunchKernelGGL(rowscan_kernel, dim3(1), dim3(SCAN_T), 0, st, cnt, ngroups, S, nodedup, R, tab, rm);
-    } else {
-        const int nblk = (ngroups + SCAN_T - 1) / SCAN_T;
-        hipLaunchKernelGGL(rowscan_sums_kernel, dim3(nblk), dim3(SCAN_T), 0, st, cnt, ngroups, S, nodedup, blk_sum);
-        hipLaunchKernelGGL(rowscan_write_kernel, dim3(nblk), dim3(SCAN_T), 0, st, cnt, ngroups, S, nodedup, R, blk_sum, tab, rm);
-    }
-    return check_launch("rowscan");
+    const ScanJob jb = make_scan_job(cnt, ngroups, S, R, tab, nodedup, idx, N, M);
+    return launch_rowscan_multi(&jb, 1, st);
 }
 }  // namespace sad
 
@@ -1075,6 +1044,7 @@ struct Prepared {
     bool launched;      // the VALU kernel was launched instead (nothing left to do)
     bool reg;           // geometry 2: register-resident chain kernel (csrc/mlp_reg.hip); `rc` is filled, p is not
     sad::RegChain rc;
+    sad::ScanJob scan;  // row-packing scan this chain needs before its kernel
     int reg_shape;
     long long reg_tiles;   // upper bound of the tile count
 };
@@ -1156,8 +1126,8 @@ static int prepare_chain(const sad_mlp_args *a, sad_stream_t stream, Prepared &q
         SAD_REQUIRE((uintptr_t)a->workspace % 16 == 0, "sad_mlp_chain_f32: workspace must be 16-byte aligned");
         SAD_REQUIRE(p.total_groups < (1LL << 30), "sad_mlp_chain_f32: too many groups");
         int *tab = (int *)a->workspace;
-        if (int e = sad::launch_rowscan(a->cnt, (int)p.total_groups, a->S, 32, tab, (hipStream_t)stream,
-                                        sad::get_option(sad::OPT_MLP_NODEDUP), a->idx, a->N, a->M)) return e;
+        // (the scan is launched by the caller: the chains of a merged dispatch share its two launches)
+        q.scan = sad::make_scan_job(a->cnt, (int)p.total_groups, a->S, 32, tab, sad::get_option(sad::OPT_MLP_NODEDUP), a->idx, a->N, a->M);
         sad::RegChain &rc = q.rc;
         rc.xyz = a->xyz; rc.new_xyz = a->new_xyz; rc.feat = a->feat; rc.packed = a->packed; rc.out = a->out;
         rc.rowtab = tab;
@@ -1334,6 +1304,9 @@ int launch_reg_chains(const Prepared *const *qs, int n, hipStream_t st) {
     sad::RegMulti mp{};
     mp.n = n;
     mp.max_tiles = 0;
+    sad::ScanJob jobs[sad::REG_MAX_CHAINS];
+    for (int i = 0; i < n; ++i) jobs[i] = qs[i]->scan;
+    if (int e = sad::launch_rowscan_multi(jobs, n, st)) return e;
     for (int i = 0; i < n; ++i) {
         mp.c[i] = qs[i]->rc;
         mp.shape[i] = qs[i]->reg_shape;

@@ -488,6 +488,8 @@ def grouped_multi(calls) -> None:
     if AUTOTUNE or len(calls) < 2 or (not MERGE_BF16 and isinstance(calls[0][0], PackedMLPBf16)):
         for mlp, xyz, feat_pm, new_xyz, idx, out, col_off, cnt in calls:
             mlp.grouped(xyz, feat_pm, new_xyz, idx, out=out, col_off=col_off, cnt=cnt)
+        if AUTOTUNE and len(calls) >= 2 and isinstance(calls[0][0], PackedMLP):
+            _tune_stage(calls)
         return
     args, keep = [], []
     for mlp, xyz, feat_pm, new_xyz, idx, out, col_off, cnt in calls:
@@ -504,6 +506,50 @@ def grouped_multi(calls) -> None:
         else:
             arr = (ctypes.POINTER(MlpArgs) * len(args))(*[ctypes.pointer(a) for a in args])
             check(lib().sad_mlp_chain_multi_f32(arr, len(args), _stream()), "sad_mlp_chain_multi_f32")
+
+
+def _tune_stage(calls) -> None:
+    """Stage-level autotune step: the branches of a stage go out as ONE dispatch, and a dispatch of
+    register-resident chains (geometry 2) shares one work list, so a branch that is slower on its own
+    (few tiles) may still be best inside the merged dispatch.  Times the merged dispatch with the
+    per-chain picks against all-geometry-2 and keeps the faster assignment."""
+    stream = torch.cuda.current_stream()
+    keys = []
+    for mlp, xyz, feat_pm, new_xyz, idx, out, col_off, cnt in calls:
+        a, _, _ = mlp._grouped_args(xyz, feat_pm, new_xyz, idx, out, col_off, cnt)
+        keys.append((bool(a.idx), a.B, a.N, a.M, a.S, a.ld_out))
+
+    def run(codes):
+        args, keep = [], []
+        for (mlp, xyz, feat_pm, new_xyz, idx, out, col_off, cnt), code in zip(calls, codes):
+            a, _, k = mlp._grouped_args(xyz, feat_pm, new_xyz, idx, out, col_off, cnt)
+            a.geometry = code
+            args.append(a)
+            keep.append(k)
+        arr = (ctypes.POINTER(MlpArgs) * len(args))(*[ctypes.pointer(a) for a in args])
+        if lib().sad_mlp_chain_multi_f32(arr, len(args), _stream()) != 0:
+            return None
+        stream.synchronize()
+        best = None
+        for _ in range(2):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            for _ in range(4):
+                lib().sad_mlp_chain_multi_f32(arr, len(args), _stream())
+            e1.record(stream)
+            stream.synchronize()
+            ms = e0.elapsed_time(e1) / 4
+            best = ms if best is None or ms < best else best
+        return best
+
+    picked = [c[0]._geom.get(k) or 0 for c, k in zip(calls, keys)]
+    if all(p == 2 for p in picked):
+        return
+    t_picked = run(picked)
+    t_reg = run([2] * len(calls))
+    if t_reg is not None and (t_picked is None or t_reg < t_picked * 0.98):
+        for c, k in zip(calls, keys):
+            c[0]._geom[k] = 2
 
 
 class PackedMLPBf16:
