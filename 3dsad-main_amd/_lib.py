@@ -32,6 +32,7 @@ class MlpArgs(ctypes.Structure):
         ("packed", vp), ("relu_mask", ctypes.c_int),
         ("out", vp), ("ld_out", ctypes.c_int), ("col_off", ctypes.c_int),
         ("geometry", ctypes.c_int),
+        ("scratch", vp), ("scratch_bytes", ctypes.c_size_t),
     ]
 
 
@@ -81,6 +82,8 @@ SIGNATURES = {
     "sad_mlp_pack_f32": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.c_int,
                                        ctypes.POINTER(vp), ctypes.POINTER(vp), vp, vp]),
     "sad_mlp_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    "sad_mlp_scratch_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                               ctypes.POINTER(ctypes.c_int)]),
     "sad_mlp_chain_f32": (ctypes.c_int, [ctypes.POINTER(MlpArgs), vp]),
     "sad_mlp_chain_multi_f32": (ctypes.c_int, [ctypes.POINTER(ctypes.POINTER(MlpArgs)), ctypes.c_int, vp]),
     "sad_mlp_packed_bytes_bf16": (ctypes.c_size_t, [ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.c_int]),

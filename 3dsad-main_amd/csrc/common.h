@@ -47,6 +47,26 @@ struct RegMulti {
     int *counter;                  // zeroed work counter (tiles of all chains form one list)
     long long max_tiles;           // upper bound of the tile count (grid sizing)
 };
+// Layer-streamed chain kernel (csrc/mlp_layer.hip): one layer of one chain / one layer of up to two chains
+struct LayerJob {
+    const float *x;                // layer input: feature matrix (gather) or the previous layer's row-major output
+    const float *xyz, *new_xyz;    // gather only
+    const int *rowtab, *row_src, *row_gid;
+    const float *packed;
+    long long off;                 // float offset of this layer inside `packed`
+    int ldx, np, kg, nog;          // input row stride, padded output channels, k-groups of 8, groups of 4 output tiles
+    int cpr, gather, relu, last;
+    float *y;                      // hidden layer: row-major output [rows][ldy]
+    int ldy;
+    float *out;                    // last layer: pooled output
+    int ld_out, col_off, cout_last;
+};
+struct LayerMulti {
+    LayerJob j[2];
+    int n;
+    int *counter;                  // zeroed work counter of this launch
+};
+int launch_layers(const LayerMulti &lm, long long max_items, hipStream_t st);
 int reg_shape_id(int L, const int *kp, const int *np);   // -1: no compiled shape
 int reg_family(int shape);
 int launch_reg(const RegMulti &mp, hipStream_t st);

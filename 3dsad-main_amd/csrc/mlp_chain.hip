@@ -1028,6 +1028,18 @@ int launch_rowscan(const int32_t *cnt, int ngroups, int S, int R, int *tab, hipS
 }
 }  // namespace sad
 
+SAD_API size_t sad_mlp_scratch_bytes(int B, int M, int S, int L, const int *dims) {
+    if (B < 1 || M < 1 || S < 1 || L < 1 || L > MAXL || !dims) return 0;
+    const Geometry g = geometry(L, dims, 1);
+    int wa = 0, wb = 0;
+    for (int l = 0; l + 1 < L; ++l) {
+        int &w = (l & 1) ? wb : wa;
+        w = g.np[l] > w ? g.np[l] : w;
+    }
+    const size_t rows_max = ((size_t)B * M * S + 31) / 32 * 32;
+    return 64 + sizeof(float) * rows_max * (size_t)(wa + wb);
+}
+
 SAD_API size_t sad_mlp_workspace_bytes(int B, int M, int S) {
     if (B < 1 || M < 1 || S < 1) return 0;
     const size_t ng = (size_t)B * M;
@@ -1045,6 +1057,11 @@ struct Prepared {
     bool reg;           // geometry 2: register-resident chain kernel (csrc/mlp_reg.hip); `rc` is filled, p is not
     sad::RegChain rc;
     sad::ScanJob scan;  // row-packing scan this chain needs before its kernel
+    bool layered;       // geometry 3: layer-streamed chain (csrc/mlp_layer.hip); lj[0..nl) are its launches
+    sad::LayerJob lj[MAXL];
+    int nl;
+    int *layer_counters;
+    long long layer_items[MAXL];
     int reg_shape;
     long long reg_tiles;   // upper bound of the tile count
 };
@@ -1055,6 +1072,7 @@ int launch_prepared(const Prepared &q, hipStream_t st);
 static int prepare_chain(const sad_mlp_args *a, sad_stream_t stream, Prepared &q) {
     q.launched = false;
     q.reg = false;
+    q.layered = false;
     SAD_REQUIRE(a, "sad_mlp_chain_f32: NULL args");
     if (int e = check_dims("sad_mlp_chain_f32", a->L, a->dims)) return e;
     const bool grouped = a->idx != nullptr;
@@ -1140,6 +1158,48 @@ static int prepare_chain(const sad_mlp_args *a, sad_stream_t stream, Prepared &q
         q.reg_shape = shape;
         q.reg_tiles = (p.total_groups * a->S + 31) / 32;
         q.W = -1;
+        return SAD_OK;
+    }
+    // ---- geometry 3: layer-streamed chain (one launch per layer, activations between layers in scratch) ----
+    if (geom_wg == 3) {
+        bool ok = grouped && a->cnt && a->workspace && a->scratch && p.cpr > 0;
+        const bool all_relu = (a->relu_mask & ((1 << a->L) - 1)) == (1 << a->L) - 1;
+        for (int l = 0; l < a->L; ++l) ok = ok && g.np[l] % 128 == 0 && (l == 0 || g.kp[l] == g.np[l - 1]);
+        ok = ok && all_relu && a->scratch_bytes >= sad_mlp_scratch_bytes(a->B, a->M, a->S, a->L, a->dims);
+        if (!ok)
+            return sad::fail(SAD_EUNSUPPORTED, "sad_mlp_chain_f32: geometry 3 (layer-streamed chain) needs cnt + workspace + scratch, "
+                                               "16-byte feature rows and layer widths that are multiples of 128");
+        SAD_REQUIRE((uintptr_t)a->workspace % 16 == 0 && (uintptr_t)a->scratch % 16 == 0, "sad_mlp_chain_f32: workspace / scratch must be 16-byte aligned");
+        SAD_REQUIRE(p.total_groups < (1LL << 30), "sad_mlp_chain_f32: too many groups");
+        int *tab = (int *)a->workspace;
+        q.scan = sad::make_scan_job(a->cnt, (int)p.total_groups, a->S, 32, tab, sad::get_option(sad::OPT_MLP_NODEDUP), a->idx, a->N, a->M);
+        const long long rows_max = (p.total_groups * a->S + 31) / 32 * 32;
+        int wa = 0, wb = 0;                         // widths of the two ping-pong activation buffers
+        for (int l = 0; l + 1 < a->L; ++l) {
+            int &w = (l & 1) ? wb : wa;
+            w = g.np[l] > w ? g.np[l] : w;
+        }
+        q.layer_counters = (int *)a->scratch;
+        float *ha = (float *)((char *)a->scratch + 64);
+        float *hb = ha + rows_max * wa;
+        q.nl = a->L;
+        for (int l = 0; l < a->L; ++l) {
+            sad::LayerJob &j = q.lj[l];
+            j = sad::LayerJob{};
+            j.rowtab = tab; j.row_src = q.scan.row_src; j.row_gid = q.scan.row_gid;
+            j.packed = a->packed; j.off = g.off[l]; j.np = g.np[l]; j.kg = g.kp[l] / 8; j.nog = g.np[l] / 128;
+            j.relu = 1; j.last = l == a->L - 1;
+            if (l == 0) {
+                j.gather = 1; j.x = a->feat; j.ldx = a->ld_feat; j.cpr = p.cpr; j.xyz = a->xyz; j.new_xyz = a->new_xyz;
+            } else {
+                j.x = ((l - 1) & 1) ? hb : ha; j.ldx = g.np[l - 1];
+            }
+            if (!j.last) { j.y = (l & 1) ? hb : ha; j.ldy = g.np[l]; }
+            else { j.out = a->out; j.ld_out = a->ld_out; j.col_off = a->col_off; j.cout_last = cout; }
+            q.layer_items[l] = rows_max / 32 * j.nog;
+        }
+        q.layered = true;
+        q.W = -2;
         return SAD_OK;
     }
     // ---- narrow 3-layer grouped chains can run on the vector ALU (geometry 1; autotune tries it) ----
@@ -1316,7 +1376,29 @@ int launch_reg_chains(const Prepared *const *qs, int n, hipStream_t st) {
     return sad::launch_reg(mp, st);
 }
 
+// Layer-streamed chains (one or two with the same number of layers): counters zeroed, one scan, then one
+// launch per layer carrying that layer of every chain.
+int launch_layered_chains(const Prepared *const *qs, int n, hipStream_t st) {
+    sad::ScanJob jobs[2];
+    for (int i = 0; i < n; ++i) jobs[i] = qs[i]->scan;
+    if (hipMemsetAsync(qs[0]->layer_counters, 0, 64, st) != hipSuccess) return sad::fail(SAD_ELAUNCH, "sad_mlp_chain_f32: counter memset failed");
+    if (int e = sad::launch_rowscan_multi(jobs, n, st)) return e;
+    for (int l = 0; l < qs[0]->nl; ++l) {
+        sad::LayerMulti lm{};
+        lm.n = n;
+        long long items = 0;
+        for (int i = 0; i < n; ++i) { lm.j[i] = qs[i]->lj[l]; items += qs[i]->layer_items[l]; }
+        lm.counter = qs[0]->layer_counters + l;
+        if (int e = sad::launch_layers(lm, items, st)) return e;
+    }
+    return SAD_OK;
+}
+
 int launch_prepared(const Prepared &q, hipStream_t st) {
+    if (q.layered) {
+        const Prepared *one = &q;
+        return launch_layered_chains(&one, 1, st);
+    }
     if (q.reg) {
         const Prepared *one = &q;
         return launch_reg_chains(&one, 1, st);
@@ -1366,6 +1448,12 @@ SAD_API int sad_mlp_chain_multi_f32(const sad_mlp_args *const *args, int n, sad_
     Prepared q[MULTI_MAX];
     for (int i = 0; i < n; ++i)
         if (int e = prepare_chain(args[i], stream, q[i])) return e;
+    // two layer-streamed chains with the same depth: their layers share launches (heavier chain first)
+    if (n == 2 && q[0].layered && q[1].layered && q[0].nl == q[1].nl) {
+        const bool swap = q[1].layer_items[q[1].nl - 1] * (long long)q[1].lj[q[1].nl - 1].kg > q[0].layer_items[q[0].nl - 1] * (long long)q[0].lj[q[0].nl - 1].kg;
+        const Prepared *ord[2] = {swap ? &q[1] : &q[0], swap ? &q[0] : &q[1]};
+        return launch_layered_chains(ord, 2, st);
+    }
     // register-resident chains of one shape family: one dispatch, tiles of the heaviest chain first
     {
         bool all_reg = n > 1 && n <= sad::REG_MAX_CHAINS;
@@ -1386,7 +1474,7 @@ SAD_API int sad_mlp_chain_multi_f32(const sad_mlp_args *const *args, int n, sad_
     }
     // one dispatch needs a common wave count and nothing already launched; otherwise one by one
     bool merge = n > 1;
-    for (int i = 0; i < n; ++i) merge = merge && !q[i].launched && !q[i].reg && q[i].W == q[0].W && q[i].W != 16;
+    for (int i = 0; i < n; ++i) merge = merge && !q[i].launched && !q[i].reg && !q[i].layered && q[i].W == q[0].W && q[i].W != 16;
     if (!merge) {
         for (int i = 0; i < n; ++i)
             if (!q[i].launched)

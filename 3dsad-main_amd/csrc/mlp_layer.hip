@@ -1,0 +1,290 @@
+// Layer-streamed fused group -> shared-MLP -> max-pool for gfx950 (SPEC.md §6): "geometry 3", for chains
+// that are WIDE and have FEW rows (the size-adaptive cluster layer: 259 -> 256 -> 512 -> 1024 on ~50 000
+// packed rows per step).  No reference source exists (/root/reference/README.md:1-2).
+//
+// Why another kernel.  Such a chain has ~1 500 row tiles of 32 rows and 46 MFLOP per tile: whatever owns a
+// whole tile (a workgroup of the tiled kernel, a wave of the register-resident kernel) is too coarse a unit
+// for 1 024 SIMDs — the tiled kernel ran 3.07 "rounds" of workgroups as 4 (77 % of its own speed) with one
+// workgroup per CU (104 KB of LDS), all waves in lockstep.  At f32 matrix rates (64 FLOP/clk/SIMD) a layer
+// needs 2*K flops per activation float, so writing a layer's activations to memory and reading them back
+// (~200 MB per step for both cluster branches, L2 / Infinity-Cache resident) is cheap next to the arithmetic.
+// So each layer is its own launch and the unit of work is (32-row tile) x (OCG = 4 output tiles of 32
+// channels): 12 560 items for the last layer of cluster.b1, handed out dynamically (items are 20-60 us
+// long, so one atomic per item is free), every wave independent, no barrier, no LDS round trip:
+//   * B operand (activations): lane (j,h) loads 16 bytes [8g + 4h, +4) of row j from the row-major input —
+//     the gathered feature row (layer 0, through the row map) or the previous layer's output — and two
+//     v_permlane32_swap turn them into the four operands of k-group g (as in csrc/mlp_reg.hip);
+//   * A operand (weights): fragment order of sad_mlp_pack_f32, one coalesced 16-byte load per lane and
+//     k-group for each of the item's four output tiles; both streams run two k-groups ahead;
+//   * four accumulators share every B operand (16 MFMAs per k-group);
+//   * k ascends from the bias, so every output is SPEC.md §6's fmaf chain bit for bit;
+//   * hidden layers store relu(acc) row-major (16 bytes per lane); the last layer pools the rows of each
+//     group (DPP segmented max) and writes through the wave's LDS staging buffer: one coalesced store per
+//     whole group, 256-byte-contiguous atomic max for groups that continue in another tile.
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int WHOLE_BIT = 1 << 30;
+constexpr int OCG = 4;            // output tiles (of 32 channels) per work item
+constexpr int LWAVES = 4;         // waves per workgroup (independent)
+constexpr int SLOTS = 16;         // pooled-output staging slots per wave (groups ending in one tile)
+constexpr int CW = OCG * 32;      // channels per item
+
+using sad::LayerJob;
+using sad::LayerMulti;
+
+struct Swapped { float lo, hi; };
+__device__ __forceinline__ Swapped swap32(float a, float b) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b), false, false);
+    const unsigned r0 = r[0], r1 = r[1];   // (copy first: bit_cast on r[1] directly reads element 0 with this hipcc)
+    return {__builtin_bit_cast(float, r0), __builtin_bit_cast(float, r1)};
+}
+// (c0..c3 | c4..c7) in v -> operands of the four MFMAs of the k-group: out[e] = (c_{2e} | c_{2e+1})
+__device__ __forceinline__ void to_operands(const float4 v, float *out) {
+    const Swapped s01 = swap32(v.x, v.y), s23 = swap32(v.z, v.w);
+    out[0] = s01.lo; out[1] = s23.lo; out[2] = s01.hi; out[3] = s23.hi;
+}
+__device__ __forceinline__ f32x16 mma4(f32x16 acc, const float4 a, const float *b) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b[2], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b[3], acc, 0, 0, 0);
+    return acc;
+}
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, ROWMASK, 0xF, true); }
+struct PoolMasks { int m[5]; };
+__device__ __forceinline__ PoolMasks pool_masks(int key) {
+    PoolMasks pm;
+    pm.m[0] = dpp_i<0x111, 0xF>(key) == key ? -1 : 0;
+    pm.m[1] = dpp_i<0x112, 0xF>(key) == key ? -1 : 0;
+    pm.m[2] = dpp_i<0x114, 0xF>(key) == key ? -1 : 0;
+    pm.m[3] = dpp_i<0x118, 0xF>(key) == key ? -1 : 0;
+    pm.m[4] = dpp_i<0x142, 0xA>(key) == key ? -1 : 0;
+    return pm;
+}
+// segmented inclusive max-scan over the 32 rows (values >= 0), all 16 registers step by step (see mlp_reg.hip)
+__device__ __forceinline__ f32x16 seg_max16(f32x16 t, const PoolMasks &pm) {
+    int x[16];
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+        const float f = t[g];
+        x[g] = __builtin_bit_cast(int, f);
+    }
+#define SAD_STEP(CTRL, RM, K)                                       \
+    _Pragma("unroll") for (int g = 0; g < 16; ++g) {                \
+        const int u = dpp_i<CTRL, RM>(x[g]) & pm.m[K];              \
+        x[g] = u > x[g] ? u : x[g];                                 \
+    }
+    SAD_STEP(0x111, 0xF, 0)
+    SAD_STEP(0x112, 0xF, 1)
+    SAD_STEP(0x114, 0xF, 2)
+    SAD_STEP(0x118, 0xF, 3)
+    SAD_STEP(0x142, 0xA, 4)
+#undef SAD_STEP
+#pragma unroll
+    for (int g = 0; g < 16; ++g) t[g] = __builtin_bit_cast(float, x[g]);
+    return t;
+}
+__device__ __forceinline__ void atomic_max_pos(float *addr, float v) {
+    atomicMax(reinterpret_cast<unsigned *>(addr), __builtin_bit_cast(unsigned, v));
+}
+
+// One work item: rows [32*rt, 32*rt + 32) x output tiles [OCG*og, OCG*og + OCG) of one layer.
+__device__ __forceinline__ void layer_item(const LayerJob &jb, const int rt, const int og, const int lane, float *stage) {
+    const int j = lane & 31, h = lane >> 5;
+    const int total = jb.rowtab[0];
+    int q = rt * 32 + j;
+    const bool live = q < total;
+    if (!live) q = total - 1;                       // rows past the end repeat the last row and store nothing
+    int src = q, gv = 0;
+    if (jb.gather || jb.last) gv = jb.row_gid[q];
+    if (jb.gather) src = jb.row_src[q];
+    const int grp = gv & (WHOLE_BIT - 1);
+    const bool whole = (gv & WHOLE_BIT) != 0;
+    const float *xrow = jb.x + (long long)src * jb.ldx;
+    float4 rel = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (jb.gather && h == 0) {
+        const float *pq = jb.xyz + (long long)src * 3;
+        const float *pc = jb.new_xyz + (long long)grp * 3;
+        rel = make_float4(pq[0] - pc[0], pq[1] - pc[1], pq[2] - pc[2], 0.f);
+    }
+    const int KG = jb.kg;
+    // activations of k-group g for this lane (16 bytes; zero outside the row)
+    auto ldb = [&](int g) -> float4 {
+        g = g < KG ? g : KG - 1;
+        if (jb.gather) {                            // [dx dy dz 0 | f0 f1 ...]: half h holds chunk 2g - 1 + h of the feature row
+            const int ch = 2 * g - 1 + h;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ch >= 0 && ch < jb.cpr) v = *reinterpret_cast<const float4 *>(xrow + 4 * ch);
+            if (g == 0 && h == 0) v = rel;
+            return v;
+        }
+        return *reinterpret_cast<const float4 *>(xrow + 8 * g + 4 * h);
+    };
+    const float4 *fr = reinterpret_cast<const float4 *>(jb.packed + jb.off + jb.np) + (size_t)(og * OCG) * KG * 64 + lane;
+    auto lda = [&](int oc, int g) -> float4 { return fr[((size_t)oc * KG + (g < KG ? g : KG - 1)) * 64]; };
+
+    f32x16 acc[OCG];
+    {
+        const float *bias = jb.packed + jb.off + (og * OCG) * 32;
+#pragma unroll
+        for (int oc = 0; oc < OCG; ++oc)
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const float4 bv = *reinterpret_cast<const float4 *>(bias + oc * 32 + 8 * a + 4 * h);
+                acc[oc][4 * a + 0] = bv.x; acc[oc][4 * a + 1] = bv.y; acc[oc][4 * a + 2] = bv.z; acc[oc][4 * a + 3] = bv.w;
+            }
+    }
+    // two k-groups in flight: slot s holds k-group (2i + s)
+    float4 b0 = ldb(0), b1 = ldb(1);
+    float4 a0[OCG], a1[OCG];
+#pragma unroll
+    for (int oc = 0; oc < OCG; ++oc) { a0[oc] = lda(oc, 0); a1[oc] = lda(oc, 1); }
+#pragma unroll 1
+    for (int g = 0; g < KG; g += 2) {
+        float ops[4];
+        to_operands(b0, ops);
+#pragma unroll
+        for (int oc = 0; oc < OCG; ++oc) acc[oc] = mma4(acc[oc], a0[oc], ops);
+        b0 = ldb(g + 2);
+#pragma unroll
+        for (int oc = 0; oc < OCG; ++oc) a0[oc] = lda(oc, g + 2);
+        __builtin_amdgcn_sched_barrier(0);
+        if (g + 1 < KG) {                           // (wave-uniform)
+            to_operands(b1, ops);
+#pragma unroll
+            for (int oc = 0; oc < OCG; ++oc) acc[oc] = mma4(acc[oc], a1[oc], ops);
+        }
+        b1 = ldb(g + 3);
+#pragma unroll
+        for (int oc = 0; oc < OCG; ++oc) a1[oc] = lda(oc, g + 3);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (jb.relu) {
+#pragma unroll
+        for (int oc = 0; oc < OCG; ++oc)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) acc[oc][g] = acc[oc][g] > 0.f ? acc[oc][g] : 0.f;
+    }
+    if (!jb.last) {
+        // hidden layer: row-major output, 16 bytes per lane and k-group (padded channels are exact zeros)
+        if (live) {
+            float *yrow = jb.y + (long long)q * jb.ldy + (og * OCG) * 32 + 4 * h;
+#pragma unroll
+            for (int oc = 0; oc < OCG; ++oc)
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+                    *reinterpret_cast<float4 *>(yrow + oc * 32 + 8 * a) = make_float4(acc[oc][4 * a], acc[oc][4 * a + 1], acc[oc][4 * a + 2], acc[oc][4 * a + 3]);
+        }
+        return;
+    }
+    // last layer: max over the rows of each group, staged in LDS, written once per group
+    const int key = live ? grp + 1 : 0;
+    const PoolMasks pm = pool_masks(key);
+    const int nkey = __shfl_down(key, 1, 64), pkey = __shfl_up(key, 1, 64);
+    const bool tail = live && (j == 31 || nkey != key);
+    const bool head = live && (j == 0 || pkey != key);
+    const unsigned heads = (unsigned)__ballot(head), tails = (unsigned)__ballot(tail);
+    const int ngroups = __builtin_popcount(heads);
+    const int slot = __builtin_popcount(heads & (0xFFFFFFFFu >> (31 - j))) - 1;
+    const bool staged = ngroups <= SLOTS;          // (wave-uniform)
+    const int ch0 = og * CW;
+#pragma unroll
+    for (int oc = 0; oc < OCG; ++oc) {
+        const f32x16 t = seg_max16(acc[oc], pm);
+        if (!tail) continue;
+        if (staged) {
+            float *d = stage + slot * CW + oc * 32 + 4 * h;
+#pragma unroll
+            for (int a = 0; a < 4; ++a) *reinterpret_cast<float4 *>(d + 8 * a) = make_float4(t[4 * a], t[4 * a + 1], t[4 * a + 2], t[4 * a + 3]);
+        } else {                                    // more groups end in this tile than slots: direct
+            float *o = jb.out + (long long)grp * jb.ld_out + jb.col_off + ch0 + oc * 32 + 4 * h;
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (ch0 + oc * 32 + 8 * a + 4 * h + e >= jb.cout_last) continue;
+                    if (whole) o[8 * a + e] = t[4 * a + e];
+                    else atomic_max_pos(o + 8 * a + e, t[4 * a + e]);
+                }
+        }
+    }
+    if (staged) {
+        unsigned rem = tails;
+        for (int s = 0; s < ngroups; ++s) {
+            const int p = __builtin_ctz(rem);
+            rem &= rem - 1;
+            const int g = __builtin_amdgcn_readlane(grp, p);
+            const bool w = __builtin_amdgcn_readlane((int)whole, p) != 0;
+            float *orow = jb.out + (long long)g * jb.ld_out + jb.col_off + ch0;
+            const float *sp = stage + s * CW;
+#pragma unroll
+            for (int k = 0; k < CW / 64; ++k) {
+                const int ch = lane + 64 * k;
+                if (ch0 + ch < jb.cout_last) {
+                    if (w) orow[ch] = sp[ch];
+                    else atomic_max_pos(orow + ch, sp[ch]);
+                }
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(LWAVES * 64, 2) void mlp_layer_kernel(const LayerMulti lm) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // per wave: SLOTS x CW staging floats
+    const int lane = threadIdx.x & 63;
+    float *stage = smem + (threadIdx.x >> 6) * (SLOTS * CW);
+    // items: job 0 first (heaviest), og fastest so that consecutive items share the activation rows
+    const int i0 = ((lm.j[0].rowtab[0] + 31) / 32) * lm.j[0].nog;
+    const int nitems = lm.n > 1 ? i0 + ((lm.j[1].rowtab[0] + 31) / 32) * lm.j[1].nog : i0;
+    int item = 0;
+    if (lane == 0) item = atomicAdd(lm.counter, 1);
+    item = __builtin_amdgcn_readfirstlane(item);
+    while (item < nitems) {
+        int next = 0;
+        if (lane == 0) next = atomicAdd(lm.counter, 1);       // in flight while this item computes (items take 20-60 us)
+        const int ji = __builtin_amdgcn_readfirstlane(item < i0 ? 0 : 1);
+        const int it = item - (ji ? i0 : 0);
+        const int nog = lm.j[ji].nog;
+        layer_item(lm.j[ji], it / nog, it % nog, lane, stage);
+        item = __builtin_amdgcn_readfirstlane(next);
+    }
+}
+
+}  // namespace
+
+namespace sad {
+
+int launch_layers(const LayerMulti &lm, long long max_items, hipStream_t st) {
+    static std::atomic<uint64_t> attr_done{0};
+    lds_attr_once(attr_done, reinterpret_cast<const void *>(&mlp_layer_kernel), 160 * 1024);
+    const size_t lds = sizeof(float) * (size_t)LWAVES * SLOTS * CW;
+    static std::atomic<int> per_cu{0};
+    int pc = per_cu.load(std::memory_order_relaxed);
+    if (pc == 0) {
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, mlp_layer_kernel, LWAVES * 64, lds) != hipSuccess || nb < 1) {
+            (void)hipGetLastError();
+            nb = 2;
+        }
+        pc = nb > 4 ? 4 : nb;
+        per_cu.store(pc, std::memory_order_relaxed);
+    }
+    if (get_option(OPT_MLP_DYN_SLOTS) > 0 && get_option(OPT_MLP_DYN_SLOTS) < pc) pc = get_option(OPT_MLP_DYN_SLOTS);
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+    }
+    (void)hipGetLastError();
+    long long grid = (long long)cus * pc;
+    const long long cap = (max_items + LWAVES - 1) / LWAVES;
+    if (grid > cap) grid = cap < 1 ? 1 : cap;
+    hipLaunchKernelGGL(mlp_layer_kernel, dim3((unsigned)grid), dim3(LWAVES * 64), lds, st, lm);
+    return check_launch("sad_mlp_chain_f32 (layer-streamed chain)");
+}
+
+}  // namespace sad

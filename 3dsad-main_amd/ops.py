@@ -308,6 +308,9 @@ class PackedMLP:
                                          self.packed.data_ptr(), _stream()), "sad_mlp_pack_f32")
             torch.cuda.current_stream().synchronize()  # ws/bs may be freed after this returns
         self.out_channels = self.dims[-1]
+        # geometry 3 (layer-streamed chain, csrc/mlp_layer.hip) applies when every layer's padded width is a
+        # multiple of 128 channels; it needs scratch for the activations between layers
+        self._layered_ok = self.first_has_xyz and all(((d + 31) // 32 * 32) % 128 == 0 for d in self.dims[1:])
 
     # Geometries tried by the autotuner: W*100 + log2(WN)*10 + RW (include/sad_amd.h, sad_mlp_args).
     _CANDIDATES = [w * 100 + n * 10 + r for w in (8, 4) for n in range(4) if (1 << n) <= w
@@ -353,12 +356,12 @@ class PackedMLP:
         stream = torch.cuda.current_stream()
         best, best_ms = 0, None
         # 1 = VALU row-per-lane kernel (narrow chains), 2 = register-resident chain kernel (csrc/mlp_reg.hip)
-        for code in self._CANDIDATES + ([1, 2] if a.idx else []):
+        for code in self._CANDIDATES + ([1, 2, 3] if a.idx else []):
             a.geometry = code
             ms = self._time(a, stream)
             if ms is not None and (best_ms is None or ms < best_ms * 0.98):   # prefer earlier entries on ties
                 best, best_ms = code, ms
-        if a.idx and best > 2:   # second sweep: groups per workgroup (how much padding is expected)
+        if a.idx and best > 3:   # second sweep: groups per workgroup (how much padding is expected)
             base = best
             for f in self._F_CODES:
                 a.geometry = base + 1000 * f
@@ -438,6 +441,12 @@ class PackedMLP:
         a.B, a.N, a.M, a.S, a.C = B, N, M, S, C
         a.out, a.ld_out, a.col_off = out.data_ptr(), out.stride(-2), col_off
         a.geometry = self._geom.get((bool(a.idx), a.B, a.N, a.M, a.S, a.ld_out)) or self.default_geometry
+        if self._layered_ok and cnt is not None and (a.geometry == 3 or AUTOTUNE):
+            dims_c = (ctypes.c_int * (self.L + 1))(*self.dims)
+            nbytes = lib().sad_mlp_scratch_bytes(B, M, S, self.L, dims_c)
+            sc = torch.empty((nbytes,), dtype=torch.uint8, device=xyz.device)
+            a.scratch, a.scratch_bytes = sc.data_ptr(), nbytes
+            keep.append(sc)
         return a, out, keep
 
     def rows(self, x: torch.Tensor, out: Optional[torch.Tensor] = None, col_off: int = 0

@@ -177,10 +177,20 @@ typedef struct sad_mlp_args {
      * + 100000: with RW = 1, the (output tile, row tile) items of every layer are dealt round-robin
      *   to all W waves instead of the fixed WN x WM grid (no wave idles in a layer narrower than WN tiles).
      * + 200000: with RW = 1 (4 or 8 waves), a wave computes two output tiles per round as two
-     *   independent accumulator chains sharing the activation operand (+300000 = both). */
+     *   independent accumulator chains sharing the activation operand (+300000 = both).
+     * Other kernels (grouped mode with cnt + workspace; SAD_EUNSUPPORTED where they do not apply):
+     *   1 = row-per-lane vector-ALU kernel (two narrow SA1 shapes);
+     *   2 = register-resident chain: one wave carries a 32-row tile through a 3-layer chain in registers
+     *       (compiled shapes: the SA stages of the KITTI / nuScenes topology and BASELINE configs[0]);
+     *   3 = layer-streamed chain: one launch per layer, (32-row tile x 128 output channels) work items,
+     *       activations between layers in `scratch` (wide chains with few rows: the cluster layer). */
     int geometry;
+    /* geometry 3 only: sad_mlp_scratch_bytes(B, M, S, L, dims) bytes of 16-byte aligned device scratch */
+    void *scratch;
+    size_t scratch_bytes;
 } sad_mlp_args;
 size_t sad_mlp_workspace_bytes(int B, int M, int S);
+size_t sad_mlp_scratch_bytes(int B, int M, int S, int L, const int *dims);
 int sad_mlp_chain_f32(const sad_mlp_args *args, sad_stream_t stream);
 /* n independent chains (typically the branches of one multi-radius stage, each writing its own
  * column slice) in one dispatch when they share a wave count: the light chains fill the tail of the

@@ -489,3 +489,71 @@ def test_register_chain_refuses_other_shapes(orc, sad, dev):
             net.grouped(X, None, Cn, idxs[0], cnt=cnts[0])
     finally:
         _lib.set_option("mlp_force", 0)
+
+
+LAYERED_CASES = [
+    # (B, N, M, S, C, mlp, radius) — geometry 3: layer-streamed chain (every padded width a multiple of 128)
+    (2, 512, 256, 16, 256, [256, 256, 512], 0.25),    # cluster branch 0
+    (2, 512, 256, 32, 256, [256, 512, 1024], 0.35),   # cluster branch 1
+    (1, 300, 70, 32, 128, [128, 256], 0.4),           # two layers
+    (1, 300, 70, 24, 8, [256], 0.4),                  # one layer, nsample 24, narrow input
+    (1, 400, 33, 32, 64, [128, 128, 128, 256], 0.5),  # four layers
+]
+
+
+@pytest.mark.parametrize("B,N,M,S,C,mlp,r", LAYERED_CASES)
+def test_layer_streamed_chain_parity(orc, sad, dev, B, N, M, S, C, mlp, r):
+    """geometry 3 = one launch per layer, (32-row tile x 128 channels) work items, activations between layers in
+    scratch (csrc/mlp_layer.hip): bit-identical to the oracle and to the tiled kernel, alone and as the merged
+    two-chain dispatch the cluster layer uses."""
+    import torch
+    from sad_amd import _lib, ops, synth
+    rng = np.random.default_rng(N + M + S + C + sum(mlp))
+    xyz = rng.uniform(0, 1, (B, N, 3)).astype(np.float32)
+    feat = rng.normal(size=(B, N, C)).astype(np.float32)
+    new_xyz = np.ascontiguousarray(xyz[:, :M])
+    X, F, Cn = _t(xyz, dev), _t(feat, dev), _t(new_xyz, dev)
+    idxs, cnts = ops.ball_query_multi((r,), (S,), X, Cn, return_counts=True)
+    layers = synth.make_mlp_weights([C + 3] + mlp, rng)
+    want = orc.sa_group_mlp_max(xyz, feat, new_xyz, idxs[0].cpu().numpy(), layers)
+    net = ops.PackedMLP(layers, True, dev)
+    assert net._layered_ok
+    net.default_geometry = 3
+    got = net.grouped(X, F, Cn, idxs[0], cnt=cnts[0]).cpu().numpy()
+    rows = int(cnts[0].clamp(min=1).sum().item())
+    print(f"[parity] layer-streamed chain {[C + 3] + mlp} S={S}: {rows} packed rows, bit-exact={np.array_equal(got, want)}")
+    assert np.array_equal(got, want), f"max diff {np.abs(got - want).max():.3e}"
+    _lib.set_option("mlp_nodedup", 1)
+    try:
+        dense = net.grouped(X, F, Cn, idxs[0], cnt=cnts[0]).cpu().numpy()
+    finally:
+        _lib.set_option("mlp_nodedup", 0)
+    assert np.array_equal(dense, want), "padding skip off: different result"
+
+
+def test_layer_streamed_two_chain_dispatch(orc, sad, dev):
+    """The cluster layer's two branches as ONE sequence of per-layer launches (sad_mlp_chain_multi_f32)."""
+    import torch
+    from sad_amd import ops, synth
+    rng = np.random.default_rng(321)
+    B, N, M, C = 2, 512, 256, 256
+    xyz = rng.uniform(0, 1, (B, N, 3)).astype(np.float32)
+    feat = np.maximum(rng.normal(size=(B, N, C)).astype(np.float32), 0)
+    new_xyz = np.ascontiguousarray(xyz[:, :M] + 0.01)
+    rad = rng.uniform(0.15, 0.3, (B, M)).astype(np.float32)
+    X, F, Cn = _t(xyz, dev), _t(feat, dev), _t(new_xyz, dev)
+    idxs, cnts = ops.ball_query_multi((1.0, 2.0), (16, 32), X, Cn, _t(rad, dev), return_counts=True)
+    mlps = [[256, 256, 512], [256, 512, 1024]]
+    nets = [ops.PackedMLP(synth.make_mlp_weights([C + 3] + m, rng), True, dev, name=f"c.b{i}") for i, m in enumerate(mlps)]
+    width = sum(m[-1] for m in mlps)
+    merged = torch.zeros(B, M, width, device=dev)
+    single = torch.zeros(B, M, width, device=dev)
+    calls, off = [], 0
+    for net, idx, cnt in zip(nets, idxs, cnts):
+        net.default_geometry = 0
+        net.grouped(X, F, Cn, idx, out=single, col_off=off, cnt=cnt)       # tiled kernel
+        net.default_geometry = 3
+        calls.append((net, X, F, Cn, idx, merged, off, cnt))
+        off += net.out_channels
+    ops.grouped_multi(calls)
+    assert torch.equal(single, merged)

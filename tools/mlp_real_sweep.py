@@ -45,7 +45,7 @@ def timeit(fn, reps=10):
 rows = int(cnt.clamp(min=1).sum().item())
 print(f"{name}: groups {cnt.numel()} rows {rows} avg {rows/cnt.numel():.2f}")
 for code in codes:
-    _lib.set_option("mlp_force", code)
+    mlp.default_geometry = code
     try:
         t = min(timeit(lambda: mlp.grouped(xyz, feat, new_xyz, idx, out=out, cnt=cnt)) for _ in range(3))
         print(f"  {code}: {t*1e3:.0f} us")
