@@ -9,8 +9,8 @@
 // needs 2*K flops per activation float, so writing a layer's activations to memory and reading them back
 // (~200 MB per step for both cluster branches, L2 / Infinity-Cache resident) is cheap next to the arithmetic.
 // So each layer is its own launch and the unit of work is (32-row tile) x (OCG = 4 output tiles of 32
-// channels): 12 560 items for the last layer of cluster.b1, handed out dynamically (items are 20-60 us
-// long, so one atomic per item is free), every wave independent, no barrier, no LDS round trip:
+// channels): 12 560 items for the last layer of cluster.b1, dealt round-robin to persistent waves, every wave
+// independent, no barrier, no LDS round trip:
 //   * B operand (activations): lane (j,h) loads 16 bytes [8g + 4h, +4) of row j from the row-major input —
 //     the gathered feature row (layer 0, through the row map) or the previous layer's output — and two
 //     v_permlane32_swap turn them into the four operands of k-group g (as in csrc/mlp_reg.hip);
@@ -34,6 +34,11 @@ constexpr int CW = OCG * 32;      // channels per item
 
 using sad::LayerJob;
 using sad::LayerMulti;
+
+#ifdef SAD_LAYER_STAMPS   // measurement build only (tools/probe/layer_stamps.py)
+__device__ unsigned long long g_lstamps[3 * 64 * 8];   // [launch % 3][wave slot][start tick, start real, end tick, end real, items, k-loop ticks, -, -]
+__device__ unsigned g_llaunch;
+#endif
 
 struct Swapped { float lo, hi; };
 __device__ __forceinline__ Swapped swap32(float a, float b) {
@@ -93,6 +98,10 @@ __device__ __forceinline__ void atomic_max_pos(float *addr, float v) {
 }
 
 // One work item: rows [32*rt, 32*rt + 32) x output tiles [OCG*og, OCG*og + OCG) of one layer.
+// (GATHER / LAST are compile-time and the k-loop body is branch-free: with a branch or a predicated load in
+// the loop the compiler drains every load — s_waitcnt vmcnt(0) — at the top of each k-group, which exposes a
+// full L2 round trip per k-group: measured 2.3x slower.)
+template <bool GATHER, bool LAST>
 __device__ __forceinline__ void layer_item(const LayerJob &jb, const int rt, const int og, const int lane, float *stage) {
     const int j = lane & 31, h = lane >> 5;
     const int total = jb.rowtab[0];
@@ -100,32 +109,46 @@ __device__ __forceinline__ void layer_item(const LayerJob &jb, const int rt, con
     const bool live = q < total;
     if (!live) q = total - 1;                       // rows past the end repeat the last row and store nothing
     int src = q, gv = 0;
-    if (jb.gather || jb.last) gv = jb.row_gid[q];
-    if (jb.gather) src = jb.row_src[q];
+    if (GATHER || LAST) gv = jb.row_gid[q];
+    if (GATHER) src = jb.row_src[q];
     const int grp = gv & (WHOLE_BIT - 1);
     const bool whole = (gv & WHOLE_BIT) != 0;
-    const float *xrow = jb.x + (long long)src * jb.ldx;
+    // loads use the scalar-base form (SGPR pair + 32-bit lane offset): stepping through the k-groups costs scalar
+    // adds, not per-lane 64-bit address arithmetic (the lane part is fixed per item; buffers are < 4 GB)
+    const unsigned xoff = (unsigned)src * (unsigned)jb.ldx * 4u;        // byte offset of this lane's row
     float4 rel = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (jb.gather && h == 0) {
+    if (GATHER && h == 0) {
         const float *pq = jb.xyz + (long long)src * 3;
         const float *pc = jb.new_xyz + (long long)grp * 3;
         rel = make_float4(pq[0] - pc[0], pq[1] - pc[1], pq[2] - pc[2], 0.f);
     }
     const int KG = jb.kg;
     // activations of k-group g for this lane (16 bytes; zero outside the row)
+    const char *xb = reinterpret_cast<const char *>(jb.x);
     auto ldb = [&](int g) -> float4 {
         g = g < KG ? g : KG - 1;
-        if (jb.gather) {                            // [dx dy dz 0 | f0 f1 ...]: half h holds chunk 2g - 1 + h of the feature row
+        if constexpr (GATHER) {                     // [dx dy dz 0 | f0 f1 ...]: half h holds chunk 2g - 1 + h of the feature row
             const int ch = 2 * g - 1 + h;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (ch >= 0 && ch < jb.cpr) v = *reinterpret_cast<const float4 *>(xrow + 4 * ch);
-            if (g == 0 && h == 0) v = rel;
-            return v;
+            const int cc = ch < 0 ? 0 : (ch < jb.cpr ? ch : jb.cpr - 1);      // always a valid address; selected below
+            return *reinterpret_cast<const float4 *>(xb + (size_t)(xoff + 16u * (unsigned)cc));
+        } else {
+            return *reinterpret_cast<const float4 *>((xb + (size_t)g * 32) + (size_t)(xoff + 16u * (unsigned)h));
         }
-        return *reinterpret_cast<const float4 *>(xrow + 8 * g + 4 * h);
     };
-    const float4 *fr = reinterpret_cast<const float4 *>(jb.packed + jb.off + jb.np) + (size_t)(og * OCG) * KG * 64 + lane;
-    auto lda = [&](int oc, int g) -> float4 { return fr[((size_t)oc * KG + (g < KG ? g : KG - 1)) * 64]; };
+    // ... and the selection, applied when the k-group is USED (applied at load time it would wait for the load there)
+    auto fixb = [&](float4 v, int g) -> float4 {
+        if constexpr (GATHER) {
+            const int ch = 2 * g - 1 + h;
+            const bool ok = ch >= 0 && ch < jb.cpr;
+            v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
+            const bool first = g == 0 && h == 0;
+            v.x = first ? rel.x : v.x; v.y = first ? rel.y : v.y; v.z = first ? rel.z : v.z; v.w = first ? rel.w : v.w;
+        }
+        return v;
+    };
+    const float4 *fr = reinterpret_cast<const float4 *>(jb.packed + jb.off + jb.np) + (size_t)(og * OCG) * KG * 64;   // wave-uniform
+    const unsigned ulane = (unsigned)lane;
+    auto lda = [&](int oc, int g) -> float4 { return (fr + ((size_t)oc * KG + (g < KG ? g : KG - 1)) * 64)[ulane]; };
 
     f32x16 acc[OCG];
     {
@@ -143,33 +166,48 @@ __device__ __forceinline__ void layer_item(const LayerJob &jb, const int rt, con
     float4 a0[OCG], a1[OCG];
 #pragma unroll
     for (int oc = 0; oc < OCG; ++oc) { a0[oc] = lda(oc, 0); a1[oc] = lda(oc, 1); }
+#ifdef SAD_LAYER_STAMPS
+    const unsigned long long k0 = __builtin_amdgcn_s_memtime();
+#endif
+    const int KG2 = KG & ~1;
 #pragma unroll 1
-    for (int g = 0; g < KG; g += 2) {
+    for (int g = 0; g < KG2; g += 2) {              // branch-free body; reloads past the end are clamped (harmless re-reads)
         float ops[4];
-        to_operands(b0, ops);
+        to_operands(fixb(b0, g), ops);
 #pragma unroll
         for (int oc = 0; oc < OCG; ++oc) acc[oc] = mma4(acc[oc], a0[oc], ops);
         b0 = ldb(g + 2);
 #pragma unroll
         for (int oc = 0; oc < OCG; ++oc) a0[oc] = lda(oc, g + 2);
         __builtin_amdgcn_sched_barrier(0);
-        if (g + 1 < KG) {                           // (wave-uniform)
-            to_operands(b1, ops);
+        to_operands(fixb(b1, g + 1), ops);
 #pragma unroll
-            for (int oc = 0; oc < OCG; ++oc) acc[oc] = mma4(acc[oc], a1[oc], ops);
-        }
+        for (int oc = 0; oc < OCG; ++oc) acc[oc] = mma4(acc[oc], a1[oc], ops);
         b1 = ldb(g + 3);
 #pragma unroll
         for (int oc = 0; oc < OCG; ++oc) a1[oc] = lda(oc, g + 3);
         __builtin_amdgcn_sched_barrier(0);
     }
+    if (KG & 1) {                                   // odd k-group count: slot 0 holds the last group
+        float ops[4];
+        to_operands(fixb(b0, KG - 1), ops);
+#pragma unroll
+        for (int oc = 0; oc < OCG; ++oc) acc[oc] = mma4(acc[oc], a0[oc], ops);
+    }
+#ifdef SAD_LAYER_STAMPS
+    if (blockIdx.x < 16 && lane == 0) {
+        // (the last MFMA's result is consumed below; this stamp sits right behind the issue of the k-loop)
+        g_lstamps[((g_llaunch % 3) * 64 + ((blockIdx.x * 4 + (threadIdx.x >> 6)) & 63)) * 8 + 5] += __builtin_amdgcn_s_memtime() - k0;
+        g_lstamps[((g_llaunch % 3) * 64 + ((blockIdx.x * 4 + (threadIdx.x >> 6)) & 63)) * 8 + 4] += 1;
+    }
+#endif
     if (jb.relu) {
 #pragma unroll
         for (int oc = 0; oc < OCG; ++oc)
 #pragma unroll
             for (int g = 0; g < 16; ++g) acc[oc][g] = acc[oc][g] > 0.f ? acc[oc][g] : 0.f;
     }
-    if (!jb.last) {
+    if constexpr (!LAST) {
         // hidden layer: row-major output, 16 bytes per lane and k-group (padded channels are exact zeros)
         if (live) {
             float *yrow = jb.y + (long long)q * jb.ldy + (og * OCG) * 32 + 4 * h;
@@ -180,7 +218,7 @@ __device__ __forceinline__ void layer_item(const LayerJob &jb, const int rt, con
                     *reinterpret_cast<float4 *>(yrow + oc * 32 + 8 * a) = make_float4(acc[oc][4 * a], acc[oc][4 * a + 1], acc[oc][4 * a + 2], acc[oc][4 * a + 3]);
         }
         return;
-    }
+    } else {
     // last layer: max over the rows of each group, staged in LDS, written once per group
     const int key = live ? grp + 1 : 0;
     const PoolMasks pm = pool_masks(key);
@@ -231,6 +269,7 @@ __device__ __forceinline__ void layer_item(const LayerJob &jb, const int rt, con
             }
         }
     }
+    }
 }
 
 __global__ __launch_bounds__(LWAVES * 64, 2) void mlp_layer_kernel(const LayerMulti lm) {
@@ -240,18 +279,33 @@ __global__ __launch_bounds__(LWAVES * 64, 2) void mlp_layer_kernel(const LayerMu
     // items: job 0 first (heaviest), og fastest so that consecutive items share the activation rows
     const int i0 = ((lm.j[0].rowtab[0] + 31) / 32) * lm.j[0].nog;
     const int nitems = lm.n > 1 ? i0 + ((lm.j[1].rowtab[0] + 31) / 32) * lm.j[1].nog : i0;
-    int item = 0;
-    if (lane == 0) item = atomicAdd(lm.counter, 1);
-    item = __builtin_amdgcn_readfirstlane(item);
-    while (item < nitems) {
-        int next = 0;
-        if (lane == 0) next = atomicAdd(lm.counter, 1);       // in flight while this item computes (items take 20-60 us)
+    // Static round-robin hand-out.  (A shared work counter does not scale: returning atomics on ONE address are
+    // served at ~30 ns each chip-wide, and a layer has up to 13 000 items — 0.4 ms of counter traffic; measured.)
+    // Items of a layer cost the same per chain, so round-robin leaves every SIMD within one item of the mean.
+    const int nwaves = gridDim.x * LWAVES;
+#ifdef SAD_LAYER_STAMPS
+    const int sl = ((g_llaunch % 3) * 64 + ((blockIdx.x * 4 + (threadIdx.x >> 6)) & 63)) * 8;
+    if (blockIdx.x < 16 && lane == 0) {
+        g_lstamps[sl + 0] = __builtin_amdgcn_s_memtime(); g_lstamps[sl + 1] = __builtin_amdgcn_s_memrealtime();
+        g_lstamps[sl + 4] = 0; g_lstamps[sl + 5] = 0;
+    }
+#endif
+    for (int item = blockIdx.x * LWAVES + (threadIdx.x >> 6); item < nitems; item += nwaves) {
         const int ji = __builtin_amdgcn_readfirstlane(item < i0 ? 0 : 1);
         const int it = item - (ji ? i0 : 0);
         const int nog = lm.j[ji].nog;
-        layer_item(lm.j[ji], it / nog, it % nog, lane, stage);
-        item = __builtin_amdgcn_readfirstlane(next);
+        const LayerJob &jb = lm.j[ji];
+        if (jb.gather) {
+            if (jb.last) layer_item<true, true>(jb, it / nog, it % nog, lane, stage);
+            else layer_item<true, false>(jb, it / nog, it % nog, lane, stage);
+        } else {
+            if (jb.last) layer_item<false, true>(jb, it / nog, it % nog, lane, stage);
+            else layer_item<false, false>(jb, it / nog, it % nog, lane, stage);
+        }
     }
+#ifdef SAD_LAYER_STAMPS
+    if (blockIdx.x < 16 && lane == 0) { g_lstamps[sl + 2] = __builtin_amdgcn_s_memtime(); g_lstamps[sl + 3] = __builtin_amdgcn_s_memrealtime(); }
+#endif
 }
 
 }  // namespace
@@ -284,7 +338,20 @@ int launch_layers(const LayerMulti &lm, long long max_items, hipStream_t st) {
     const long long cap = (max_items + LWAVES - 1) / LWAVES;
     if (grid > cap) grid = cap < 1 ? 1 : cap;
     hipLaunchKernelGGL(mlp_layer_kernel, dim3((unsigned)grid), dim3(LWAVES * 64), lds, st, lm);
+#ifdef SAD_LAYER_STAMPS
+    {
+        static unsigned launch = 0;
+        ++launch;
+        (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_llaunch), &launch, sizeof launch, 0, hipMemcpyHostToDevice, st);
+    }
+#endif
     return check_launch("sad_mlp_chain_f32 (layer-streamed chain)");
 }
 
 }  // namespace sad
+
+#ifdef SAD_LAYER_STAMPS
+extern "C" __attribute__((visibility("default"))) int sad_debug_read_layer_stamps(unsigned long long *dst) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_lstamps), sizeof(unsigned long long) * 3 * 64 * 8);
+}
+#endif

@@ -518,10 +518,10 @@ def grouped_multi(calls) -> None:
 
 
 def _tune_stage(calls) -> None:
-    """Stage-level autotune step: the branches of a stage go out as ONE dispatch, and a dispatch of
-    register-resident chains (geometry 2) shares one work list, so a branch that is slower on its own
-    (few tiles) may still be best inside the merged dispatch.  Times the merged dispatch with the
-    per-chain picks against all-geometry-2 and keeps the faster assignment."""
+    """Stage-level autotune step: the branches of a stage go out as ONE dispatch, and register-resident
+    (geometry 2) / layer-streamed (geometry 3) chains share their launches and work lists, so a branch
+    that is slower on its own (few tiles) may still be best inside the merged dispatch.  Times the merged
+    dispatch with the per-chain picks against all-2 and all-3 and keeps the fastest assignment."""
     stream = torch.cuda.current_stream()
     keys = []
     for mlp, xyz, feat_pm, new_xyz, idx, out, col_off, cnt in calls:
@@ -552,13 +552,15 @@ def _tune_stage(calls) -> None:
         return best
 
     picked = [c[0]._geom.get(k) or 0 for c, k in zip(calls, keys)]
-    if all(p == 2 for p in picked):
-        return
-    t_picked = run(picked)
-    t_reg = run([2] * len(calls))
-    if t_reg is not None and (t_picked is None or t_reg < t_picked * 0.98):
-        for c, k in zip(calls, keys):
-            c[0]._geom[k] = 2
+    best, t_best = picked, run(picked)
+    for code in (2, 3):              # the two kernels whose chains share launches: register-resident, layer-streamed
+        if all(p == code for p in picked):
+            continue
+        t = run([code] * len(calls))
+        if t is not None and (t_best is None or t < t_best * 0.98):
+            best, t_best = [code] * len(calls), t
+    for c, k, code in zip(calls, keys, best):
+        c[0]._geom[k] = code
 
 
 class PackedMLPBf16:
