@@ -38,6 +38,7 @@ using sad::LayerMulti;
 #ifdef SAD_LAYER_STAMPS   // measurement build only (tools/probe/layer_stamps.py)
 __device__ unsigned long long g_lstamps[3 * 64 * 8];   // [launch % 3][wave slot][start tick, start real, end tick, end real, items, k-loop ticks, -, -]
 __device__ unsigned g_llaunch;
+__device__ unsigned long long g_lall[4096 * 4];        // last launch, every wave: start real, end real, items, SIMD/CU id
 #endif
 
 struct Swapped { float lo, hi; };
@@ -161,38 +162,56 @@ __device__ __forceinline__ void layer_item(const LayerJob &jb, const int rt, con
                 acc[oc][4 * a + 0] = bv.x; acc[oc][4 * a + 1] = bv.y; acc[oc][4 * a + 2] = bv.z; acc[oc][4 * a + 3] = bv.w;
             }
     }
-    // two k-groups in flight: slot s holds k-group (2i + s)
-    float4 b0 = ldb(0), b1 = ldb(1);
-    float4 a0[OCG], a1[OCG];
+    // Weights (L2-resident) run two k-groups ahead, activations FOUR: a row tile's activations are touched for the
+    // first time by this XCD here (Infinity Cache / HBM latency), and with two k-groups of cover identical items
+    // finished anywhere between 300 and 576 us depending on the CU's distance to the data (measured).
+#ifndef SAD_LAYER_AD
+#define SAD_LAYER_AD 2
+#endif
+    constexpr int AD = SAD_LAYER_AD;                // k-groups of weight fragments in flight (2 or 4)
+    float4 bq[4], aq[AD][OCG];
 #pragma unroll
-    for (int oc = 0; oc < OCG; ++oc) { a0[oc] = lda(oc, 0); a1[oc] = lda(oc, 1); }
+    for (int u = 0; u < 4; ++u) bq[u] = ldb(u);
+#pragma unroll
+    for (int u = 0; u < AD; ++u)
+#pragma unroll
+        for (int oc = 0; oc < OCG; ++oc) aq[u][oc] = lda(oc, u);
 #ifdef SAD_LAYER_STAMPS
     const unsigned long long k0 = __builtin_amdgcn_s_memtime();
 #endif
-    const int KG2 = KG & ~1;
+    // Issue order inside a k-group: the four MFMAs of ONE output tile (a dependent chain: 64-cycle latency =
+    // 64-cycle issue), then at once the reload of that tile's weight fragment — a vector-memory instruction costs
+    // tens of issue cycles, which hide in the shadow of the following MFMAs only if the loads are spread between
+    // them (all five loads bunched behind the sixteen MFMAs left ~200 of 1 200 cycles per k-group exposed:
+    // measured).  The operands of the NEXT k-group are prepared (two lane swaps) behind the second output tile.
+    const int KG4 = KG & ~3;
+    float ops[4];
+    to_operands(fixb(bq[0], 0), ops);
 #pragma unroll 1
-    for (int g = 0; g < KG2; g += 2) {              // branch-free body; reloads past the end are clamped (harmless re-reads)
-        float ops[4];
-        to_operands(fixb(b0, g), ops);
+    for (int g = 0; g < KG4; g += 4) {              // branch-free body; reloads past the end are clamped (harmless re-reads)
 #pragma unroll
-        for (int oc = 0; oc < OCG; ++oc) acc[oc] = mma4(acc[oc], a0[oc], ops);
-        b0 = ldb(g + 2);
+        for (int u = 0; u < 4; ++u) {
+            float nops[4];
 #pragma unroll
-        for (int oc = 0; oc < OCG; ++oc) a0[oc] = lda(oc, g + 2);
-        __builtin_amdgcn_sched_barrier(0);
-        to_operands(fixb(b1, g + 1), ops);
+            for (int oc = 0; oc < OCG; ++oc) {
+                acc[oc] = mma4(acc[oc], aq[u % AD][oc], ops);
+                aq[u % AD][oc] = lda(oc, g + AD + u);
+                if (oc == 0) bq[u] = ldb(g + 4 + u);                       // (its old content became `ops` one k-group ago)
+                if (oc == 1) to_operands(fixb(bq[(u + 1) & 3], g + u + 1), nops);
+                __builtin_amdgcn_sched_barrier(0);
+            }
 #pragma unroll
-        for (int oc = 0; oc < OCG; ++oc) acc[oc] = mma4(acc[oc], a1[oc], ops);
-        b1 = ldb(g + 3);
-#pragma unroll
-        for (int oc = 0; oc < OCG; ++oc) a1[oc] = lda(oc, g + 3);
-        __builtin_amdgcn_sched_barrier(0);
+            for (int e = 0; e < 4; ++e) ops[e] = nops[e];
+        }
     }
-    if (KG & 1) {                                   // odd k-group count: slot 0 holds the last group
-        float ops[4];
-        to_operands(fixb(b0, KG - 1), ops);
+    for (int u = 0; u < (KG & 3); ++u) {            // up to three trailing k-groups (slots hold groups KG4 + u)
+        const float4 bv = u == 0 ? bq[0] : (u == 1 ? bq[1] : bq[2]);
+        to_operands(fixb(bv, KG4 + u), ops);
 #pragma unroll
-        for (int oc = 0; oc < OCG; ++oc) acc[oc] = mma4(acc[oc], a0[oc], ops);
+        for (int oc = 0; oc < OCG; ++oc) {
+            const float4 av = u < 2 ? (u == 0 ? aq[0][oc] : aq[1][oc]) : (AD == 4 && u == 2 ? aq[2 % AD][oc] : lda(oc, KG4 + u));
+            acc[oc] = mma4(acc[oc], av, ops);
+        }
     }
 #ifdef SAD_LAYER_STAMPS
     if (blockIdx.x < 16 && lane == 0) {
@@ -290,6 +309,12 @@ __global__ __launch_bounds__(LWAVES * 64, 2) void mlp_layer_kernel(const LayerMu
         g_lstamps[sl + 4] = 0; g_lstamps[sl + 5] = 0;
     }
 #endif
+#ifdef SAD_LAYER_STAMPS
+    if (lane == 0 && blockIdx.x * LWAVES + (threadIdx.x >> 6) < 4096) {
+        g_lall[(blockIdx.x * LWAVES + (threadIdx.x >> 6)) * 4 + 0] = __builtin_amdgcn_s_memrealtime();
+        g_lall[(blockIdx.x * LWAVES + (threadIdx.x >> 6)) * 4 + 2] = (nitems - (blockIdx.x * LWAVES + (threadIdx.x >> 6)) + nwaves - 1) / nwaves;
+    }
+#endif
     for (int item = blockIdx.x * LWAVES + (threadIdx.x >> 6); item < nitems; item += nwaves) {
         const int ji = __builtin_amdgcn_readfirstlane(item < i0 ? 0 : 1);
         const int it = item - (ji ? i0 : 0);
@@ -305,6 +330,17 @@ __global__ __launch_bounds__(LWAVES * 64, 2) void mlp_layer_kernel(const LayerMu
     }
 #ifdef SAD_LAYER_STAMPS
     if (blockIdx.x < 16 && lane == 0) { g_lstamps[sl + 2] = __builtin_amdgcn_s_memtime(); g_lstamps[sl + 3] = __builtin_amdgcn_s_memrealtime(); }
+    if (lane == 0) {
+        const int w = blockIdx.x * LWAVES + (threadIdx.x >> 6);
+        if (w < 4096) {
+            g_lall[w * 4 + 1] = __builtin_amdgcn_s_memrealtime();
+            unsigned hwid;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+            unsigned xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            g_lall[w * 4 + 3] = ((unsigned long long)xcc << 32) | hwid;
+        }
+    }
 #endif
 }
 
@@ -351,6 +387,9 @@ int launch_layers(const LayerMulti &lm, long long max_items, hipStream_t st) {
 }  // namespace sad
 
 #ifdef SAD_LAYER_STAMPS
+extern "C" __attribute__((visibility("default"))) int sad_debug_read_layer_all(unsigned long long *dst) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_lall), sizeof(unsigned long long) * 4096 * 4);
+}
 extern "C" __attribute__((visibility("default"))) int sad_debug_read_layer_stamps(unsigned long long *dst) {
     return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_lstamps), sizeof(unsigned long long) * 3 * 64 * 8);
 }
