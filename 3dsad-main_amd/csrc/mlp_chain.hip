@@ -1196,7 +1196,7 @@ static int prepare_chain(const sad_mlp_args *a, sad_stream_t stream, Prepared &q
             }
             if (!j.last) { j.y = (l & 1) ? hb : ha; j.ldy = g.np[l]; }
             else { j.out = a->out; j.ld_out = a->ld_out; j.col_off = a->col_off; j.cout_last = cout; }
-            q.layer_items[l] = rows_max / 32 * j.nog;
+            q.layer_items[l] = (rows_max + 127) / 128 * j.nog;      // (128-row block) x (128-channel block) work items
         }
         q.layered = true;
         q.W = -2;
