@@ -40,6 +40,11 @@ __device__ __forceinline__ int cell_coord(float x, float x0, float inv, int g) {
 }
 
 // ---- build: bounding box, cell histogram, exclusive scan, scatter of (x,y,z,idx) records ---------
+// One 1024-thread workgroup per scene.  Scenes of up to 16 384 points keep their points in REGISTERS (PTS
+// points per thread, read once, coalesced) through all four phases — the three passes over global memory of
+// the first version (bounding box, histogram, scatter) made the SA1 build 37 us, a third of the query it
+// serves; larger scenes (N <= 65 536) walk global memory as before (PTS = 0).
+template <int PTS>
 __global__ __launch_bounds__(BUILD_T) void grid_build_kernel(const float *__restrict__ xyz, int N,
                                                              float cs_min, char *__restrict__ ws) {
     extern __shared__ int hist[];               // GRID_MAXC + 64 ints
@@ -51,16 +56,35 @@ __global__ __launch_bounds__(BUILD_T) void grid_build_kernel(const float *__rest
     GridHdr *hdr = reinterpret_cast<GridHdr *>(base);
     int *cell_start = reinterpret_cast<int *>(base + sizeof(GridHdr));
     float4 *rec = reinterpret_cast<float4 *>(base + sizeof(GridHdr) + sizeof(int) * (size_t)(GRID_MAXC + 16));
+    constexpr int NP = PTS > 0 ? PTS : 1;
+    float px[NP], py[NP], pz[NP];
+    if constexpr (PTS > 0) {
+#pragma unroll
+        for (int k = 0; k < PTS; ++k) {
+            const int j = tid + k * BUILD_T;
+            const int jj = j < N ? j : N - 1;
+            px[k] = p[jj * 3]; py[k] = p[jj * 3 + 1]; pz[k] = p[jj * 3 + 2];
+        }
+    }
+    auto for_points = [&](auto &&fn) {          // fn(j, x, y, z) for this thread's points
+        if constexpr (PTS > 0) {
+#pragma unroll
+            for (int k = 0; k < PTS; ++k) {
+                const int j = tid + k * BUILD_T;
+                if (j < N) fn(j, px[k], py[k], pz[k]);
+            }
+        } else {
+            for (int j = tid; j < N; j += BUILD_T) fn(j, p[j * 3], p[j * 3 + 1], p[j * 3 + 2]);
+        }
+    };
 
     // 1. bounding box
     float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
-    for (int j = tid; j < N; j += BUILD_T)
-#pragma unroll
-        for (int d = 0; d < 3; ++d) {
-            const float v = p[j * 3 + d];
-            lo[d] = v < lo[d] ? v : lo[d];
-            hi[d] = v > hi[d] ? v : hi[d];
-        }
+    for_points([&](int, float x, float y, float z) {
+        lo[0] = x < lo[0] ? x : lo[0]; hi[0] = x > hi[0] ? x : hi[0];
+        lo[1] = y < lo[1] ? y : lo[1]; hi[1] = y > hi[1] ? y : hi[1];
+        lo[2] = z < lo[2] ? z : lo[2]; hi[2] = z > hi[2] ? z : hi[2];
+    });
 #pragma unroll
     for (int d = 0; d < 3; ++d)
         for (int off = 32; off >= 1; off >>= 1) {
@@ -125,7 +149,7 @@ __global__ __launch_bounds__(BUILD_T) void grid_build_kernel(const float *__rest
         iz = iz < 0 ? 0 : (iz > gz - 1 ? gz - 1 : iz);
         return (iz * gy + iy) * gx + ix;
     };
-    for (int j = tid; j < N; j += BUILD_T) atomicAdd(&hist[cell_of(p[j * 3], p[j * 3 + 1], p[j * 3 + 2])], 1);
+    for_points([&](int, float x, float y, float z) { atomicAdd(&hist[cell_of(x, y, z)], 1); });
     __syncthreads();
     // 4. exclusive scan over the cells: thread t owns cells [t*CPT, (t+1)*CPT)
     constexpr int CPT = GRID_MAXC / BUILD_T;   // 16
@@ -156,11 +180,22 @@ __global__ __launch_bounds__(BUILD_T) void grid_build_kernel(const float *__rest
     if (tid == BUILD_T - 1) cell_start[GRID_MAXC] = tbase + sum;   // = N
     __syncthreads();
     // 5. scatter records (order inside a cell is irrelevant: the query restores index order)
-    for (int j = tid; j < N; j += BUILD_T) {
-        const float x = p[j * 3], y = p[j * 3 + 1], z = p[j * 3 + 2];
+    for_points([&](int j, float x, float y, float z) {
         const int pos = atomicAdd(&hist[cell_of(x, y, z)], 1);
         rec[pos] = make_float4(x, y, z, __int_as_float(j));
-    }
+    });
+}
+
+// inclusive prefix sum over the 64 lanes with DPP row shifts / broadcasts (the shuffle version is six dependent
+// ds_bpermute round trips)
+__device__ __forceinline__ int wave_incl_scan(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, true);    // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, true);    // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, true);    // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, true);    // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, true);    // row_bcast:15 -> rows 1, 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, true);    // row_bcast:31 -> rows 2, 3
+    return v;
 }
 
 // ---- query -------------------------------------------------------------------------------------
@@ -205,42 +240,68 @@ __global__ __launch_bounds__(GQ_WAVES * 64) void grid_query_kernel(const float *
 
     for (int w = lane; w < NR * (NWP + 64); w += 64) bm[w] = 0u;
 
+    // The wave's GQ_CPW centroids are independent: their dependent memory round trips (centroid -> cell starts ->
+    // first records) are issued for all of them before any is processed — one latency chain per wave instead
+    // of one per centroid (the kernel is latency-bound: ~10 000 cycles of wave time per centroid for ~2 000 of work).
+    const int m0 = (bx * GQ_WAVES + wave) * GQ_CPW;
+    float ccx[GQ_CPW], ccy[GQ_CPW], ccz[GQ_CPW];
+    int crs[GQ_CPW], crl[GQ_CPW];               // lanes 0..8: start / length of the nine record runs
+#pragma unroll
     for (int cc = 0; cc < GQ_CPW; ++cc) {
-        const int m = (bx * GQ_WAVES + wave) * GQ_CPW + cc;
-        if (m >= M) break;                      // wave-uniform
+        const int m = m0 + cc < M ? m0 + cc : M - 1;
         const float *q = new_xyz + ((size_t)b * M + m) * 3;
-        const float cx = q[0], cy = q[1], cz = q[2];
+        ccx[cc] = q[0]; ccy[cc] = q[1]; ccz[cc] = q[2];
+        const int ix = cell_coord(ccx[cc], x0, inv, gx), iy = cell_coord(ccy[cc], y0, inv, gy), iz = cell_coord(ccz[cc], z0, inv, gz);
+        // nine runs of up to three x-adjacent cells (contiguous in the record array): lane l < 9
+        int rs = 0, rl = 0;
+        const int dy = lane % 3 - 1, dz = (lane / 3) % 3 - 1;
+        const int yy = iy + dy, zz = iz + dz;
+        const int xlo = ix - 1 < 0 ? 0 : ix - 1, xhi = ix + 1 > gx - 1 ? gx - 1 : ix + 1;
+        if (lane < 9 && yy >= 0 && yy < gy && zz >= 0 && zz < gz && xlo <= xhi) {
+            const int c0 = (zz * gy + yy) * gx;
+            rs = cell_start[c0 + xlo];
+            rl = cell_start[c0 + xhi + 1] - rs;
+        }
+        crs[cc] = rs; crl[cc] = rl;
+    }
+    float4 pr0[GQ_CPW];                         // first 64 candidate records of each centroid
+#pragma unroll
+    for (int cc = 0; cc < GQ_CPW; ++cc) {
+        int src = __builtin_amdgcn_readlane(crs[cc], 0) + lane, off = 0;
+#pragma unroll
+        for (int r = 0; r < 9; ++r) {
+            const int st = __builtin_amdgcn_readlane(crs[cc], r);
+            src = lane >= off ? st + (lane - off) : src;
+            off += __builtin_amdgcn_readlane(crl[cc], r);
+        }
+        pr0[cc] = rec[lane < off ? src : 0];
+    }
+#pragma unroll
+    for (int cc = 0; cc < GQ_CPW; ++cc) {
+        const int m = m0 + cc;
+        if (m >= M) break;                      // wave-uniform
+        const float cx = ccx[cc], cy = ccy[cc], cz = ccz[cc];
         float r2[NR];
 #pragma unroll
         for (int r = 0; r < NR; ++r) r2[r] = prm.radii[r] * prm.radii[r];
-        const int ix = cell_coord(cx, x0, inv, gx), iy = cell_coord(cy, y0, inv, gy), iz = cell_coord(cz, z0, inv, gz);
-        // nine runs of up to three x-adjacent cells (contiguous in the record array): lane l < 9
-        int rs = 0, rl = 0;
-        {
-            const int dy = lane % 3 - 1, dz = (lane / 3) % 3 - 1;
-            const int yy = iy + dy, zz = iz + dz;
-            const int xlo = ix - 1 < 0 ? 0 : ix - 1, xhi = ix + 1 > gx - 1 ? gx - 1 : ix + 1;
-            if (lane < 9 && yy >= 0 && yy < gy && zz >= 0 && zz < gz && xlo <= xhi) {
-                const int c0 = (zz * gy + yy) * gx;
-                rs = cell_start[c0 + xlo];
-                rl = cell_start[c0 + xhi + 1] - rs;
-            }
-        }
         int rstart[9], roff[10];
         roff[0] = 0;
 #pragma unroll
         for (int r = 0; r < 9; ++r) {
-            rstart[r] = __builtin_amdgcn_readlane(rs, r);
-            roff[r + 1] = roff[r] + __builtin_amdgcn_readlane(rl, r);
+            rstart[r] = __builtin_amdgcn_readlane(crs[cc], r);
+            roff[r + 1] = roff[r] + __builtin_amdgcn_readlane(crl[cc], r);
         }
         const int T = roff[9];
         for (int i0 = 0; i0 < T; i0 += 64) {
             const int i = i0 + lane;
             const bool valid = i < T;
-            int src = rstart[0] + i;
+            float4 pr = pr0[cc];
+            if (i0 > 0) {                       // (rare: more than 64 candidates)
+                int src = rstart[0] + i;
 #pragma unroll
-            for (int r = 1; r < 9; ++r) src = i >= roff[r] ? rstart[r] + (i - roff[r]) : src;
-            const float4 pr = rec[valid ? src : 0];
+                for (int r = 1; r < 9; ++r) src = i >= roff[r] ? rstart[r] + (i - roff[r]) : src;
+                pr = rec[valid ? src : 0];
+            }
             const float d = sad::d2f(pr.x, pr.y, pr.z, cx, cy, cz);
             const unsigned j = (unsigned)__float_as_int(pr.w);
 #pragma unroll
@@ -261,11 +322,7 @@ __global__ __launch_bounds__(GQ_WAVES * 64) void grid_query_kernel(const float *
             dm[r * 64 + lane] = 0u;
             int cnt = 0;
             for (unsigned dd = dirty; dd; dd &= dd - 1) cnt += __builtin_popcount(bw[__builtin_ctz(dd)]);
-            int incl = cnt;
-            for (int off = 1; off < 64; off <<= 1) {
-                const int v = __shfl_up(incl, off, 64);
-                if (lane >= off) incl += v;
-            }
+            const int incl = wave_incl_scan(cnt);               // DPP: no LDS round trips on this dependent chain
             int slot = incl - cnt;                              // exclusive prefix
             const int total = __builtin_amdgcn_readlane(incl, 63);
             int myfirst = 0;
@@ -332,10 +389,18 @@ SAD_API int sad_ball_query_grid_f32(const float *xyz, const float *new_xyz, int 
         rmax = radii[r] > rmax ? radii[r] : rmax;
     }
     hipStream_t st = (hipStream_t)stream;
-    static std::atomic<uint64_t> attr_done{0};
-    sad::lds_attr_once(attr_done, reinterpret_cast<const void *>(&grid_build_kernel), 96 * 1024);
-    hipLaunchKernelGGL(grid_build_kernel, dim3(B), dim3(BUILD_T), sizeof(int) * (GRID_MAXC + 64), st, xyz, N,
-                       rmax * 1.001f, (char *)workspace);
+    static std::atomic<uint64_t> attr_done0{0}, attr_done4{0}, attr_done16{0};
+    const size_t blds = sizeof(int) * (GRID_MAXC + 64);
+    if (N <= 4 * BUILD_T) {
+        sad::lds_attr_once(attr_done4, reinterpret_cast<const void *>(&grid_build_kernel<4>), 96 * 1024);
+        hipLaunchKernelGGL(grid_build_kernel<4>, dim3(B), dim3(BUILD_T), blds, st, xyz, N, rmax * 1.001f, (char *)workspace);
+    } else if (N <= 16 * BUILD_T) {
+        sad::lds_attr_once(attr_done16, reinterpret_cast<const void *>(&grid_build_kernel<16>), 96 * 1024);
+        hipLaunchKernelGGL(grid_build_kernel<16>, dim3(B), dim3(BUILD_T), blds, st, xyz, N, rmax * 1.001f, (char *)workspace);
+    } else {
+        sad::lds_attr_once(attr_done0, reinterpret_cast<const void *>(&grid_build_kernel<0>), 96 * 1024);
+        hipLaunchKernelGGL(grid_build_kernel<0>, dim3(B), dim3(BUILD_T), blds, st, xyz, N, rmax * 1.001f, (char *)workspace);
+    }
     if (int e = sad::check_launch("sad_ball_query_grid_f32 (build)")) return e;
     const char *ws = (const char *)workspace;
     switch (n_radii) {

@@ -1,0 +1,27 @@
+"""Ball-query timing on the KITTI SA1 / SA2 shapes (B = 32): HIP events around sad_ball_query_grid_f32
+(build + query), run under tools/trace_one.sh for the per-kernel split.  usage: python tools/bq_bench.py"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import sad_amd
+from sad_amd import config, ops, synth
+dev = torch.device("cuda:0")
+cfg = config.KITTI
+pts = torch.from_numpy(synth.make_batch(0, 32)).to(dev)
+xyz = pts[:, :, :3].contiguous()
+c1 = ops.gather_xyz(xyz, ops.fps(xyz, 4096))
+c2 = c1[:, :1024].contiguous()
+def timeit(fn, reps=20):
+    fn(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps * 1e3
+st1, st2 = cfg.stages[0], cfg.stages[1]
+t1 = timeit(lambda: ops.ball_query_multi(st1.radii, st1.nsamples, xyz, c1, return_counts=True))
+t2 = timeit(lambda: ops.ball_query_multi(st2.radii, st2.nsamples, c1, c2, return_counts=True))
+work = config.work_per_scene(cfg)
+b1 = 32 * sum(16384 * 12 + 4096 * 12 + 4096 * s * 4 for s in st1.nsamples)
+print(f"SA1 ball query (16384 -> 4096 x 3 radii, 32 scenes): {t1:.1f} us = {b1 / t1 / 1e3:.0f} GB/s of algorithmic bytes ({b1 / 1e6:.1f} MB)")
+print(f"SA2 ball query (4096 -> 1024 x 3 radii, 32 scenes): {t2:.1f} us")

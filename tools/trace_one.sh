@@ -7,7 +7,7 @@ python3 - gpurun_out/$name <<'PY'
 import csv, glob, sys
 f = glob.glob(sys.argv[1] + "/*/*kernel_trace.csv")[0]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
-rows = [r for r in rows if any(k in r["Kernel_Name"] for k in ("mlp_", "rowscan", "fillBuffer", "FillBuffer", "memset"))]
+rows = [r for r in rows if any(k in r["Kernel_Name"] for k in ("mlp_", "rowscan", "fillBuffer", "FillBuffer", "memset", "grid_", "ball_query", "fps_"))]
 tail = rows[-14:]
 t0 = int(tail[0]["Start_Timestamp"])
 for r in tail:
