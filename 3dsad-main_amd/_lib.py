@@ -77,6 +77,7 @@ SIGNATURES = {
     "sad_ball_query_grid_f32": (ctypes.c_int, [vp, vp, ctypes.c_int, c_f32p, ctypes.POINTER(ctypes.c_int),
                                               ctypes.POINTER(vp), ctypes.POINTER(vp),
                                               ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp]),
+    "sad_subsample_pad_f32": (ctypes.c_int, [vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_uint, vp, vp]),
     "sad_knn_f32": (ctypes.c_int, [vp, vp] + [ctypes.c_int] * 4 + [vp, vp]),
     "sad_mlp_packed_floats": (ctypes.c_size_t, [ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.c_int]),
     "sad_mlp_pack_f32": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.c_int,

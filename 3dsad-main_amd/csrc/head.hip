@@ -96,3 +96,47 @@ SAD_API int sad_decode_boxes_f32(const float *cand, const float *o, int B, int K
                        cand, o, total, a, boxes);
     return sad::check_launch("sad_decode_boxes_f32");
 }
+
+// ---- SPEC.md §17: ragged scenes -> fixed point count ------------------------------------------------------
+// HBM-bound row copy (algorithmic bytes: n_points * C * 4 read + written per scene); one thread per output row,
+// the source row is a pure integer function of (seed, scene, row), identical to io.fix_size and the oracle.
+namespace {
+__device__ __forceinline__ unsigned mix32(unsigned a) {
+    a ^= a >> 16; a *= 0x85EBCA6Bu; a ^= a >> 13; a *= 0xC2B2AE35u; a ^= a >> 16;
+    return a;
+}
+__device__ __forceinline__ unsigned h17(unsigned seed, unsigned b, unsigned i) {
+    return mix32(seed * 0x9E3779B1u + b * 0x85EBCA77u + i * 0xC2B2AE3Du + 0x27D4EB2Fu);
+}
+__global__ __launch_bounds__(256) void subsample_pad_kernel(const float *__restrict__ points, const int32_t *__restrict__ offsets,
+                                                            int C, int n_points, unsigned seed, float *__restrict__ out) {
+    const int b = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_points) return;
+    const long long o = offsets[b], n = (long long)offsets[b + 1] - o;
+    float *dst = out + ((size_t)b * n_points + i) * C;
+    if (n <= 0) {
+        for (int c = 0; c < C; ++c) dst[c] = 0.f;
+        return;
+    }
+    long long j;
+    if (n == n_points) j = i;
+    else if (n > n_points) j = ((long long)i * n + (long long)(h17(seed, (unsigned)b, 0xFFFFFFFFu) % (unsigned)n)) / n_points;
+    else j = i < n ? i : (long long)(h17(seed, (unsigned)b, (unsigned)i) % (unsigned)n);
+    const float *src = points + (size_t)(o + j) * C;
+    if (C == 4 && (((uintptr_t)points | (uintptr_t)out) & 15) == 0) {
+        *reinterpret_cast<float4 *>(dst) = *reinterpret_cast<const float4 *>(src);
+    } else {
+        for (int c = 0; c < C; ++c) dst[c] = src[c];
+    }
+}
+}  // namespace
+
+SAD_API int sad_subsample_pad_f32(const float *points, const int32_t *offsets, int B, int C, int n_points,
+                                  unsigned seed, float *out, sad_stream_t stream) {
+    SAD_REQUIRE(offsets && out, "sad_subsample_pad_f32: NULL pointer");
+    SAD_REQUIRE(B >= 1 && B <= 65535 && C >= 1 && C <= 64 && n_points >= 1, "sad_subsample_pad_f32: need 1 <= B <= 65535, 1 <= C <= 64, n_points >= 1");
+    hipLaunchKernelGGL(subsample_pad_kernel, dim3((unsigned)((n_points + 255) / 256), B), dim3(256), 0, (hipStream_t)stream,
+                       points, offsets, C, n_points, seed, out);
+    return sad::check_launch("sad_subsample_pad_f32");
+}

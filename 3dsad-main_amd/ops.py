@@ -167,6 +167,23 @@ def group_points(features: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def subsample_pad(points: torch.Tensor, offsets: torch.Tensor, n_points: int, seed: int = 0) -> torch.Tensor:
+    """Ragged scenes -> a fixed point count on the GPU (SPEC.md §17; the step before the path).
+    points [total, C] f32 (all scenes concatenated), offsets [B+1] int32 on the GPU -> [B, n_points, C]:
+    more points than needed = an evenly spread subset in file order, fewer = all points then hashed
+    repeats, empty = zeros.  Same rows as the host loader ``io.fix_size(points_b, n_points, seed, scene=b)``."""
+    points = _need(points, "points", torch.float32, 2)
+    offsets = _need(offsets, "offsets", torch.int32, 1)
+    B = offsets.shape[0] - 1
+    if B < 1:
+        raise ValueError("offsets must have B + 1 >= 2 entries")
+    C = points.shape[1]
+    out = torch.empty((B, n_points, C), dtype=torch.float32, device=points.device)
+    check(lib().sad_subsample_pad_f32(points.data_ptr(), offsets.data_ptr(), B, C, int(n_points),
+                                      int(seed) & 0xFFFFFFFF, out.data_ptr(), _stream()), "sad_subsample_pad_f32")
+    return out
+
+
 def ball_query(radius: Union[float, torch.Tensor], nsample: int, xyz: torch.Tensor,
                new_xyz: torch.Tensor) -> torch.Tensor:
     """Ball query (SPEC.md §3).  ``radius``: Python float (fixed) or [B,M] f32 tensor (adaptive,

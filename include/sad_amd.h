@@ -123,6 +123,13 @@ int sad_ball_query_grid_f32(const float *xyz, const float *new_xyz, int n_radii,
                             const int *nsamples, int32_t *const *idx, int32_t *const *cnt, int B,
                             int N, int M, void *workspace, sad_stream_t stream);
 
+/* SPEC.md §17 (the step before the path).  Ragged scenes -> fixed point count:
+ * points[total, C] (C floats per point), offsets[B+1] (device, int32; scene b owns rows offsets[b] ..
+ * offsets[b+1]-1) -> out[B, n_points, C].  Deterministic for (seed, scene); integer arithmetic only, so the
+ * rows equal those of the numpy loader (io.fix_size) and of the oracle. */
+int sad_subsample_pad_f32(const float *points, const int32_t *offsets, int B, int C, int n_points,
+                          unsigned seed, float *out, sad_stream_t stream);
+
 /* SPEC.md §4.  -> idx[B,M,K] sorted by (d2, index); K <= 64, K <= N. */
 int sad_knn_f32(const float *xyz, const float *new_xyz, int B, int N, int M, int K, int32_t *idx,
                 sad_stream_t stream);

@@ -195,6 +195,17 @@ def sa_group_mlp_max(xyz, feat_pm, new_xyz, idx, layers, out=None, col_off=0, sk
     return out
 
 
+def subsample_pad(points, offsets, n_points, seed=0):
+    """SPEC.md §17.  points [total, C] f32, offsets [B+1] int32 -> out [B, n_points, C]."""
+    points, pp = _f(points)
+    offsets, po = _i(offsets)
+    B = offsets.shape[0] - 1
+    C = points.shape[1]
+    out = np.empty((B, n_points, C), np.float32)
+    lib().orc_subsample_pad(pp, po, B, C, int(n_points), ctypes.c_uint32(int(seed) & 0xFFFFFFFF), out.ctypes.data_as(_f32p))
+    return out
+
+
 def bf16_round(x):
     """SPEC.md §14: round-to-nearest-even binary32 -> bfloat16, returned as binary32 values."""
     u = np.ascontiguousarray(x, dtype=np.float32).view(np.uint32).astype(np.uint64)

@@ -557,3 +557,29 @@ ORC_API void orc_nms_bev(const float *boxes, int B, int K, float iou_thr, float 
         free(rank);
     }
 }
+
+/* SPEC.md §17 — ragged scenes -> fixed point count (integer arithmetic only: every implementation agrees).
+ * points[total, C], offsets[B+1] -> out[B, n_points, C]. */
+static inline uint32_t mix32(uint32_t a) {
+    a ^= a >> 16; a *= 0x85EBCA6Bu; a ^= a >> 13; a *= 0xC2B2AE35u; a ^= a >> 16;
+    return a;
+}
+static inline uint32_t h17(uint32_t seed, uint32_t b, uint32_t i) {
+    return mix32(seed * 0x9E3779B1u + b * 0x85EBCA77u + i * 0xC2B2AE3Du + 0x27D4EB2Fu);
+}
+ORC_API void orc_subsample_pad(const float *points, const int32_t *offsets, int B, int C, int n_points,
+                               uint32_t seed, float *out) {
+    for (int b = 0; b < B; ++b) {
+        const int64_t o = offsets[b], n = (int64_t)offsets[b + 1] - o;
+        float *dst = out + (size_t)b * n_points * C;
+        if (n <= 0) { memset(dst, 0, sizeof(float) * (size_t)n_points * C); continue; }
+        const int64_t r = (int64_t)(h17(seed, (uint32_t)b, 0xFFFFFFFFu) % (uint32_t)n);
+        for (int64_t i = 0; i < n_points; ++i) {
+            int64_t j;
+            if (n == n_points) j = i;
+            else if (n > n_points) j = (i * n + r) / n_points;
+            else j = i < n ? i : (int64_t)(h17(seed, (uint32_t)b, (uint32_t)i) % (uint32_t)n);
+            memcpy(dst + (size_t)i * C, points + (size_t)(o + j) * C, sizeof(float) * (size_t)C);
+        }
+    }
+}

@@ -470,3 +470,29 @@ def test_fps_cell_geometries_agree(orc, sad, dev):
             ops.fps(_t(rng.normal(size=(1, 16384, 3)).astype(np.float32), dev), 10)
     finally:
         _lib.set_option("fps_threads", 0)
+
+
+def test_subsample_pad_gpu(orc, sad, dev, tmp_path):
+    """SPEC.md §17 on the device: ops.subsample_pad == oracle == io.fix_size, from files written here (KITTI-style
+    .bin) through io.load_ragged; the result feeds the detector like a host-prepared batch."""
+    import torch
+    from sad_amd import io, ops
+    rng = np.random.default_rng(5)
+    sizes = [30000, 9000, 16384, 1, 0, 16385]
+    paths = []
+    for i, n in enumerate(sizes):
+        p = tmp_path / f"s{i}.bin"
+        rng.uniform(-20, 60, (n, 4)).astype("<f4").tofile(p)
+        paths.append(str(p))
+    pts, offs = io.load_ragged(paths)
+    assert offs.tolist() == [0] + list(np.cumsum(sizes))
+    for seed in (0, 99):
+        got = ops.subsample_pad(_t(pts, dev), _t(offs, dev), 16384, seed).cpu().numpy()
+        want = orc.subsample_pad(pts, offs, 16384, seed)
+        np.testing.assert_array_equal(got, want)
+        host = io.load_batch(paths, 16384, seed=seed)
+        np.testing.assert_array_equal(got, host)
+    # 5-column nuScenes-style points and a tiny target
+    p5 = rng.normal(size=(777, 5)).astype(np.float32)
+    o5 = np.array([0, 500, 777], np.int32)
+    np.testing.assert_array_equal(ops.subsample_pad(_t(p5, dev), _t(o5, dev), 64, 1).cpu().numpy(), orc.subsample_pad(p5, o5, 64, 1))

@@ -40,3 +40,23 @@ def test_crop_and_bad_file(tmp_path, sad):
     (tmp_path / "bad.bin").write_bytes(b"\0" * 10)
     with pytest.raises(ValueError):
         io.read_bin(str(tmp_path / "bad.bin"))
+
+
+def test_fix_size_equals_oracle_subsample_pad(orc, sad):
+    """SPEC.md §17: io.fix_size (numpy) and the C oracle pick the same rows for ragged scenes (more points than
+    needed, fewer, exactly enough, one point, empty)."""
+    from sad_amd import io
+    rng = np.random.default_rng(17)
+    sizes = [5000, 300, 1024, 1, 0, 1025, 40000]
+    parts = [rng.normal(size=(n, 4)).astype(np.float32) for n in sizes]
+    pts = np.concatenate(parts, 0)
+    offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+    for seed in (0, 7, 123456789):
+        got = orc.subsample_pad(pts, offs, 1024, seed)
+        for b, p in enumerate(parts):
+            np.testing.assert_array_equal(got[b], io.fix_size(p, 1024, seed, scene=b), err_msg=f"scene {b} seed {seed}")
+    big = io.fix_size(parts[0], 1024, 3, scene=0)
+    rows = {r.tobytes() for r in parts[0]}
+    assert all(r.tobytes() in rows for r in big) and len({r.tobytes() for r in big}) == 1024      # a subset, no repeats
+    sel = io.select_rows(5000, 1024, 3, 0)
+    assert (np.diff(sel) > 0).all() and sel.max() - sel.min() > 4000                                # file order, spread over the file
