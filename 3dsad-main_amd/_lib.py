@@ -33,6 +33,7 @@ class MlpArgs(ctypes.Structure):
         ("out", vp), ("ld_out", ctypes.c_int), ("col_off", ctypes.c_int),
         ("geometry", ctypes.c_int),
         ("scratch", vp), ("scratch_bytes", ctypes.c_size_t),
+        ("prescanned", ctypes.c_int),
     ]
 
 
@@ -83,6 +84,8 @@ SIGNATURES = {
     "sad_mlp_pack_f32": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.c_int,
                                        ctypes.POINTER(vp), ctypes.POINTER(vp), vp, vp]),
     "sad_mlp_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    "sad_mlp_rowscan": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_int),
+                                       ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(vp), vp]),
     "sad_mlp_scratch_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                                ctypes.POINTER(ctypes.c_int)]),
     "sad_mlp_chain_f32": (ctypes.c_int, [ctypes.POINTER(MlpArgs), vp]),

@@ -1028,6 +1028,20 @@ int launch_rowscan(const int32_t *cnt, int ngroups, int S, int R, int *tab, hipS
 }
 }  // namespace sad
 
+SAD_API int sad_mlp_rowscan(int n, const int32_t *const *cnt, const int32_t *const *idx, const int *S, int B, int N,
+                            int M, void *const *workspace, sad_stream_t stream) {
+    SAD_REQUIRE(n >= 1 && n <= 3 && cnt && idx && S && workspace, "sad_mlp_rowscan: need 1..3 chains and non-NULL arrays");
+    SAD_REQUIRE(B >= 1 && N >= 1 && M >= 1 && (long long)B * M < (1LL << 30), "sad_mlp_rowscan: bad B/N/M");
+    sad::ScanJob jobs[3];
+    for (int i = 0; i < n; ++i) {
+        SAD_REQUIRE(cnt[i] && idx[i] && workspace[i] && S[i] >= 1 && S[i] <= 64, "sad_mlp_rowscan: chain %d: NULL pointer or bad nsample", i);
+        SAD_REQUIRE((uintptr_t)workspace[i] % 16 == 0, "sad_mlp_rowscan: workspace must be 16-byte aligned");
+        SAD_REQUIRE((long long)B * M * S[i] < (1LL << 31), "sad_mlp_rowscan: B*M*S too large");
+        jobs[i] = sad::make_scan_job(cnt[i], B * M, S[i], 32, (int *)workspace[i], sad::get_option(sad::OPT_MLP_NODEDUP), idx[i], N, M);
+    }
+    return sad::launch_rowscan_multi(jobs, n, (hipStream_t)stream);
+}
+
 SAD_API size_t sad_mlp_scratch_bytes(int B, int M, int S, int L, const int *dims) {
     if (B < 1 || M < 1 || S < 1 || L < 1 || L > MAXL || !dims) return 0;
     const Geometry g = geometry(L, dims, 1);
@@ -1057,6 +1071,7 @@ struct Prepared {
     bool reg;           // geometry 2: register-resident chain kernel (csrc/mlp_reg.hip); `rc` is filled, p is not
     sad::RegChain rc;
     sad::ScanJob scan;  // row-packing scan this chain needs before its kernel
+    bool prescanned;    // ... unless the caller already ran sad_mlp_rowscan on the workspace
     bool layered;       // geometry 3: layer-streamed chain (csrc/mlp_layer.hip); lj[0..nl) are its launches
     sad::LayerJob lj[MAXL];
     int nl;
@@ -1073,6 +1088,7 @@ static int prepare_chain(const sad_mlp_args *a, sad_stream_t stream, Prepared &q
     q.launched = false;
     q.reg = false;
     q.layered = false;
+    q.prescanned = a && a->prescanned != 0;
     SAD_REQUIRE(a, "sad_mlp_chain_f32: NULL args");
     if (int e = check_dims("sad_mlp_chain_f32", a->L, a->dims)) return e;
     const bool grouped = a->idx != nullptr;
@@ -1360,13 +1376,20 @@ int launch_mlp2(const MlpParams &p, size_t lds, long long nblocks, hipStream_t s
     return sad::check_launch("sad_mlp_chain_f32");
 }
 
+// scans of the chains that did not come with a table (prescanned = 0), in one pair of launches
+int launch_pending_scans(const Prepared *const *qs, int n, hipStream_t st) {
+    sad::ScanJob jobs[sad::REG_MAX_CHAINS];
+    int m = 0;
+    for (int i = 0; i < n; ++i)
+        if (!qs[i]->prescanned) jobs[m++] = qs[i]->scan;
+    return m ? sad::launch_rowscan_multi(jobs, m, st) : SAD_OK;
+}
+
 int launch_reg_chains(const Prepared *const *qs, int n, hipStream_t st) {
     sad::RegMulti mp{};
     mp.n = n;
     mp.max_tiles = 0;
-    sad::ScanJob jobs[sad::REG_MAX_CHAINS];
-    for (int i = 0; i < n; ++i) jobs[i] = qs[i]->scan;
-    if (int e = sad::launch_rowscan_multi(jobs, n, st)) return e;
+    if (int e = launch_pending_scans(qs, n, st)) return e;
     for (int i = 0; i < n; ++i) {
         mp.c[i] = qs[i]->rc;
         mp.shape[i] = qs[i]->reg_shape;
@@ -1379,10 +1402,7 @@ int launch_reg_chains(const Prepared *const *qs, int n, hipStream_t st) {
 // Layer-streamed chains (one or two with the same number of layers): counters zeroed, one scan, then one
 // launch per layer carrying that layer of every chain.
 int launch_layered_chains(const Prepared *const *qs, int n, hipStream_t st) {
-    sad::ScanJob jobs[2];
-    for (int i = 0; i < n; ++i) jobs[i] = qs[i]->scan;
-    if (hipMemsetAsync(qs[0]->layer_counters, 0, 64, st) != hipSuccess) return sad::fail(SAD_ELAUNCH, "sad_mlp_chain_f32: counter memset failed");
-    if (int e = sad::launch_rowscan_multi(jobs, n, st)) return e;
+    if (int e = launch_pending_scans(qs, n, st)) return e;
     for (int l = 0; l < qs[0]->nl; ++l) {
         sad::LayerMulti lm{};
         lm.n = n;

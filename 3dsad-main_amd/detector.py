@@ -22,7 +22,7 @@ from .sa_module import SAModuleMSG
 
 class SADDetector(nn.Module):
     def __init__(self, cfg: DetectorConfig, weights: dict, device, overlap_fps: bool = True,
-                 n_fps_streams: int = 4, n_main_streams: int = 2, nested_fps_shortcut: bool = True,
+                 n_fps_streams: int = 2, n_main_streams: int = 2, nested_fps_shortcut: bool = True,
                  dtype: str = "f32", query_on_sampling_stream: bool = True):
         """``dtype="bf16"``: every MLP runs on the bf16 matrix-core path (SPEC.md §14, BASELINE.json
         configs[4]); sampling, ball query and box decode are unchanged."""
@@ -206,7 +206,8 @@ class SADDetector(nn.Module):
                     prev = cur
                     cur = self._sample_stage(si, cur)
                     centroids.append(cur)
-                    queries.append(self.stages[si].query(prev, cur) if self.query_on_sampling_stream else None)
+                    queries.append(self.stages[si].query(prev, cur, prescan=not ops.AUTOTUNE)
+                                   if self.query_on_sampling_stream else None)
                     ev = torch.cuda.Event()
                     ev.record(side)
                     evs.append(ev)
@@ -215,8 +216,9 @@ class SADDetector(nn.Module):
                 t.record_stream(main)
             for q in queries:
                 if q is not None:
-                    for t in q[0] + q[1]:
-                        t.record_stream(main)
+                    for part in q:
+                        for t in part:
+                            t.record_stream(main)
             zeros.record_stream(main)
             main.wait_event(ev_xyz)
         else:

@@ -250,6 +250,30 @@ def ball_query_multi(radii: Sequence[float], nsamples: Sequence[int], xyz: torch
     return (outs, cnts) if return_counts else outs
 
 
+def rowscan_multi(idxs: Sequence[torch.Tensor], cnts: Sequence[torch.Tensor], N: int) -> List[torch.Tensor]:
+    """Row-packing tables (prefix sum of the per-group counts + row map) of up to three branches of one ball
+    query, two launches for all of them.  Needs only what the ball query produced, so it can run on the stream
+    that ran the query (the sampling stream), off the MLP stream's critical path; pass table i as the last
+    element of branch i's ``grouped_multi`` call (``PackedMLP.grouped(..., ws=table)``)."""
+    n = len(idxs)
+    if n != len(cnts) or not 1 <= n <= 3:
+        raise ValueError("need 1..3 (idx, cnt) pairs")
+    B, M = cnts[0].shape
+    wss = []
+    for idx, cnt in zip(idxs, cnts):
+        idx = _need(idx, "idx", torch.int32, 3)
+        cnt = _need(cnt, "cnt", torch.int32, 2)
+        if tuple(idx.shape[:2]) != (B, M) or tuple(cnt.shape) != (B, M):
+            raise ValueError("idx / cnt shapes do not match")
+        wss.append(torch.empty((lib().sad_mlp_workspace_bytes(B, M, idx.shape[2]),), dtype=torch.uint8, device=idx.device))
+    c_arr = (vp * n)(*[c.data_ptr() for c in cnts])
+    i_arr = (vp * n)(*[i.data_ptr() for i in idxs])
+    s_arr = (ctypes.c_int * n)(*[int(i.shape[2]) for i in idxs])
+    w_arr = (vp * n)(*[w.data_ptr() for w in wss])
+    check(lib().sad_mlp_rowscan(n, c_arr, i_arr, s_arr, B, int(N), M, w_arr, _stream()), "sad_mlp_rowscan")
+    return wss
+
+
 def knn_query(k: int, xyz: torch.Tensor, new_xyz: torch.Tensor) -> torch.Tensor:
     """k nearest neighbours sorted by (d2, index) (SPEC.md §4).  -> idx [B,M,k] int32."""
     xyz = _need(xyz, "xyz", torch.float32, 3)
@@ -407,17 +431,18 @@ class PackedMLP:
 
     def grouped(self, xyz: torch.Tensor, feat_pm: Optional[torch.Tensor], new_xyz: torch.Tensor,
                 idx: torch.Tensor, out: Optional[torch.Tensor] = None, col_off: int = 0,
-                cnt: Optional[torch.Tensor] = None) -> torch.Tensor:
+                cnt: Optional[torch.Tensor] = None, ws: Optional[torch.Tensor] = None) -> torch.Tensor:
         """Fused group -> MLP -> max over nsample.  xyz [B,N,3]; feat_pm point-major [B,N,C] (or
         None); new_xyz [B,M,3]; idx [B,M,S].  Writes out[:, :, col_off:col_off+C_out] of a
         point-major [B,M,ld_out] buffer (allocated [B,M,C_out] when ``out`` is None).  A caller-
         provided ``out`` slice must be ZERO on entry (groups spanning two row tiles are combined
-        with an atomic max).  Samples that repeat a group's first index are skipped."""
-        a, out, _keep = self._grouped_args(xyz, feat_pm, new_xyz, idx, out, col_off, cnt)
+        with an atomic max).  Samples that repeat a group's first index are skipped.  ``ws``: the
+        row-packing table of (idx, cnt) from ``rowscan_multi`` (else the chain scans the counts itself)."""
+        a, out, _keep = self._grouped_args(xyz, feat_pm, new_xyz, idx, out, col_off, cnt, ws)
         self._launch(a)
         return out
 
-    def _grouped_args(self, xyz, feat_pm, new_xyz, idx, out, col_off, cnt):
+    def _grouped_args(self, xyz, feat_pm, new_xyz, idx, out, col_off, cnt, ws=None):
         """Validated ``MlpArgs`` of a grouped call + the output tensor + tensors to keep alive."""
         if not self.first_has_xyz:
             raise RuntimeError("this PackedMLP was packed without the xyz prefix")
@@ -452,8 +477,13 @@ class PackedMLP:
             if tuple(cnt.shape) != (B, M):
                 raise ValueError("cnt must be [B,M]")
             a.cnt = cnt.data_ptr()
-            ws = torch.empty((lib().sad_mlp_workspace_bytes(B, M, S),), dtype=torch.uint8, device=xyz.device)
-            a.workspace = ws.data_ptr()   # global row packing + dynamic pass hand-out
+            if ws is None:
+                ws = torch.empty((lib().sad_mlp_workspace_bytes(B, M, S),), dtype=torch.uint8, device=xyz.device)
+            else:             # table already filled by rowscan_multi (geometries 2 / 3 then launch no scan)
+                if ws.numel() < lib().sad_mlp_workspace_bytes(B, M, S):
+                    raise ValueError("ws: too small for this (B, M, S)")
+                a.prescanned = 1
+            a.workspace = ws.data_ptr()   # global row packing
             keep += [cnt, ws]
         a.B, a.N, a.M, a.S, a.C = B, N, M, S, C
         a.out, a.ld_out, a.col_off = out.data_ptr(), out.stride(-2), col_off
@@ -508,18 +538,24 @@ MERGE_BF16: bool = True
 def grouped_multi(calls) -> None:
     """Several independent fused group -> MLP -> max launches (the branches of one multi-radius
     stage) as ONE dispatch (``sad_mlp_chain_multi_f32``): the light chains fill the tail of the
-    heavy one.  ``calls`` = [(PackedMLP, xyz, feat_pm, new_xyz, idx, out, col_off, cnt), ...] with
-    caller-provided zero ``out`` buffers.  While autotuning, or for a single call, each chain is
+    heavy one.  ``calls`` = [(PackedMLP, xyz, feat_pm, new_xyz, idx, out, col_off, cnt[, ws]), ...] with
+    caller-provided zero ``out`` buffers (``ws``: row-packing table from ``rowscan_multi``).  While autotuning, or for a single call, each chain is
     launched (and tuned) on its own."""
     if AUTOTUNE or len(calls) < 2 or (not MERGE_BF16 and isinstance(calls[0][0], PackedMLPBf16)):
-        for mlp, xyz, feat_pm, new_xyz, idx, out, col_off, cnt in calls:
+        for c in calls:
+            mlp, xyz, feat_pm, new_xyz, idx, out, col_off, cnt = c[:8]
             mlp.grouped(xyz, feat_pm, new_xyz, idx, out=out, col_off=col_off, cnt=cnt)
         if AUTOTUNE and len(calls) >= 2 and isinstance(calls[0][0], PackedMLP):
-            _tune_stage(calls)
+            _tune_stage([c[:8] for c in calls])
         return
     args, keep = [], []
-    for mlp, xyz, feat_pm, new_xyz, idx, out, col_off, cnt in calls:
-        a, _, k = mlp._grouped_args(xyz, feat_pm, new_xyz, idx, out, col_off, cnt)
+    for c in calls:
+        mlp, xyz, feat_pm, new_xyz, idx, out, col_off, cnt = c[:8]
+        ws = c[8] if len(c) > 8 else None
+        if ws is not None and isinstance(mlp, PackedMLP):
+            a, _, k = mlp._grouped_args(xyz, feat_pm, new_xyz, idx, out, col_off, cnt, ws)
+        else:
+            a, _, k = mlp._grouped_args(xyz, feat_pm, new_xyz, idx, out, col_off, cnt)
         args.append(a)
         keep.append(k)
     bf16 = isinstance(calls[0][0], PackedMLPBf16)

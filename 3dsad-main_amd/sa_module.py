@@ -57,11 +57,17 @@ class SAModuleMSG(nn.Module):
         return fidx, ops.gather_xyz(xyz, fidx)
 
     def query(self, xyz: torch.Tensor, new_xyz: torch.Tensor, radius_pc: Optional[torch.Tensor] = None,
-              radii: Optional[Sequence[float]] = None):
-        """The stage's multi-radius ball query: ([idx_b [B,M,S_b]], [cnt_b [B,M]])."""
+              radii: Optional[Sequence[float]] = None, prescan: bool = False):
+        """The stage's multi-radius ball query: ([idx_b [B,M,S_b]], [cnt_b [B,M]]) and, with ``prescan``,
+        the row-packing tables of the branches as a third element."""
         st = self.stage
-        return ops.ball_query_multi(radii if radii is not None else st.radii, st.nsamples, xyz, new_xyz,
-                                    radius_pc, return_counts=True)
+        idxs, cnts = ops.ball_query_multi(radii if radii is not None else st.radii, st.nsamples, xyz, new_xyz,
+                                          radius_pc, return_counts=True)
+        if prescan and self.dtype == "f32":
+            # the row-packing scan needs only the query's output: run it here (on the sampling stream when the
+            # detector overlaps), so the MLP stream launches no small latency-bound kernels before its chains
+            return idxs, cnts, ops.rowscan_multi(idxs, cnts, xyz.shape[1])
+        return idxs, cnts
 
     def group_and_pool(self, xyz: torch.Tensor, feat_pm: Optional[torch.Tensor],
                        new_xyz: torch.Tensor, radius_pc: Optional[torch.Tensor] = None,
@@ -72,14 +78,16 @@ class SAModuleMSG(nn.Module):
         only, so a caller may run it ahead on another stream)."""
         st = self.stage
         B, M = new_xyz.shape[0], new_xyz.shape[1]
-        idxs, cnts = query if query is not None else self.query(xyz, new_xyz, radius_pc, radii)
+        q = query if query is not None else self.query(xyz, new_xyz, radius_pc, radii)
+        idxs, cnts = q[0], q[1]
+        wss = q[2] if len(q) > 2 else [None] * len(idxs)
         if keep is not None:
             keep["ball_idx"] = idxs
         if cat is None:      # ``cat``: a caller-provided ZERO [B,M,sum C_b] float32 buffer
             cat = torch.zeros((B, M, self.cat_channels), dtype=torch.float32, device=xyz.device)
         calls, off = [], 0               # all branches in one dispatch (ops.grouped_multi)
-        for mlp, idx, cnt in zip(self.branches, idxs, cnts):
-            calls.append((mlp, xyz, feat_pm, new_xyz, idx, cat, off, cnt))
+        for mlp, idx, cnt, ws in zip(self.branches, idxs, cnts, wss):
+            calls.append((mlp, xyz, feat_pm, new_xyz, idx, cat, off, cnt, ws))
             off += mlp.out_channels
         ops.grouped_multi(calls)
         if self.agg is None:

@@ -161,7 +161,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=32, help="scenes per GPU per step")
     ap.add_argument("--no-overlap", action="store_true", help="run FPS on the main stream")
-    ap.add_argument("--fps-streams", type=int, default=4, help="sampling streams used round-robin")
+    ap.add_argument("--fps-streams", type=int, default=2, help="sampling streams used round-robin")
     ap.add_argument("--main-streams", type=int, default=2, help="main streams used round-robin by consecutive steps")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg (parity_check then uses 4 scenes)")
     ap.add_argument("--cpu-scenes", type=int, default=32)

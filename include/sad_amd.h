@@ -195,8 +195,17 @@ typedef struct sad_mlp_args {
     /* geometry 3 only: sad_mlp_scratch_bytes(B, M, S, L, dims) bytes of 16-byte aligned device scratch */
     void *scratch;
     size_t scratch_bytes;
+    /* != 0: `workspace` already holds the row-packing table of (cnt, idx) from sad_mlp_rowscan (geometries 2
+     * and 3 only): the chain launches no scan of its own.  The scan needs coordinates-side data only, so a
+     * caller can run it right behind the ball query on another stream, off the MLP stream's critical path. */
+    int prescanned;
 } sad_mlp_args;
 size_t sad_mlp_workspace_bytes(int B, int M, int S);
+/* Row-packing tables of n (<= 3) chains over the same (B, N, M): cnt[i] [B,M] and idx[i] [B,M,S[i]] from the
+ * ball query -> workspace[i] (sad_mlp_workspace_bytes(B, M, S[i]) bytes each, 16-byte aligned).  Two launches
+ * for all n.  Pass the workspaces to sad_mlp_chain_f32 with prescanned = 1. */
+int sad_mlp_rowscan(int n, const int32_t *const *cnt, const int32_t *const *idx, const int *S, int B, int N,
+                    int M, void *const *workspace, sad_stream_t stream);
 size_t sad_mlp_scratch_bytes(int B, int M, int S, int L, const int *dims);
 int sad_mlp_chain_f32(const sad_mlp_args *args, sad_stream_t stream);
 /* n independent chains (typically the branches of one multi-radius stage, each writing its own
