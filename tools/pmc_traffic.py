@@ -1,0 +1,33 @@
+"""HBM traffic of the MLP dispatches of one step from the rocprofv3 --pmc passes of tools/pmc.sh
+(FETCH_SIZE and WRITE_SIZE collected in separate passes).  usage: python tools/pmc_traffic.py gpurun_out/pmc profiles/r02_pmc_traffic.json
+Units and corrections as /opt/skills/guides/MI355X_MICROARCH.md prescribes: both counters are in KiB... (see `note`)."""
+import csv, glob, json, os, sys
+root, out = sys.argv[1], sys.argv[2]
+MLP = ("mlp_reg_kernel", "mlp_layer_kernel", "mlp_chain_kernel", "mlp_chain2_kernel", "mlp_multi_kernel", "rowscan_")
+def total(passname, counter):
+    tot, steps = 0.0, 0
+    for f in glob.glob(os.path.join(root, passname, "*", "*_counter_collection.csv")):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] != counter:
+                continue
+            n = r["Kernel_Name"]
+            if "fps_cell_kernel" in n or "fps_cellg_kernel" in n:
+                steps += 1          # one per forward pass
+            if any(k in n for k in MLP):
+                tot += float(r["Counter_Value"])
+    return tot, steps
+fetch, s1 = total("fetch", "FETCH_SIZE")
+write, s2 = total("write", "WRITE_SIZE")
+# FETCH_SIZE / WRITE_SIZE are reported in kilobytes; on gfx950 FETCH_SIZE counts 32-byte requests as 64-byte units
+# halved, i.e. the raw value is doubled (MI355X_MICROARCH.md, HBM section) — same correction as in round 1
+res = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes, tools/pmc.sh: bench.py --geometry-file "
+                 "profiles/r02_geometry.json --main-streams 1 --steps 3 --warmup 1), summed over the MLP dispatches (mlp_reg / mlp_layer / "
+                 "mlp_chain / mlp_multi kernels + their row-packing scans) and divided by the forward passes of the run; FETCH_SIZE doubled "
+                 "per the gfx950 correction of MI355X_MICROARCH.md (HBM section); gather-width reads uncalibrated",
+       "forward_passes": s1,
+       "fetch_size_raw_kb_per_step": fetch / max(1, s1),
+       "fetch_bytes_per_step": int(2 * fetch * 1024 / max(1, s1)),
+       "write_bytes_per_step": int(write * 1024 / max(1, s2)),
+       "build": "r02"}
+json.dump(res, open(out, "w"), indent=1)
+print(json.dumps(res, indent=1))
