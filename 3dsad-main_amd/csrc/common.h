@@ -51,7 +51,8 @@ struct RegMulti {
 struct LayerJob {
     const float *x;                // layer input: feature matrix (gather) or the previous layer's row-major output
     const float *xyz, *new_xyz;    // gather only
-    const int *rowtab, *row_src, *row_gid;
+    const int *rowtab, *row_src, *row_gid;   // rowtab == NULL: plain rows, `rows` of them (no row map, no pooling)
+    int rows;
     const float *packed;
     long long off;                 // float offset of this layer inside `packed`
     int ldx, np, kg, nog;          // input row stride, padded output channels, k-groups of 8, groups of 4 output tiles

@@ -1177,6 +1177,43 @@ static int prepare_chain(const sad_mlp_args *a, sad_stream_t stream, Prepared &q
         return SAD_OK;
     }
     // ---- geometry 3: layer-streamed chain (one launch per layer, activations between layers in scratch) ----
+    if (geom_wg == 3 && !grouped) {
+        // plain rows: every layer is a row-major GEMM launch (bias + optional ReLU); the last one writes the caller's
+        // output slice, whole 128-channel blocks at a time, so C_out must be its own padded width
+        bool ok = p.cpr > 0 && a->C % 8 == 0 && p.vec_out && g.np[a->L - 1] == cout;
+        for (int l = 0; l < a->L; ++l) ok = ok && g.np[l] % 128 == 0 && (l == 0 || g.kp[l] == g.np[l - 1]);
+        ok = ok && (a->L == 1 || (a->scratch && a->scratch_bytes >= sad_mlp_scratch_bytes(a->B, a->M, 1, a->L, a->dims)));
+        if (!ok)
+            return sad::fail(SAD_EUNSUPPORTED, "sad_mlp_chain_f32: geometry 3 (layer-streamed chain) on plain rows needs 16-byte rows, "
+                                               "C %% 8 == 0, layer widths that are multiples of 128 and, for L > 1, scratch");
+        SAD_REQUIRE(a->L == 1 || (uintptr_t)a->scratch % 16 == 0, "sad_mlp_chain_f32: scratch must be 16-byte aligned");
+        const long long rows_max = (p.total_rows + 31) / 32 * 32;
+        int wa = 0, wb = 0;
+        for (int l = 0; l + 1 < a->L; ++l) {
+            int &w = (l & 1) ? wb : wa;
+            w = g.np[l] > w ? g.np[l] : w;
+        }
+        float *ha = a->L > 1 ? (float *)((char *)a->scratch + 64) : nullptr;
+        float *hb = ha ? ha + rows_max * wa : nullptr;
+        q.layer_counters = nullptr;
+        q.nl = a->L;
+        for (int l = 0; l < a->L; ++l) {
+            sad::LayerJob &j = q.lj[l];
+            j = sad::LayerJob{};
+            j.rows = (int)p.total_rows;
+            j.packed = a->packed; j.off = g.off[l]; j.np = g.np[l]; j.kg = g.kp[l] / 8; j.nog = g.np[l] / 128;
+            j.relu = (a->relu_mask >> l) & 1;
+            if (l == 0) { j.x = a->feat; j.ldx = a->ld_feat; }
+            else { j.x = ((l - 1) & 1) ? hb : ha; j.ldx = g.np[l - 1]; }
+            if (l + 1 < a->L) { j.y = (l & 1) ? hb : ha; j.ldy = g.np[l]; }
+            else { j.y = a->out + a->col_off; j.ldy = a->ld_out; }
+            q.layer_items[l] = (p.total_rows + 127) / 128 * j.nog;
+        }
+        q.prescanned = true;     // no row map
+        q.layered = true;
+        q.W = -2;
+        return SAD_OK;
+    }
     if (geom_wg == 3) {
         bool ok = grouped && a->cnt && a->workspace && a->scratch && p.cpr > 0;
         const bool all_relu = (a->relu_mask & ((1 << a->L) - 1)) == (1 << a->L) - 1;
@@ -1408,7 +1445,7 @@ int launch_layered_chains(const Prepared *const *qs, int n, hipStream_t st) {
         lm.n = n;
         long long items = 0;
         for (int i = 0; i < n; ++i) { lm.j[i] = qs[i]->lj[l]; items += qs[i]->layer_items[l]; }
-        lm.counter = qs[0]->layer_counters + l;
+        lm.counter = qs[0]->layer_counters ? qs[0]->layer_counters + l : nullptr;   // (unused: work is dealt statically)
         if (int e = sad::launch_layers(lm, items, st)) return e;
     }
     return SAD_OK;

@@ -99,6 +99,8 @@ __device__ __forceinline__ void atomic_max_pos(float *addr, float v) {
 constexpr int KC = SAD_LAYER_KC;                    // k-groups per LDS stage (2 or 4)
 constexpr int STAGE_F4 = KC * 8 * 64;               // float4 per stage: KC x (4 weight + 4 activation fragments) x 64 lanes
 
+__device__ __forceinline__ int job_rows(const LayerJob &jb) { return jb.rowtab ? jb.rowtab[0] : jb.rows; }
+
 // Row bookkeeping of one 32-row tile for this lane
 struct RowInfo {
     int q, grp;
@@ -110,7 +112,7 @@ template <bool GATHER>
 __device__ __forceinline__ RowInfo row_info(const LayerJob &jb, int rt, int lane, bool need_gid) {
     RowInfo r;
     const int j = lane & 31, h = lane >> 5;
-    const int total = jb.rowtab[0];
+    const int total = job_rows(jb);
     r.q = rt * 32 + j;
     r.live = r.q < total;
     if (!r.live) r.q = total - 1;                   // rows past the end repeat the last row and store nothing
@@ -327,8 +329,8 @@ __global__ __launch_bounds__(LWAVES * 64) __attribute__((amdgpu_waves_per_eu(2, 
     // fastest, so the workgroups that share a row block (and its activations in L2) run at about the same time.
     // Static round-robin: a shared work counter does not scale (returning atomics on one address are served at
     // ~30 ns each chip-wide; measured) and items of a layer cost the same.
-    const int i0 = ((lm.j[0].rowtab[0] + 127) / 128) * lm.j[0].nog;
-    const int nitems = lm.n > 1 ? i0 + ((lm.j[1].rowtab[0] + 127) / 128) * lm.j[1].nog : i0;
+    const int i0 = ((job_rows(lm.j[0]) + 127) / 128) * lm.j[0].nog;
+    const int nitems = lm.n > 1 ? i0 + ((job_rows(lm.j[1]) + 127) / 128) * lm.j[1].nog : i0;
     for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
         const int ji = item < i0 ? 0 : 1;
         const int it = item - (ji ? i0 : 0);
@@ -360,7 +362,7 @@ int launch_layers(const LayerMulti &lm, long long max_items, hipStream_t st) {
             (void)hipGetLastError();
             nb = 2;
         }
-        pc = nb > 4 ? 4 : nb;
+        pc = nb > 2 ? 2 : nb;       // (three fit when the allocator stays under 170 registers, and run 20 % slower: 876 vs 728 us on cluster.b1)
         per_cu.store(pc, std::memory_order_relaxed);
     }
     if (get_option(OPT_MLP_DYN_SLOTS) > 0 && get_option(OPT_MLP_DYN_SLOTS) < pc) pc = get_option(OPT_MLP_DYN_SLOTS);

@@ -351,7 +351,9 @@ class PackedMLP:
         self.out_channels = self.dims[-1]
         # geometry 3 (layer-streamed chain, csrc/mlp_layer.hip) applies when every layer's padded width is a
         # multiple of 128 channels; it needs scratch for the activations between layers
-        self._layered_ok = self.first_has_xyz and all(((d + 31) // 32 * 32) % 128 == 0 for d in self.dims[1:])
+        # (plain rows: also C % 8 == 0 and an unpadded C_out, whole 128-channel blocks are stored)
+        wide = all(((d + 31) // 32 * 32) % 128 == 0 for d in self.dims[1:])
+        self._layered_ok = wide and (self.first_has_xyz or (self.dims[0] % 8 == 0 and self.dims[-1] % 128 == 0))
 
     # Geometries tried by the autotuner: W*100 + log2(WN)*10 + RW (include/sad_amd.h, sad_mlp_args).
     _CANDIDATES = [w * 100 + n * 10 + r for w in (8, 4) for n in range(4) if (1 << n) <= w
@@ -397,7 +399,7 @@ class PackedMLP:
         stream = torch.cuda.current_stream()
         best, best_ms = 0, None
         # 1 = VALU row-per-lane kernel (narrow chains), 2 = register-resident chain kernel (csrc/mlp_reg.hip)
-        for code in self._CANDIDATES + ([1, 2, 3] if a.idx else []):
+        for code in self._CANDIDATES + ([1, 2, 3] if a.idx else ([3] if self._layered_ok else [])):
             a.geometry = code
             ms = self._time(a, stream)
             if ms is not None and (best_ms is None or ms < best_ms * 0.98):   # prefer earlier entries on ties
@@ -519,6 +521,13 @@ class PackedMLP:
         a.feat, a.ld_feat = x2.data_ptr(), x2.stride(0)
         a.B, a.N, a.M, a.S, a.C = 1, 0, R, 1, C
         a.out, a.ld_out, a.col_off = out.data_ptr(), out.stride(-2), col_off
+        geom = self._geom.get((bool(a.idx), a.B, a.N, a.M, a.S, a.ld_out)) or self.default_geometry
+        sc = None
+        if self._layered_ok and self.L > 1 and (geom == 3 or AUTOTUNE):   # activations between the layer launches
+            dims_c = (ctypes.c_int * (self.L + 1))(*self.dims)
+            nbytes = lib().sad_mlp_scratch_bytes(1, R, 1, self.L, dims_c)
+            sc = torch.empty((nbytes,), dtype=torch.uint8, device=x.device)
+            a.scratch, a.scratch_bytes = sc.data_ptr(), nbytes
         self._launch(a)
         return out
 

@@ -531,6 +531,50 @@ def test_layer_streamed_chain_parity(orc, sad, dev, B, N, M, S, C, mlp, r):
     assert np.array_equal(dense, want), "padding skip off: different result"
 
 
+PLAIN_LAYERED_CASES = [
+    # (rows, dims, relu_mask, ld_out, col_off) — geometry 3 on plain rows (the stage aggregations of the detector)
+    (777, [320, 128], None, 128, 0),          # sa2.agg, ragged last block
+    (1000, [768, 256], None, 256, 0),         # sa3.agg
+    (4096, [768, 256], None, 384, 128),       # into a slice of a wider buffer
+    (333, [128, 128, 256], 0b01, 256, 0),     # two layers through scratch, last one linear
+    (130, [8, 256, 128, 128], 0b101, 128, 0), # three layers
+    (1, [64, 128], None, 128, 0),             # a single row
+]
+
+
+@pytest.mark.parametrize("rows,dims,mask,ld_out,col_off", PLAIN_LAYERED_CASES)
+def test_layer_streamed_plain_rows_parity(orc, sad, dev, rows, dims, mask, ld_out, col_off):
+    """geometry 3 on plain rows: every layer one GEMM launch of (128 rows x 128 channels) items, bit-identical to
+    the oracle's fmaf chains; columns outside the output slice are left alone."""
+    import torch
+    from sad_amd import ops, synth
+    rng = np.random.default_rng(rows + sum(dims))
+    layers = synth.make_mlp_weights(dims, rng)
+    x = rng.normal(size=(rows, dims[0])).astype(np.float32)
+    want = orc.mlp_rows(x, layers, relu_mask=mask)
+    net = ops.PackedMLP(layers, False, dev, relu_mask=mask)
+    assert net._layered_ok
+    net.default_geometry = 3
+    out = torch.full((rows, ld_out), -7.0, dtype=torch.float32, device=dev)
+    net.rows(_t(x, dev), out=out, col_off=col_off)
+    got = out.cpu().numpy()
+    assert np.array_equal(got[:, col_off:col_off + dims[-1]], want), f"max diff {np.abs(got[:, col_off:col_off + dims[-1]] - want).max():.3e}"
+    rest = np.delete(got, np.s_[col_off:col_off + dims[-1]], axis=1)
+    assert (rest == -7.0).all(), "columns outside the slice were written"
+
+
+def test_layer_streamed_plain_rows_refusal(sad, dev):
+    """Shapes the plain layer-streamed path cannot take are refused with SAD_EUNSUPPORTED, never computed wrong."""
+    import torch
+    from sad_amd import ops, synth
+    rng = np.random.default_rng(5)
+    for dims in ([128, 64], [132, 128], [256, 128, 6]):
+        net = ops.PackedMLP(synth.make_mlp_weights(dims, rng), False, dev, relu_mask=(1 << (len(dims) - 2)) - 1 if len(dims) > 2 else None)
+        net.default_geometry = 3
+        with pytest.raises(RuntimeError, match=r"\(-2\)"):
+            net.rows(torch.zeros((64, dims[0]), device=dev))
+
+
 def test_layer_streamed_two_chain_dispatch(orc, sad, dev):
     """The cluster layer's two branches as ONE sequence of per-layer launches (sad_mlp_chain_multi_f32)."""
     import torch
