@@ -36,6 +36,7 @@ struct RegChain {
     const int *rowtab;             // hdr of the row-packing table: [0] = packed rows
     const int *row_src, *row_gid;  // row map (see rowscan_kernel)
     long long off[3];              // float offset of layer l inside `packed` (bias block, then A fragments)
+    long long stream_off;          // float offset of the stream image (mlp_coop.hip), -1 if the shape has none
     int np[3];                     // padded output channels of layer l
     int ld_feat, C, cpr;           // cpr = C / 4 when feature rows are read as 16-byte chunks, else 0
     int ld_out, col_off, cout_last, vec_out;
@@ -71,6 +72,10 @@ int launch_layers(const LayerMulti &lm, long long max_items, hipStream_t st);
 int reg_shape_id(int L, const int *kp, const int *np);   // -1: no compiled shape
 int reg_family(int shape);
 int launch_reg(const RegMulti &mp, hipStream_t st);
+// Cooperative variant (csrc/mlp_coop.hip, geometry 4): the four waves of a workgroup share the weight stream through LDS
+bool coop_shape(int shape);
+long long coop_stream_frags(int shape, const int *kp, const int *np);   // fragments (1 KB) of the stream image, 0 = none
+int launch_coop(const RegMulti &mp, hipStream_t st);
 enum { OPT_FPS_DPP = 0, OPT_MLP_RW = 1, OPT_MLP_BUDGET_KB = 2, OPT_BQ_VARIANT = 3, OPT_FPS_VARIANT = 4, OPT_MLP_FORCE = 5, OPT_MLP_DEDUP_F = 6, OPT_MLP_NODEDUP = 7, OPT_FPS_THREADS = 8, OPT_MLP_STATIC = 9, OPT_GROUP_VARIANT = 10, OPT_MLP_DYN_SLOTS = 11, OPT_MLP_NOXCD = 12, OPT_COUNT };
 
 inline int fail(int code, const char *fmt, ...) {

@@ -909,6 +909,33 @@ __global__ __launch_bounds__(256) void pack_kernel(const float *__restrict__ Wm,
     dst[t] = ok ? Wm[(size_t)oc * Cin + k] : 0.f;
 }
 
+// Stream image of a 3-layer chain (mlp_coop.hip): the A fragments of the three layers copied into the order a tile
+// consumes them — per layer-0 output tile o its NT0 fragments, then the 4*NO1 layer-1 fragments it feeds (output tile
+// i / 4, k-group 4o + i % 4), then layer 2 tile by tile; zero fragments pad the last stage.
+__global__ __launch_bounds__(256) void stream_pack_kernel(const float *__restrict__ packed, long long off0, long long off1, long long off2,
+                                                          int NT0, int NO0, int NO1, int NO2, long long nfrag, float *__restrict__ dst) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;      // one float4 per thread
+    if (t >= nfrag * 64) return;
+    const long long p = t >> 6;
+    const int lane = (int)(t & 63);
+    const int NI = 4 * NO1, PER = NT0 + NI, TOT = NO0 * PER, NG1 = 4 * NO0, NG2 = 4 * NO1;
+    const float4 *f0 = reinterpret_cast<const float4 *>(packed + off0 + NO0 * 32);
+    const float4 *f1 = reinterpret_cast<const float4 *>(packed + off1 + NO1 * 32);
+    const float4 *f2 = reinterpret_cast<const float4 *>(packed + off2 + NO2 * 32);
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p < TOT) {
+        const int o = (int)(p / PER), r = (int)(p % PER);
+        if (r < NT0) v = f0[(long long)(o * NT0 + r) * 64 + lane];
+        else {
+            const int i = r - NT0;
+            v = f1[(long long)((i >> 2) * NG1 + 4 * o + (i & 3)) * 64 + lane];
+        }
+    } else if (p < TOT + (long long)NO2 * NG2) {
+        v = f2[(p - TOT) * 64 + lane];
+    }
+    reinterpret_cast<float4 *>(dst)[t] = v;
+}
+
 __global__ __launch_bounds__(256) void transpose_kernel(const float *__restrict__ Wm, int Cout, int Cin,
                                                         float *__restrict__ Wt) {
     const int t = blockIdx.x * 256 + threadIdx.x;
@@ -924,6 +951,8 @@ struct Geometry {
     long long off[MAXL];     // packed layer l: bias block then A fragments
     long long raw_w[MAXL];   // plain row-major copy W[l][C_out][C_in] (for the VALU kernel)
     long long raw_b[MAXL];
+    long long stream_off;    // stream image of the cooperative register-resident kernel (mlp_coop.hip), -1 = none
+    long long stream_frags;
     long long total;
 };
 
@@ -942,6 +971,18 @@ inline Geometry geometry(int L, const int *dims, int first_has_xyz) {
         off += round_up(dims[l] * dims[l + 1], 4);
         g.raw_b[l] = off;
         off += round_up(dims[l + 1], 4);
+    }
+    g.stream_off = -1;
+    g.stream_frags = 0;
+    if (first_has_xyz && L == 3) {
+        const int shape = sad::reg_shape_id(L, g.kp, g.np);
+        const long long nf = shape >= 0 ? sad::coop_stream_frags(shape, g.kp, g.np) : 0;
+        if (nf > 0) {
+            off = (off + 63) / 64 * 64;       // 256-byte aligned
+            g.stream_off = off;
+            g.stream_frags = nf;
+            off += nf * 256;
+        }
     }
     g.total = off;
     return g;
@@ -987,6 +1028,11 @@ SAD_API int sad_mlp_pack_f32(int L, const int *dims, int first_has_xyz, const fl
         if (hipMemcpyAsync(packed + g.raw_b[l], bias[l], sizeof(float) * dims[l + 1],
                            hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess)
             return sad::fail(SAD_ELAUNCH, "sad_mlp_pack_f32: device copy of layer %d failed", l);
+    }
+    if (g.stream_off >= 0) {
+        const long long n4 = g.stream_frags * 64;
+        hipLaunchKernelGGL(stream_pack_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, packed, g.off[0], g.off[1],
+                           g.off[2], g.kp[0] / 8, g.np[0] / 32, g.np[1] / 32, g.np[2] / 32, g.stream_frags, packed + g.stream_off);
     }
     return sad::check_launch("sad_mlp_pack_f32");
 }
@@ -1069,6 +1115,7 @@ struct Prepared {
     int W, RW, CW;
     bool launched;      // the VALU kernel was launched instead (nothing left to do)
     bool reg;           // geometry 2: register-resident chain kernel (csrc/mlp_reg.hip); `rc` is filled, p is not
+    bool coop;          // ... geometry 4: its cooperative variant (csrc/mlp_coop.hip)
     sad::RegChain rc;
     sad::ScanJob scan;  // row-packing scan this chain needs before its kernel
     bool prescanned;    // ... unless the caller already ran sad_mlp_rowscan on the workspace
@@ -1087,6 +1134,7 @@ int launch_prepared(const Prepared &q, hipStream_t st);
 static int prepare_chain(const sad_mlp_args *a, sad_stream_t stream, Prepared &q) {
     q.launched = false;
     q.reg = false;
+    q.coop = false;
     q.layered = false;
     q.prescanned = a && a->prescanned != 0;
     SAD_REQUIRE(a, "sad_mlp_chain_f32: NULL args");
@@ -1150,8 +1198,10 @@ static int prepare_chain(const sad_mlp_args *a, sad_stream_t stream, Prepared &q
         p.cpr = 0; p.cshift = 0;
     }
     // ---- geometry 2: register-resident chain (one wave per 32-row tile, no LDS round trips, no barriers) ----
-    if (geom_wg == 2) {
+    if (geom_wg == 2 || geom_wg == 4) {
         const int shape = grouped ? sad::reg_shape_id(a->L, g.kp, g.np) : -1;
+        if (geom_wg == 4 && (shape < 0 || !sad::coop_shape(shape) || g.stream_off < 0 || p.cpr <= 0))
+            return sad::fail(SAD_EUNSUPPORTED, "sad_mlp_chain_f32: geometry 4 (cooperative register-resident chain) is compiled for the SA2 / SA3 shapes");
         const bool all_relu = (a->relu_mask & ((1 << a->L) - 1)) == (1 << a->L) - 1;
         const bool feat_ok = a->C == 0 || a->C == 1 || p.cpr > 0;
         if (shape < 0 || !all_relu || !feat_ok || !a->cnt || !a->workspace)
@@ -1168,6 +1218,8 @@ static int prepare_chain(const sad_mlp_args *a, sad_stream_t stream, Prepared &q
         rc.row_src = tab + 4 + (p.total_groups + 1) + (p.total_groups * a->S / 32 + 2) + (p.total_groups / 1024 + 2);
         rc.row_gid = rc.row_src + p.total_groups * a->S;
         for (int l = 0; l < 3; ++l) { rc.off[l] = g.off[l]; rc.np[l] = g.np[l]; }
+        rc.stream_off = g.stream_off;
+        q.coop = geom_wg == 4;
         rc.ld_feat = a->ld_feat; rc.C = a->C; rc.cpr = p.cpr;
         rc.ld_out = a->ld_out; rc.col_off = a->col_off; rc.cout_last = cout; rc.vec_out = p.vec_out;
         q.reg = true;
@@ -1433,7 +1485,7 @@ int launch_reg_chains(const Prepared *const *qs, int n, hipStream_t st) {
         mp.max_tiles += qs[i]->reg_tiles;
     }
     mp.counter = const_cast<int *>(mp.c[0].rowtab) + 2;      // zeroed by chain 0's rowscan
-    return sad::launch_reg(mp, st);
+    return qs[0]->coop ? sad::launch_coop(mp, st) : sad::launch_reg(mp, st);
 }
 
 // Layer-streamed chains (one or two with the same number of layers): counters zeroed, one scan, then one
@@ -1514,7 +1566,7 @@ SAD_API int sad_mlp_chain_multi_f32(const sad_mlp_args *const *args, int n, sad_
     // register-resident chains of one shape family: one dispatch, tiles of the heaviest chain first
     {
         bool all_reg = n > 1 && n <= sad::REG_MAX_CHAINS;
-        for (int i = 0; i < n; ++i) all_reg = all_reg && q[i].reg && sad::reg_family(q[i].reg_shape) == sad::reg_family(q[0].reg_shape);
+        for (int i = 0; i < n; ++i) all_reg = all_reg && q[i].reg && q[i].coop == q[0].coop && sad::reg_family(q[i].reg_shape) == sad::reg_family(q[0].reg_shape);
         if (all_reg) {
             const Prepared *ord[MULTI_MAX];
             for (int i = 0; i < n; ++i) ord[i] = &q[i];

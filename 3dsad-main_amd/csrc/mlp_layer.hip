@@ -46,7 +46,10 @@ __device__ __forceinline__ f32x16 mma4(f32x16 acc, const float4 a, const float *
 }
 template <int CTRL, int ROWMASK>
 __device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, ROWMASK, 0xF, true); }
-struct PoolMasks { int m[5]; };
+struct PoolMasks {
+    int m[5];
+    bool any[5];     // (wave-uniform) some lane takes part in step k; a step nobody takes part in is skipped (identity)
+};
 __device__ __forceinline__ PoolMasks pool_masks(int key) {
     PoolMasks pm;
     pm.m[0] = dpp_i<0x111, 0xF>(key) == key ? -1 : 0;
@@ -54,6 +57,8 @@ __device__ __forceinline__ PoolMasks pool_masks(int key) {
     pm.m[2] = dpp_i<0x114, 0xF>(key) == key ? -1 : 0;
     pm.m[3] = dpp_i<0x118, 0xF>(key) == key ? -1 : 0;
     pm.m[4] = dpp_i<0x142, 0xA>(key) == key ? -1 : 0;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) pm.any[k] = __ballot(pm.m[k] != 0) != 0;
     return pm;
 }
 // segmented inclusive max-scan over the 32 rows (values >= 0), all 16 registers step by step (see mlp_reg.hip)
@@ -65,9 +70,11 @@ __device__ __forceinline__ f32x16 seg_max16(f32x16 t, const PoolMasks &pm) {
         x[g] = __builtin_bit_cast(int, f);
     }
 #define SAD_STEP(CTRL, RM, K)                                       \
-    _Pragma("unroll") for (int g = 0; g < 16; ++g) {                \
-        const int u = dpp_i<CTRL, RM>(x[g]) & pm.m[K];              \
-        x[g] = u > x[g] ? u : x[g];                                 \
+    if (pm.any[K]) {                                                \
+        _Pragma("unroll") for (int g = 0; g < 16; ++g) {            \
+            const int u = dpp_i<CTRL, RM>(x[g]) & pm.m[K];          \
+            x[g] = u > x[g] ? u : x[g];                             \
+        }                                                           \
     }
     SAD_STEP(0x111, 0xF, 0)
     SAD_STEP(0x112, 0xF, 1)

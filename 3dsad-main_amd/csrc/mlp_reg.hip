@@ -34,8 +34,8 @@
 
 namespace {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-constexpr int WHOLE_BIT = 1 << 30;
+#include "reg_common.h"
+
 #ifndef SAD_REG_RING
 #define SAD_REG_RING 4
 #endif
@@ -50,8 +50,6 @@ constexpr int RING = SAD_REG_RING;   // weight fragments in flight per wave
 constexpr int RING2 = SAD_REG_RING2;
 constexpr int WAVES = 4;         // waves per workgroup (independent; they only share the bias copy)
 
-using sad::RegChain;
-using sad::RegMulti;
 
 #ifdef SAD_REG_STAMPS    // measurement build only (tools/probe/reg_stamps.py): s_memtime at the phase boundaries of a tile
 __device__ unsigned long long g_stamps[64 * 64];
@@ -64,26 +62,6 @@ __device__ unsigned long long g_stamps[64 * 64];
 #define SAD_STAMP(i)
 #endif
 
-struct Swapped { float lo, hi; };
-// lanes 32-63 of `a` <-> lanes 0-31 of `b`:  lo = (a.lo | b.lo), hi = (a.hi | b.hi) read as (lanes 0-31 | lanes 32-63)
-__device__ __forceinline__ Swapped swap32(float a, float b) {
-    const auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b), false, false);
-    // (copy the elements out first: __builtin_bit_cast applied to r[1] directly reads element 0 with this hipcc)
-    const unsigned r0 = r[0], r1 = r[1];
-    return {__builtin_bit_cast(float, r0), __builtin_bit_cast(float, r1)};
-}
-
-// (c0..c3 on lanes 0-31 | c4..c7 on lanes 32-63) in v[0..3]  ->  B operands of the four MFMAs of the k-group:
-// out[e] = (c_{2e} | c_{2e+1})
-__device__ __forceinline__ void to_operands(float v0, float v1, float v2, float v3, float *out) {
-    const Swapped s01 = swap32(v0, v1);   // (c0|c1), (c4|c5)
-    const Swapped s23 = swap32(v2, v3);   // (c2|c3), (c6|c7)
-    out[0] = s01.lo;
-    out[1] = s23.lo;
-    out[2] = s01.hi;
-    out[3] = s23.hi;
-}
-
 // A-fragment array of one layer: fragment k (64 lanes x 16 B) at base[k * 64 + lane], base wave-uniform
 struct Frags {
     const float4 *__restrict__ base;
@@ -91,14 +69,6 @@ struct Frags {
     __device__ __forceinline__ float4 operator()(int k) const { return (base + (size_t)k * 64)[lane]; }   // scalar add, then the lane slot
     __device__ __forceinline__ Frags at(int k) const { return Frags{base + (size_t)k * 64, lane}; }
 };
-
-__device__ __forceinline__ f32x16 mma4(f32x16 acc, const float4 a, const float *b) {
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b[0], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b[1], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b[2], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b[3], acc, 0, 0, 0);
-    return acc;
-}
 
 // acc += W[oc tile, 0 : 8*NT] * X, X given as NT*4 operand registers.  af: this lane's first fragment
 // (consecutive k-groups are 64 float4 apart).
@@ -138,160 +108,6 @@ __device__ __forceinline__ f32x16 ktile_lds(f32x16 acc, const Frags af, const fl
         __builtin_amdgcn_sched_barrier(0);
     }
     return acc;
-}
-
-__device__ __forceinline__ f32x16 bias_tile(const float *sb, int h) {   // sb: 32 biases of the tile (LDS)
-    f32x16 t;
-#pragma unroll
-    for (int a = 0; a < 4; ++a) {
-        const float4 bv = *reinterpret_cast<const float4 *>(sb + 8 * a + 4 * h);
-        t[4 * a + 0] = bv.x; t[4 * a + 1] = bv.y; t[4 * a + 2] = bv.z; t[4 * a + 3] = bv.w;
-    }
-    return t;
-}
-
-__device__ __forceinline__ f32x16 relu16(f32x16 t) {
-#pragma unroll
-    for (int g = 0; g < 16; ++g) t[g] = t[g] > 0.f ? t[g] : 0.f;
-    return t;
-}
-
-template <int CTRL, int ROWMASK>
-__device__ __forceinline__ int dpp_i(int v) {
-    return __builtin_amdgcn_update_dpp(0, v, CTRL, ROWMASK, 0xF, true);   // out-of-range / masked rows read 0
-}
-
-// Segmented inclusive max-scan over the 32 rows (lanes j = 0..31 of each half) for values >= 0:
-// m[st] = all-ones where lane j - 2^st lies in the same 16-lane DPP row AND the same group, m[4] = all-ones
-// on the upper 16 lanes whose group continues from lane 15 of the lower 16.
-struct PoolMasks { int m[5]; };
-
-__device__ __forceinline__ PoolMasks pool_masks(int key) {   // key >= 1 for live rows, 0 for rows past the end
-    PoolMasks pm;
-    pm.m[0] = dpp_i<0x111, 0xF>(key) == key ? -1 : 0;   // row_shr:1
-    pm.m[1] = dpp_i<0x112, 0xF>(key) == key ? -1 : 0;   // row_shr:2
-    pm.m[2] = dpp_i<0x114, 0xF>(key) == key ? -1 : 0;   // row_shr:4
-    pm.m[3] = dpp_i<0x118, 0xF>(key) == key ? -1 : 0;   // row_shr:8
-    pm.m[4] = dpp_i<0x142, 0xA>(key) == key ? -1 : 0;   // row_bcast:15 into DPP rows 1 and 3 (rows 0, 2 read 0)
-    return pm;
-}
-
-// All 16 registers of a tile at once, step by step: consecutive instructions are independent, so the DPP
-// read-after-write wait states are covered by the other registers' work (a register-by-register scan is a
-// chain of ten dependent instructions per register: ~4000 cycles per tile instead of ~700).
-__device__ __forceinline__ f32x16 seg_max16(f32x16 t, const PoolMasks &pm) {
-    int x[16];
-#pragma unroll
-    for (int g = 0; g < 16; ++g) {
-        const float f = t[g];          // (copy first: __builtin_bit_cast on a vector element reads element 0 with this hipcc)
-        x[g] = __builtin_bit_cast(int, f);
-    }
-    // (values are >= +0: their bit patterns order like integers and 0 is the neutral element)
-#define SAD_STEP(CTRL, RM, K)                                       \
-    _Pragma("unroll") for (int g = 0; g < 16; ++g) {                \
-        const int u = dpp_i<CTRL, RM>(x[g]) & pm.m[K];              \
-        x[g] = u > x[g] ? u : x[g];                                 \
-    }
-    SAD_STEP(0x111, 0xF, 0)
-    SAD_STEP(0x112, 0xF, 1)
-    SAD_STEP(0x114, 0xF, 2)
-    SAD_STEP(0x118, 0xF, 3)
-    SAD_STEP(0x142, 0xA, 4)
-#undef SAD_STEP
-#pragma unroll
-    for (int g = 0; g < 16; ++g) t[g] = __builtin_bit_cast(float, x[g]);
-    return t;
-}
-
-__device__ __forceinline__ void atomic_max_pos(float *addr, float v) {
-    atomicMax(reinterpret_cast<unsigned *>(addr), __builtin_bit_cast(unsigned, v));
-}
-
-// max-pool of one finished 32-channel tile over the rows of each group + store (whole groups) / atomic max (groups
-// that continue in another tile; outputs are >= 0 and the buffer starts at zero)
-__device__ __forceinline__ void pool_store(f32x16 t, const PoolMasks &pm, bool tail, bool whole, float *orow, int o, int h,
-                                           const RegChain &c) {
-#ifdef SAD_REG_NOPOOL       // measurement build: no pooling, one store per tile keeps the chain alive
-    if (t[0] == 123.f) orow[0] = t[0];
-    return;
-#endif
-    t = seg_max16(t, pm);
-#ifdef SAD_REG_NOSTORE      // measurement build: pooling arithmetic only
-    {
-        float s = 0.f;
-#pragma unroll
-        for (int g = 0; g < 16; ++g) s += t[g];
-        if (s == 123.456f) orow[0] = s;
-        return;
-    }
-#endif
-#ifdef SAD_REG_NOATOMIC     // measurement build: plain stores where the product merges with an atomic max (wrong results)
-    whole = true;
-#endif
-    if (tail) {
-#pragma unroll
-        for (int a = 0; a < 4; ++a) {
-            const int ch = o * 32 + 8 * a + 4 * h;
-            if (whole && c.vec_out && ch + 3 < c.cout_last) {
-                *reinterpret_cast<float4 *>(orow + ch) = make_float4(t[4 * a], t[4 * a + 1], t[4 * a + 2], t[4 * a + 3]);
-            } else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    if (ch + e >= c.cout_last) continue;
-                    if (whole) orow[ch + e] = t[4 * a + e];
-                    else atomic_max_pos(orow + ch + e, t[4 * a + e]);
-                }
-            }
-        }
-    }
-}
-
-// Staged output.  A tile's pooled results are first collected in the wave's LDS (slot = ordinal of the group
-// inside the tile, COUT floats per slot) and written out when the tile is complete: one coalesced store per
-// whole group, or COUT / 64 atomic-max instructions of 256 contiguous bytes for a group that continues in
-// another tile — instead of 4 stores + 16 scattered single-lane atomics per 32-channel tile (measured on
-// sa3.b2: the scattered atomics alone were 10 % of the kernel; a wave stalls once ~16 of them are in flight).
-struct Stage {
-    float *lds;          // [slots][COUT] of this wave, or nullptr: direct stores (more groups in the tile than slots)
-    int slot;            // this lane's group ordinal inside the tile
-    unsigned tails;      // bit j: lane j holds the last row of its group in this tile
-    int ngroups;
-};
-
-template <int COUT>
-__device__ __forceinline__ void pool_stage(f32x16 t, const PoolMasks &pm, bool tail, const Stage &sg, int o, int h) {
-    t = seg_max16(t, pm);
-    if (tail) {
-        float *d = sg.lds + sg.slot * COUT + o * 32 + 4 * h;
-#pragma unroll
-        for (int a = 0; a < 4; ++a)
-            *reinterpret_cast<float4 *>(d + 8 * a) = make_float4(t[4 * a], t[4 * a + 1], t[4 * a + 2], t[4 * a + 3]);
-    }
-}
-
-template <int COUT>
-__device__ __forceinline__ void stage_flush(const Stage &sg, int grp, bool whole, int lane, const RegChain &c) {
-    unsigned rem = sg.tails;
-    for (int s = 0; s < sg.ngroups; ++s) {                 // wave-uniform loop over the groups that end in this tile
-        const int p = __builtin_ctz(rem);
-        rem &= rem - 1;
-        const int g = __builtin_amdgcn_readlane(grp, p);
-        const bool w = __builtin_amdgcn_readlane((int)whole, p) != 0;
-        float *orow = c.out + (long long)g * c.ld_out + c.col_off;
-        const float *src = sg.lds + s * COUT;
-        if (w && c.vec_out && COUT == c.cout_last) {
-            if (lane * 4 < COUT) *reinterpret_cast<float4 *>(orow + lane * 4) = *reinterpret_cast<const float4 *>(src + lane * 4);
-        } else {
-#pragma unroll
-            for (int k = 0; k < (COUT + 63) / 64; ++k) {
-                const int ch = lane + 64 * k;
-                if (ch < COUT && ch < c.cout_last) {
-                    if (w) orow[ch] = src[ch];
-                    else atomic_max_pos(orow + ch, src[ch]);
-                }
-            }
-        }
-    }
 }
 
 // One tile of 32 packed rows through a 3-layer chain.

@@ -398,13 +398,14 @@ class PackedMLP:
     def _tune(self, a: MlpArgs) -> int:
         stream = torch.cuda.current_stream()
         best, best_ms = 0, None
-        # 1 = VALU row-per-lane kernel (narrow chains), 2 = register-resident chain kernel (csrc/mlp_reg.hip)
-        for code in self._CANDIDATES + ([1, 2, 3] if a.idx else ([3] if self._layered_ok else [])):
+        # 1 = VALU row-per-lane kernel (narrow chains), 2 = register-resident chain kernel (csrc/mlp_reg.hip),
+        # 3 = layer-streamed chain (csrc/mlp_layer.hip), 4 = cooperative register-resident chain (csrc/mlp_coop.hip)
+        for code in self._CANDIDATES + ([1, 2, 3, 4] if a.idx else ([3] if self._layered_ok else [])):
             a.geometry = code
             ms = self._time(a, stream)
             if ms is not None and (best_ms is None or ms < best_ms * 0.98):   # prefer earlier entries on ties
                 best, best_ms = code, ms
-        if a.idx and best > 3:   # second sweep: groups per workgroup (how much padding is expected)
+        if a.idx and best > 4:   # second sweep: groups per workgroup (how much padding is expected)
             base = best
             for f in self._F_CODES:
                 a.geometry = base + 1000 * f
@@ -615,7 +616,7 @@ def _tune_stage(calls) -> None:
 
     picked = [c[0]._geom.get(k) or 0 for c, k in zip(calls, keys)]
     best, t_best = picked, run(picked)
-    for code in (2, 3):              # the two kernels whose chains share launches: register-resident, layer-streamed
+    for code in (2, 3, 4):           # the kernels whose chains share launches: register-resident, layer-streamed, cooperative
         if all(p == code for p in picked):
             continue
         t = run([code] * len(calls))

@@ -189,14 +189,19 @@ typedef struct sad_mlp_args {
      *   1 = row-per-lane vector-ALU kernel (two narrow SA1 shapes);
      *   2 = register-resident chain: one wave carries a 32-row tile through a 3-layer chain in registers
      *       (compiled shapes: the SA stages of the KITTI / nuScenes topology and BASELINE configs[0]);
-     *   3 = layer-streamed chain: one launch per layer, (32-row tile x 128 output channels) work items,
-     *       activations between layers in `scratch` (wide chains with few rows: the cluster layer). */
+     *   3 = layer-streamed chain: one launch per layer, (128 rows x 128 output channels) work items,
+     *       activations between layers in `scratch` (wide chains with few rows: the cluster layer); also
+     *       on plain rows (idx == NULL) when C % 8 == 0 and every width, C_out included, is a multiple of 128;
+     *   4 = cooperative register-resident chain: as 2, but the four waves of a workgroup walk four tiles
+     *       through the chain in lockstep and share the weight stream through an LDS ring (one global load per
+     *       16 MFMAs instead of one per 4; compiled for the SA2 / SA3 shapes 67 -> 64 -> {64,96} -> 128 and
+     *       131 -> 128 -> {128,192,256} -> 256). */
     int geometry;
     /* geometry 3 only: sad_mlp_scratch_bytes(B, M, S, L, dims) bytes of 16-byte aligned device scratch */
     void *scratch;
     size_t scratch_bytes;
-    /* != 0: `workspace` already holds the row-packing table of (cnt, idx) from sad_mlp_rowscan (geometries 2
-     * and 3 only): the chain launches no scan of its own.  The scan needs coordinates-side data only, so a
+    /* != 0: `workspace` already holds the row-packing table of (cnt, idx) from sad_mlp_rowscan (geometries 2,
+     * 3 and 4 only): the chain launches no scan of its own.  The scan needs coordinates-side data only, so a
      * caller can run it right behind the ball query on another stream, off the MLP stream's critical path. */
     int prescanned;
 } sad_mlp_args;

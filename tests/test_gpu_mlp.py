@@ -474,6 +474,76 @@ def test_register_chain_kernel_parity(orc, sad, dev, B, N, M, S, C, mlp, r):
     assert np.array_equal(dense, want), "padding skip off: different result"
 
 
+COOP_CASES = [
+    # (B, N, M, S, C, mlp, radius) — geometry 4: the cooperative register-resident chain (SA3 and SA2 shapes)
+    (2, 1024, 300, 32, 128, [128, 128, 256], 0.3),
+    (2, 1024, 300, 32, 128, [128, 192, 256], 0.5),
+    (2, 1024, 300, 32, 128, [128, 256, 256], 0.7),
+    (1, 300, 7, 16, 128, [128, 256, 256], 0.2),       # fewer rows than one work item (dummy waves)
+    (3, 2048, 512, 32, 128, [128, 128, 256], 0.9),    # full groups: many tiles per workgroup
+    (2, 2000, 400, 32, 64, [64, 64, 128], 0.2),       # SA2
+    (2, 2000, 400, 64, 64, [64, 96, 128], 0.35),      # SA2, layer-2 tiles of 12 k-groups (not whole stages)
+    (1, 500, 40, 32, 64, [64, 96, 128], 0.9),
+]
+
+
+@pytest.mark.parametrize("B,N,M,S,C,mlp,r", COOP_CASES)
+def test_cooperative_chain_kernel_parity(orc, sad, dev, B, N, M, S, C, mlp, r):
+    """geometry 4 = four waves carry four tiles through the chain in registers and share the weight stream through
+    an LDS ring (csrc/mlp_coop.hip): bit-identical to the oracle and to the tiled kernel, alone, with the padding
+    skip off, and as the merged three-chain dispatch of a stage."""
+    import torch
+    from sad_amd import _lib, ops, synth
+    rng = np.random.default_rng(N + M + S + C + sum(mlp))
+    xyz = rng.uniform(0, 1, (B, N, 3)).astype(np.float32)
+    feat = rng.normal(size=(B, N, C)).astype(np.float32)
+    new_xyz = np.ascontiguousarray(xyz[:, :M])
+    X, F, Cn = _t(xyz, dev), _t(feat, dev), _t(new_xyz, dev)
+    idxs, cnts = ops.ball_query_multi((r,), (S,), X, Cn, return_counts=True)
+    layers = synth.make_mlp_weights([C + 3] + mlp, rng)
+    want = orc.sa_group_mlp_max(xyz, feat, new_xyz, idxs[0].cpu().numpy(), layers)
+    net = ops.PackedMLP(layers, True, dev)
+    net.default_geometry = 4
+    got = net.grouped(X, F, Cn, idxs[0], cnt=cnts[0]).cpu().numpy()
+    rows = int(cnts[0].clamp(min=1).sum().item())
+    print(f"[parity] cooperative chain {[C + 3] + mlp} S={S}: {rows} packed rows, bit-exact={np.array_equal(got, want)}")
+    assert np.array_equal(got, want), f"max diff {np.abs(got - want).max():.3e}"
+    _lib.set_option("mlp_nodedup", 1)
+    try:
+        dense = net.grouped(X, F, Cn, idxs[0], cnt=cnts[0]).cpu().numpy()
+    finally:
+        _lib.set_option("mlp_nodedup", 0)
+    assert np.array_equal(dense, want), "padding skip off: different result"
+
+
+def test_cooperative_three_chain_dispatch(orc, sad, dev):
+    """The three SA3 branches as ONE cooperative dispatch (sad_mlp_chain_multi_f32): chains of different shapes
+    follow each other in a workgroup's item list, the ring carries over from one chain's stream to the next."""
+    import torch
+    from sad_amd import ops, synth
+    rng = np.random.default_rng(77)
+    B, N, M, C = 2, 1024, 384, 128
+    xyz = rng.uniform(0, 1, (B, N, 3)).astype(np.float32)
+    feat = rng.normal(size=(B, N, C)).astype(np.float32)
+    new_xyz = np.ascontiguousarray(xyz[:, :M])
+    X, F, Cn = _t(xyz, dev), _t(feat, dev), _t(new_xyz, dev)
+    radii, ns = (0.2, 0.35, 0.5), (32, 32, 32)
+    mlps = ([128, 128, 256], [128, 192, 256], [128, 256, 256])
+    idxs, cnts = ops.ball_query_multi(radii, ns, X, Cn, return_counts=True)
+    out = torch.zeros((B, M, 768), device=dev)
+    calls, wants = [], []
+    for bi, mlp in enumerate(mlps):
+        layers = synth.make_mlp_weights([C + 3] + mlp, rng)
+        net = ops.PackedMLP(layers, True, dev)
+        net.default_geometry = 4
+        calls.append((net, X, F, Cn, idxs[bi], out, 256 * bi, cnts[bi]))
+        wants.append(orc.sa_group_mlp_max(xyz, feat, new_xyz, idxs[bi].cpu().numpy(), layers))
+    ops.grouped_multi(calls)
+    got = out.cpu().numpy()
+    for bi in range(3):
+        assert np.array_equal(got[:, :, 256 * bi:256 * (bi + 1)], wants[bi]), f"branch {bi}"
+
+
 def test_register_chain_refuses_other_shapes(orc, sad, dev):
     """A chain without a compiled shape is refused with SAD_EUNSUPPORTED (autotuners skip it), never wrong."""
     from sad_amd import _lib, ops, synth
