@@ -27,6 +27,9 @@ def _stream() -> int:
 # C-ABI call with HIP events recorded on the stream the kernel is launched on and appends
 # (kind, name, start_event, end_event).  None (the default) adds nothing to the launch path.
 LAUNCH_LOG: Optional[list] = None
+# When a list, every f32 MLP dispatch appends (name, fn): fn() enqueues the SAME dispatch again (same arguments; the
+# tensors it reads are kept alive by the entry).  bench.py re-times the dispatches of a step back to back with it.
+RERUN_LOG: Optional[list] = None
 
 # ball_query_multi uses the grid-pruned kernel for scenes with at least this many points (scalar
 # radii only); below it the brute-force scan is already cheap.  Set very large to force brute force.
@@ -364,7 +367,7 @@ class PackedMLP:
     # +100000 flexible item distribution, +200000 two output tiles per wave, +300000 both
     _F_CODES = (2, 4, 5, 6)      # grouped mode: 2^f * R / S groups per workgroup (default f = 3)
 
-    def _launch(self, a: MlpArgs) -> None:
+    def _launch(self, a: MlpArgs, keep=None) -> None:
         """Enqueue the chain.  With AUTOTUNE on, the first call for a shape times every workgroup
         geometry that fits (a few ms, synchronous) and the fastest one is reused afterwards."""
         key = (bool(a.idx), a.B, a.N, a.M, a.S, a.ld_out)
@@ -375,6 +378,9 @@ class PackedMLP:
         a.geometry = geom or self.default_geometry
         with _timed("mlp", self.name):
             check(lib().sad_mlp_chain_f32(ctypes.byref(a), _stream()), "sad_mlp_chain_f32")
+        if RERUN_LOG is not None:
+            RERUN_LOG.append((self.name, lambda a=a, keep=keep: check(
+                lib().sad_mlp_chain_f32(ctypes.byref(a), _stream()), "sad_mlp_chain_f32")))
 
     def _time(self, a: MlpArgs, stream) -> Optional[float]:
         """ms per launch of the geometry in ``a`` (None if it does not fit): one warm launch, then the
@@ -442,7 +448,7 @@ class PackedMLP:
         with an atomic max).  Samples that repeat a group's first index are skipped.  ``ws``: the
         row-packing table of (idx, cnt) from ``rowscan_multi`` (else the chain scans the counts itself)."""
         a, out, _keep = self._grouped_args(xyz, feat_pm, new_xyz, idx, out, col_off, cnt, ws)
-        self._launch(a)
+        self._launch(a, _keep + [out])
         return out
 
     def _grouped_args(self, xyz, feat_pm, new_xyz, idx, out, col_off, cnt, ws=None):
@@ -529,7 +535,7 @@ class PackedMLP:
             nbytes = lib().sad_mlp_scratch_bytes(1, R, 1, self.L, dims_c)
             sc = torch.empty((nbytes,), dtype=torch.uint8, device=x.device)
             a.scratch, a.scratch_bytes = sc.data_ptr(), nbytes
-        self._launch(a)
+        self._launch(a, [x2, out, sc])
         return out
 
     def _check_out(self, out: torch.Tensor, rows: int, col_off: int) -> None:
@@ -578,6 +584,10 @@ def grouped_multi(calls) -> None:
         else:
             arr = (ctypes.POINTER(MlpArgs) * len(args))(*[ctypes.pointer(a) for a in args])
             check(lib().sad_mlp_chain_multi_f32(arr, len(args), _stream()), "sad_mlp_chain_multi_f32")
+            if RERUN_LOG is not None:
+                outs = [c[5] for c in calls]
+                RERUN_LOG.append(("+".join(c[0].name for c in calls), lambda arr=arr, args=args, keep=(keep, outs): check(
+                    lib().sad_mlp_chain_multi_f32(arr, len(args), _stream()), "sad_mlp_chain_multi_f32")))
 
 
 def _tune_stage(calls) -> None:

@@ -417,6 +417,41 @@ def main():
                                   "note": "the same launches in extra steps run exactly like the timed region (two main streams run "
                                           "consecutive batches side by side): intervals stretch (kernels share the chip) and their "
                                           "sum may exceed ms_per_step; not a kernel-quality figure"}}
+            # ---- the same dispatches back to back (f32): in the serial pass every step begins with ~3 ms of FPS on 32 of
+            # 256 CUs, the chip clocks down meanwhile and the MLP launches behind it run several % slower than the
+            # same launches at the clock the timed region holds (tools/insitu_probe.py) — so each dispatch of one
+            # serial step is enqueued again, 1 + 5 times in a row, and timed with one pair of events
+            if args.dtype == "f32":
+                det.overlap_fps, ov = False, det.overlap_fps
+                try:
+                    ops.RERUN_LOG = []
+                    det(points)
+                    torch.cuda.synchronize()
+                    reruns, ops.RERUN_LOG = ops.RERUN_LOG, None
+                finally:
+                    det.overlap_fps = ov
+                    ops.RERUN_LOG = None
+                steady = {}
+                cur = torch.cuda.current_stream()
+                for name, fn in reruns:
+                    fn()
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(cur)
+                    for _ in range(5):
+                        fn()
+                    e1.record(cur)
+                    torch.cuda.synchronize()
+                    steady[name] = steady.get(name, 0.0) + e0.elapsed_time(e1) / 5
+                del reruns
+                st_ms = sum(steady.values())
+                res["roofline"]["steady_clock"] = {
+                    "ms_per_step": round(st_ms, 3), "achieved": round(exec_flops / (st_ms * 1e-3) / 1e12, 2),
+                    "frac": round(exec_flops / (st_ms * 1e-3) / 1e12 / PEAK, 4),
+                    "per_launch_ms": {n: round(v, 4) for n, v in sorted(steady.items())},
+                    "note": "the same dispatches (same arguments, from one more serial step), each enqueued 5 times in a row: "
+                            "durations at the clock a continuously busy chip holds.  In the serial pass above every step starts with "
+                            "~3 ms of FPS on 32 CUs and the MLP launches behind it run at a lower clock; the timed region (two "
+                            "main streams, FPS overlapped) is continuously busy.  `frac` above stays the in-step figure"}
             kern = []
             fps_ms = ser_kind.get("fps", 0.0)
             if fps_ms > 0:
