@@ -46,9 +46,15 @@ __device__ __forceinline__ f32x16 bias_tile(const float *sb, int h) {   // sb: 3
     return t;
 }
 
+// x > 0 ? x : 0 as ONE v_max_f32 per register (a NaN gives 0 like the comparison does): written as `x > 0 ? x : 0`
+// the compiler emits a canonicalising v_max_f32 v, v, v in front of it, 16 more vector-ALU operations per tile
 __device__ __forceinline__ f32x16 relu16(f32x16 t) {
 #pragma unroll
-    for (int g = 0; g < 16; ++g) t[g] = t[g] > 0.f ? t[g] : 0.f;
+    for (int g = 0; g < 16; ++g) {
+        float x = t[g], y;
+        asm("v_max_f32 %0, 0, %1" : "=v"(y) : "v"(x));
+        t[g] = y;
+    }
     return t;
 }
 
@@ -61,19 +67,19 @@ __device__ __forceinline__ int dpp_i(int v) {
 // m[st] = all-ones where lane j - 2^st lies in the same 16-lane DPP row AND the same group, m[4] = all-ones
 // on the upper 16 lanes whose group continues from lane 15 of the lower 16.
 struct PoolMasks {
-    int m[5];
-    bool any[5];     // (wave-uniform) some lane takes part in step k: a step whose masks are all zero is the identity and is skipped
+    bool m[5];       // this lane takes part in step k
+    bool any[5];     // (wave-uniform) some lane takes part in step k: a step nobody takes part in is the identity and is skipped
 };
 
 __device__ __forceinline__ PoolMasks pool_masks(int key) {   // key >= 1 for live rows, 0 for rows past the end
     PoolMasks pm;
-    pm.m[0] = dpp_i<0x111, 0xF>(key) == key ? -1 : 0;   // row_shr:1
-    pm.m[1] = dpp_i<0x112, 0xF>(key) == key ? -1 : 0;   // row_shr:2
-    pm.m[2] = dpp_i<0x114, 0xF>(key) == key ? -1 : 0;   // row_shr:4
-    pm.m[3] = dpp_i<0x118, 0xF>(key) == key ? -1 : 0;   // row_shr:8
-    pm.m[4] = dpp_i<0x142, 0xA>(key) == key ? -1 : 0;   // row_bcast:15 into DPP rows 1 and 3 (rows 0, 2 read 0)
+    pm.m[0] = dpp_i<0x111, 0xF>(key) == key;   // row_shr:1
+    pm.m[1] = dpp_i<0x112, 0xF>(key) == key;   // row_shr:2
+    pm.m[2] = dpp_i<0x114, 0xF>(key) == key;   // row_shr:4
+    pm.m[3] = dpp_i<0x118, 0xF>(key) == key;   // row_shr:8
+    pm.m[4] = dpp_i<0x142, 0xA>(key) == key;   // row_bcast:15 into DPP rows 1 and 3 (rows 0, 2 read 0)
 #pragma unroll
-    for (int k = 0; k < 5; ++k) pm.any[k] = __ballot(pm.m[k] != 0) != 0;   // groups of one or two rows need no or one step
+    for (int k = 0; k < 5; ++k) pm.any[k] = __ballot(pm.m[k]) != 0;   // groups of one or two rows need no or one step
     return pm;
 }
 
@@ -81,19 +87,22 @@ __device__ __forceinline__ PoolMasks pool_masks(int key) {   // key >= 1 for liv
 // read-after-write wait states are covered by the other registers' work (a register-by-register scan is a
 // chain of ten dependent instructions per register: ~4000 cycles per tile instead of ~700).
 __device__ __forceinline__ f32x16 seg_max16(f32x16 t, const PoolMasks &pm) {
-    int x[16];
+    unsigned x[16];
 #pragma unroll
     for (int g = 0; g < 16; ++g) {
         const float f = t[g];          // (copy first: __builtin_bit_cast on a vector element reads element 0 with this hipcc)
-        x[g] = __builtin_bit_cast(int, f);
+        x[g] = __builtin_bit_cast(unsigned, f);
     }
-    // (values are >= +0: their bit patterns order like integers and 0 is the neutral element)
-#define SAD_STEP(CTRL, RM, K)                                       \
-    if (pm.any[K]) {                                                \
-        _Pragma("unroll") for (int g = 0; g < 16; ++g) {            \
-            const int u = dpp_i<CTRL, RM>(x[g]) & pm.m[K];          \
-            x[g] = u > x[g] ? u : x[g];                             \
-        }                                                           \
+    // (values are >= +0: their bit patterns order like unsigned integers and 0 is the neutral element, so a lane whose
+    // DPP source is out of range or masked reads 0 = "no change").  Written as max-then-select: two vector-ALU
+    // operations per register and step (v_max_u32_dpp + v_cndmask_b32); the and-then-max form compiled to three
+#define SAD_STEP(CTRL, RM, K)                                                   \
+    if (pm.any[K]) {                                                            \
+        _Pragma("unroll") for (int g = 0; g < 16; ++g) {                        \
+            const unsigned u = (unsigned)dpp_i<CTRL, RM>((int)x[g]);            \
+            const unsigned r = u > x[g] ? u : x[g];                             \
+            x[g] = pm.m[K] ? r : x[g];                                          \
+        }                                                                       \
     }
     SAD_STEP(0x111, 0xF, 0)
     SAD_STEP(0x112, 0xF, 1)
