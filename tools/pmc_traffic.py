@@ -3,7 +3,7 @@
 Units and corrections as /opt/skills/guides/MI355X_MICROARCH.md prescribes: both counters are in KiB... (see `note`)."""
 import csv, glob, json, os, sys
 root, out = sys.argv[1], sys.argv[2]
-MLP = ("mlp_reg_kernel", "mlp_layer_kernel", "mlp_chain_kernel", "mlp_chain2_kernel", "mlp_multi_kernel", "rowscan_")
+MLP = ("mlp_reg_kernel", "mlp_coop_kernel", "mlp_layer_kernel", "mlp_chain_kernel", "mlp_chain2_kernel", "mlp_multi_kernel", "rowscan_")
 def total(passname, counter):
     tot, steps = 0.0, 0
     for f in glob.glob(os.path.join(root, passname, "*", "*_counter_collection.csv")):
@@ -21,7 +21,7 @@ write, s2 = total("write", "WRITE_SIZE")
 # FETCH_SIZE / WRITE_SIZE are reported in kilobytes; on gfx950 FETCH_SIZE counts 32-byte requests as 64-byte units
 # halved, i.e. the raw value is doubled (MI355X_MICROARCH.md, HBM section) — same correction as in round 1
 res = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes, tools/pmc.sh: bench.py --geometry-file "
-                 "profiles/r02_geometry.json --main-streams 1 --steps 3 --warmup 1), summed over the MLP dispatches (mlp_reg / mlp_layer / "
+                 "profiles/r02_geometry.json --main-streams 1 --steps 3 --warmup 1), summed over the MLP dispatches (mlp_reg / mlp_coop / mlp_layer / "
                  "mlp_chain / mlp_multi kernels + their row-packing scans) and divided by the forward passes of the run; FETCH_SIZE doubled "
                  "per the gfx950 correction of MI355X_MICROARCH.md (HBM section); gather-width reads uncalibrated",
        "forward_passes": s1,
