@@ -373,7 +373,8 @@ def test_every_geometry_code_is_bit_identical(orc, sad, dev):
     codes = list(ops.PackedMLP._CANDIDATES)
     codes += [c + 1000 * f for c in (801, 811, 100811) for f in ops.PackedMLP._F_CODES]
     codes += [c + 10000 * d for c in (801, 821, 100821, 5811) for d in (1, 2)]
-    ran = 0
+    codes += [2, 4]        # register-resident chain and its cooperative variant (this chain is the SA2 shape 67 -> 64 -> 96 -> 128)
+    ran, special = 0, []
     try:
         for code in codes:
             _lib.set_option("mlp_force", code)
@@ -383,6 +384,8 @@ def test_every_geometry_code_is_bit_identical(orc, sad, dev):
                 assert "(-2)" in str(e), f"geometry {code}: {e}"      # SAD_EUNSUPPORTED only
                 continue
             assert np.array_equal(got, want), f"grouped geometry {code}: max diff {np.abs(got - want).max()}"
+            if code in (2, 4):
+                special.append(code)
             if code % 100000 < 1000:      # every wave-grid / flag code also on plain rows (f / packing codes are grouped-only)
                 try:
                     pg = pnet.rows(_t(rows, dev)).cpu().numpy()
@@ -393,6 +396,7 @@ def test_every_geometry_code_is_bit_identical(orc, sad, dev):
     finally:
         _lib.set_option("mlp_force", 0)
     assert ran >= 20, f"only {ran} geometries ran"
+    assert special == [2, 4], f"register-resident geometries that ran: {special}"
 
 
 @pytest.mark.parametrize("mlp", [[16, 16, 32], [32, 32, 64]])
@@ -553,12 +557,14 @@ def test_register_chain_refuses_other_shapes(orc, sad, dev):
     Cn = X[:, :50].contiguous()
     idxs, cnts = ops.ball_query_multi((0.3,), (16,), X, Cn, return_counts=True)
     net = ops.PackedMLP(synth.make_mlp_weights([3, 24, 40], rng), True, dev)
-    _lib.set_option("mlp_force", 2)
-    try:
-        with pytest.raises(RuntimeError, match=r"\(-2\)"):
-            net.grouped(X, None, Cn, idxs[0], cnt=cnts[0])
-    finally:
-        _lib.set_option("mlp_force", 0)
+    narrow = ops.PackedMLP(synth.make_mlp_weights([3, 16, 16, 32], rng), True, dev)   # an SA1 shape: geometry 2 yes, 4 no
+    for code, chain in ((2, net), (4, net), (4, narrow)):
+        _lib.set_option("mlp_force", code)
+        try:
+            with pytest.raises(RuntimeError, match=r"\(-2\)"):
+                chain.grouped(X, None, Cn, idxs[0], cnt=cnts[0])
+        finally:
+            _lib.set_option("mlp_force", 0)
 
 
 LAYERED_CASES = [
