@@ -45,7 +45,8 @@ struct RegMulti {
     RegChain c[REG_MAX_CHAINS];
     int shape[REG_MAX_CHAINS];
     int n;
-    int *counter;                  // zeroed work counter (tiles of all chains form one list)
+    int *counter;                  // zeroed item queues (see ItemQueue; tiles of all chains form one list)
+    int nq;                        // 8: one queue per XCD, 1: a single counter
     long long max_tiles;           // upper bound of the tile count (grid sizing)
 };
 // Layer-streamed chain kernel (csrc/mlp_layer.hip): one layer of one chain / one layer of up to two chains
@@ -66,7 +67,8 @@ struct LayerJob {
 struct LayerMulti {
     LayerJob j[2];
     int n;
-    int *counter;                  // zeroed work counter of this launch
+    int *counter;                  // zeroed item queues of this launch (see ItemQueue), NULL: static deal
+    int nq;
 };
 int launch_layers(const LayerMulti &lm, long long max_items, hipStream_t st);
 int reg_shape_id(int L, const int *kp, const int *np);   // -1: no compiled shape
@@ -105,6 +107,56 @@ inline int check_launch(const char *what) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(SAD_ELAUNCH, "%s: %s", what, hipGetErrorString(e));
     return SAD_OK;
+}
+
+// ---- work-item queues of the persistent MLP kernels (mlp_coop.hip, mlp_layer.hip) ------------------------------
+// Items are dealt dynamically: a static deal is ~1 % faster on an empty chip, but an FPS kernel of another stream (32
+// workgroups x 1024 threads for 2.8 ms) leaves room for fewer of these workgroups on its 32 CUs; the ones that do
+// not fit start when others finish, and with a static deal they still own a full share of the items (+40 % on the
+// SA3 dispatch, tools/fps_overlap_probe.py).  Returning atomics on ONE address are served at ~30 ns each chip-wide,
+// so there are eight queues, one per XCD: item i belongs to queue i % 8, a workgroup pulls from the queue of the XCD
+// it runs on (HW_REG_XCC_ID: correct under any placement) and, when that queue is empty, looks at the others
+// (plain loads first: a stale count is a smaller count, so a non-empty queue is never missed) — an XCD that received
+// no workgroup has its items taken by the rest.  Layout (ints, in the header of the row-packing table): q[0] the
+// single counter used when nq == 1 (small tables / grids), q[1] workgroups finished (the last one out re-arms
+// everything for the next launch), q[2 + 32 x] the counter of XCD x (one 128-byte line each).
+struct ItemQueue {
+    int *q;
+    int nq, own;
+};
+constexpr int ITEMQ_INTS = 2 + 32 * 8;     // ints behind `q` when nq == 8
+__device__ __forceinline__ ItemQueue itemq_init(int *q, int nq) {
+    unsigned xcc = 0;
+    if (nq == 8) asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    return ItemQueue{q, nq, (int)(xcc & 7u)};
+}
+__device__ __forceinline__ int *itemq_counter(const ItemQueue &Q, int x) { return Q.nq == 8 ? Q.q + 2 + 32 * x : Q.q; }
+__device__ __forceinline__ int itemq_item(const ItemQueue &Q, int x, int pos) { return Q.nq == 8 ? pos * 8 + x : pos; }
+// next item of the own queue (may be >= nitems: queue empty); returning atomic: issue it early, use it late
+__device__ __forceinline__ int itemq_pull(const ItemQueue &Q, int n = 1) { return atomicAdd(itemq_counter(Q, Q.own), n); }
+// the own queue is empty: an item of another queue, or `nitems`
+__device__ __forceinline__ int itemq_steal(const ItemQueue &Q, int nitems) {
+    if (Q.nq != 8) return nitems;
+    int seen[7];
+#pragma unroll
+    for (int k = 0; k < 7; ++k)      // (seven independent loads: one round trip, not seven)
+        seen[k] = __hip_atomic_load(itemq_counter(Q, (Q.own + 1 + k) & 7), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+        const int x = (Q.own + 1 + k) & 7;
+        if (itemq_item(Q, x, seen[k]) >= nitems) continue;
+        const int it = itemq_item(Q, x, atomicAdd(itemq_counter(Q, x), 1));
+        if (it < nitems) return it;
+    }
+    return nitems;
+}
+// one thread per workgroup, after its last pull has returned
+__device__ __forceinline__ void itemq_done(const ItemQueue &Q, int workgroups) {
+    if (atomicAdd(Q.q + 1, 1) != workgroups - 1) return;
+    Q.q[0] = 0;
+    Q.q[1] = 0;
+    if (Q.nq == 8)
+        for (int x = 0; x < 8; ++x) Q.q[2 + 32 * x] = 0;
 }
 
 // SPEC.md §1 — the one squared-distance expression every index decision uses.  The library is

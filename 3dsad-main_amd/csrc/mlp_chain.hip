@@ -310,7 +310,10 @@ __global__ __launch_bounds__(SCAN_T) void rowscan_write_kernel(const sad::ScanMu
         const int total = base + run + c;
         jb.tab[0] = total;
         jb.tab[1] = (total + jb.R - 1) / jb.R;
-        jb.tab[2] = 0;
+        jb.tab[2] = 0;                           // item queues of the kernels that deal items dynamically (common.h, ItemQueue;
+        jb.tab[3] = 0;                           // they re-arm them when they finish): single counter, finished workgroups,
+        if (jb.ngroups + 1 >= sad::ITEMQ_INTS)   // and one counter per XCD in the (otherwise unused) row_start area
+            for (int x = 0; x < 8; ++x) jb.tab[4 + 32 * x] = 0;
     }
     if (!jb.row_src) return;
     // row map of rows [base, base + blk_rows), by destination row
@@ -1485,6 +1488,7 @@ int launch_reg_chains(const Prepared *const *qs, int n, hipStream_t st) {
         mp.max_tiles += qs[i]->reg_tiles;
     }
     mp.counter = const_cast<int *>(mp.c[0].rowtab) + 2;      // zeroed by chain 0's rowscan
+    mp.nq = qs[0]->scan.ngroups + 1 >= sad::ITEMQ_INTS ? 8 : 1;
     return qs[0]->coop ? sad::launch_coop(mp, st) : sad::launch_reg(mp, st);
 }
 

@@ -30,6 +30,7 @@ constexpr int S = 8;                 // fragments per stage
 constexpr int NS = 3;                // ring slots (stages): being read / complete / being written
 constexpr int FPW = S / WAVES;       // fragments each wave fetches per stage
 constexpr int RING_F4 = NS * S * 64; // float4 in the ring
+// (work items are pulled from the per-XCD queues of common.h, one item ahead)
 // pooled-output staging per wave (floats): 8 slots of a tile's COUT channels (groups ending inside one tile)
 __host__ __device__ constexpr int pool_floats(int family) { return family == 2 ? 8 * 256 : 8 * 128; }
 
@@ -59,7 +60,7 @@ struct RingState {
 template <int NT0, int NO0, int NO1, int NO2, int PF>
 __device__ __forceinline__ void coop_tile(const RegChain &c, const int tile, const float *__restrict__ sbias, const int lane, const int wave,
                                           RingState &rs, const float4 *__restrict__ sbase, const float4 *__restrict__ nbase,
-                                          float *lds_pool) {
+                                          float *lds_pool, const sad::ItemQueue &Q, int &grabbed) {
     constexpr int COUT = NO2 * 32;
     constexpr int NI = NO1 * 4, NG2 = NO1 * 4;
     constexpr int PER = NT0 + NI, TOT = NO0 * PER, P = TOT + NO2 * NG2;
@@ -161,6 +162,9 @@ __device__ __forceinline__ void coop_tile(const RegChain &c, const int tile, con
         for (int p = 0; p < TOT; ++p) {
             const int o = p / PER, r = p % PER, m = p % S;
             if (m == 0) stage_begin();
+            // the pull for the item after the next: a returning atomic, issued BEHIND the stage's fragment loads — vector
+            // memory operations return in order, so in front of them it would hold up the first stage of every item
+            if (p == 0 && threadIdx.x == 0) grabbed = sad::itemq_item(Q, Q.own, sad::itemq_pull(Q));
             if (r == 0) t = bias_tile(sb0 + o * 32, h);
             if (r < NT0) {
                 const int n = o * NT0 + r;
@@ -235,15 +239,15 @@ __device__ __forceinline__ void coop_tile(const RegChain &c, const int tile, con
 // Family 2 (SA3): 4: 131 -> 128 -> 128 -> 256, 5: 131 -> 128 -> 192 -> 256, 6: 131 -> 128 -> 256 -> 256.
 template <int FAMILY>
 __device__ __forceinline__ void run_coop(const RegChain &c, int shape, int tile, const float *sb, int lane, int wave, RingState &rs,
-                                         const float4 *sbase, const float4 *nbase, float *lp) {
+                                         const float4 *sbase, const float4 *nbase, float *lp, const sad::ItemQueue &Q, int &grabbed) {
     constexpr int PF = pool_floats(FAMILY);
     if constexpr (FAMILY == 1) {
-        if (shape == 2) coop_tile<9, 2, 2, 4, PF>(c, tile, sb, lane, wave, rs, sbase, nbase, lp);
-        else coop_tile<9, 2, 3, 4, PF>(c, tile, sb, lane, wave, rs, sbase, nbase, lp);
+        if (shape == 2) coop_tile<9, 2, 2, 4, PF>(c, tile, sb, lane, wave, rs, sbase, nbase, lp, Q, grabbed);
+        else coop_tile<9, 2, 3, 4, PF>(c, tile, sb, lane, wave, rs, sbase, nbase, lp, Q, grabbed);
     } else {
-        if (shape == 4) coop_tile<17, 4, 4, 8, PF>(c, tile, sb, lane, wave, rs, sbase, nbase, lp);
-        else if (shape == 5) coop_tile<17, 4, 6, 8, PF>(c, tile, sb, lane, wave, rs, sbase, nbase, lp);
-        else coop_tile<17, 4, 8, 8, PF>(c, tile, sb, lane, wave, rs, sbase, nbase, lp);
+        if (shape == 4) coop_tile<17, 4, 4, 8, PF>(c, tile, sb, lane, wave, rs, sbase, nbase, lp, Q, grabbed);
+        else if (shape == 5) coop_tile<17, 4, 6, 8, PF>(c, tile, sb, lane, wave, rs, sbase, nbase, lp, Q, grabbed);
+        else coop_tile<17, 4, 8, 8, PF>(c, tile, sb, lane, wave, rs, sbase, nbase, lp, Q, grabbed);
     }
 }
 
@@ -267,12 +271,22 @@ __global__ __launch_bounds__(WAVES * 64, FAMILY == 2 ? 2 : 3) void mlp_coop_kern
             bo += c.np[l];
         }
     }
-    // items = 4 consecutive tiles of one chain, chain 0 first (heaviest); static round-robin over the workgroups
+    // items = 4 consecutive tiles of one chain, chain 0 first (heaviest)
     const int t0 = ((mp.c[0].rowtab[0] + 31) / 32 + WAVES - 1) / WAVES;
     const int t1 = mp.n > 1 ? t0 + ((mp.c[1].rowtab[0] + 31) / 32 + WAVES - 1) / WAVES : t0;
     const int nitems = mp.n > 2 ? t1 + ((mp.c[2].rowtab[0] + 31) / 32 + WAVES - 1) / WAVES : t1;
-    int item = blockIdx.x;
-    if (item >= nitems) return;                     // (workgroup-uniform)
+    int *s_next = reinterpret_cast<int *>(sbias + ((bo + 3) & ~3));      // [0], [1]: item indices handed from thread 0 to the workgroup
+    const sad::ItemQueue Q = sad::itemq_init(mp.counter, mp.nq);
+    if (tid == 0) {
+        const int pos = sad::itemq_pull(Q, 2);      // the first two items with one atomic
+        int first = sad::itemq_item(Q, Q.own, pos), second = sad::itemq_item(Q, Q.own, pos + 1);
+        if (first >= nitems) first = sad::itemq_steal(Q, nitems);
+        s_next[0] = first;
+        s_next[1] = second;
+    }
+    __syncthreads();                                // (also: the biases are in place)
+    int item = s_next[0], nxt = s_next[1];
+    __syncthreads();                                // s_next is written again at the end of the first item
 #ifdef SAD_COOP_STAMPS
     if (blockIdx.x < 2048 && tid == 0) {
         g_call[blockIdx.x * 4 + 0] = __builtin_amdgcn_s_memrealtime();
@@ -295,7 +309,7 @@ __global__ __launch_bounds__(WAVES * 64, FAMILY == 2 ? 2 : 3) void mlp_coop_kern
         const RegChain &c = mp.c[ci];
         return reinterpret_cast<const float4 *>(c.packed + c.stream_off);
     };
-    {   // prologue: stages 0 and 1 of the first item
+    if (item < nitems) {   // prologue: stages 0 and 1 of the first item
         const float4 *sp = stream_of(item) + (size_t)(FPW * wave) * 64;
 #pragma unroll
         for (int s = 0; s < 2; ++s)
@@ -304,16 +318,28 @@ __global__ __launch_bounds__(WAVES * 64, FAMILY == 2 ? 2 : 3) void mlp_coop_kern
     }
     __syncthreads();
     RingState rs{ring, 0};
-    for (; item < nitems; item += gridDim.x) {
+    while (item < nitems) {                         // (workgroup-uniform)
+        int grabbed = 0;                            // the item after the next: pulled inside the tile, in flight while it runs
         const int ci = __builtin_amdgcn_readfirstlane(item < t0 ? 0 : (item < t1 ? 1 : 2));
         const int tg = item - (ci == 0 ? 0 : (ci == 1 ? t0 : t1));
-        const int nxt = item + (int)gridDim.x < nitems ? item + (int)gridDim.x : item;
         run_coop<FAMILY>(mp.c[ci], mp.shape[ci], tg * WAVES + wave, sbias + (ci == 0 ? 0 : (ci == 1 ? b1 : b2)), lane, wave, rs, stream_of(item),
-                 stream_of(nxt), lds_pool);
+                 stream_of(nxt < nitems ? nxt : item), lds_pool, Q, grabbed);
+        if (tid == 0) {
+            if (grabbed >= nitems && nxt >= nitems) grabbed = sad::itemq_steal(Q, nitems);   // own queue empty and nothing in hand
+            s_next[0] = grabbed;
+        }
+        __syncthreads();
+        item = nxt;
+        nxt = s_next[0];                            // (rewritten only after the next item's many barriers)
+        if (item >= nitems) {                       // (the item in hand was past the end, the stolen one is not)
+            item = nxt;
+            nxt = nitems;
+        }
 #ifdef SAD_COOP_STAMPS
         if (blockIdx.x < 16 && lane == 0) g_cstamps[(blockIdx.x * 4 + wave) * 16 + 12] += 1;
 #endif
     }
+    if (tid == 0) sad::itemq_done(Q, (int)gridDim.x);             // the last workgroup out re-arms the queues for the next launch
 #ifdef SAD_COOP_STAMPS
     if (blockIdx.x < 2048 && tid == 0) g_call[blockIdx.x * 4 + 1] = __builtin_amdgcn_s_memrealtime();
     if (blockIdx.x < 16 && lane == 0) {
@@ -363,13 +389,16 @@ static int launch_coop_family(const RegMulti &mp, size_t lds, hipStream_t st) {
     long long grid = (long long)cus * pc;
     const long long cap = mp.max_tiles / WAVES + mp.n;          // never more workgroups than items could exist
     if (grid > cap) grid = cap < 1 ? 1 : cap;
-    hipLaunchKernelGGL((mlp_coop_kernel<FAMILY>), dim3((unsigned)grid), dim3(WAVES * 64), lds, st, mp);
+    RegMulti mq = mp;
+    if (grid < 64) mq.nq = 1;                                   // (a small grid may leave XCDs without a workgroup: one queue)
+    hipLaunchKernelGGL((mlp_coop_kernel<FAMILY>), dim3((unsigned)grid), dim3(WAVES * 64), lds, st, mq);
     return check_launch("sad_mlp_chain_f32 (cooperative register-resident chain)");
 }
 
 int launch_coop(const RegMulti &mp, hipStream_t st) {
     const int fam = reg_family(mp.shape[0]);
     size_t lds = sizeof(float4) * RING_F4 + sizeof(float) * WAVES * pool_floats(fam);
+    lds += 16;                                                  // the item indices handed to the workgroup
     for (int i = 0; i < mp.n; ++i) {
         lds += sizeof(float) * (size_t)(mp.c[i].np[0] + mp.c[i].np[1] + mp.c[i].np[2]);
         if (!coop_shape(mp.shape[i]) || mp.c[i].stream_off < 0 || reg_family(mp.shape[i]) != fam)
