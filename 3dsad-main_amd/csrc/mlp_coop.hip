@@ -164,7 +164,7 @@ __device__ __forceinline__ void coop_tile(const RegChain &c, const int tile, con
             if (m == 0) stage_begin();
             // the pull for the item after the next: a returning atomic, issued BEHIND the stage's fragment loads — vector
             // memory operations return in order, so in front of them it would hold up the first stage of every item
-            if (p == 0 && threadIdx.x == 0) grabbed = sad::itemq_item(Q, Q.own, sad::itemq_pull(Q));
+            if (p == 0 && threadIdx.x == 0 && Q.nq) grabbed = sad::itemq_item(Q, Q.own, sad::itemq_pull(Q));
             if (r == 0) t = bias_tile(sb0 + o * 32, h);
             if (r < NT0) {
                 const int n = o * NT0 + r;
@@ -278,11 +278,16 @@ __global__ __launch_bounds__(WAVES * 64, FAMILY == 2 ? 2 : 3) void mlp_coop_kern
     int *s_next = reinterpret_cast<int *>(sbias + ((bo + 3) & ~3));      // [0], [1]: item indices handed from thread 0 to the workgroup
     const sad::ItemQueue Q = sad::itemq_init(mp.counter, mp.nq);
     if (tid == 0) {
-        const int pos = sad::itemq_pull(Q, 2);      // the first two items with one atomic
-        int first = sad::itemq_item(Q, Q.own, pos), second = sad::itemq_item(Q, Q.own, pos + 1);
-        if (first >= nitems) first = sad::itemq_steal(Q, nitems);
-        s_next[0] = first;
-        s_next[1] = second;
+        if (mp.nq == 0) {                           // A/B knob (mlp_static=1): static round-robin deal
+            s_next[0] = (int)blockIdx.x;
+            s_next[1] = (int)(blockIdx.x + gridDim.x);
+        } else {
+            const int pos = sad::itemq_pull(Q, 2);  // the first two items with one atomic
+            int first = sad::itemq_item(Q, Q.own, pos), second = sad::itemq_item(Q, Q.own, pos + 1);
+            if (first >= nitems) first = sad::itemq_steal(Q, nitems);
+            s_next[0] = first;
+            s_next[1] = second;
+        }
     }
     __syncthreads();                                // (also: the biases are in place)
     int item = s_next[0], nxt = s_next[1];
@@ -325,7 +330,8 @@ __global__ __launch_bounds__(WAVES * 64, FAMILY == 2 ? 2 : 3) void mlp_coop_kern
         run_coop<FAMILY>(mp.c[ci], mp.shape[ci], tg * WAVES + wave, sbias + (ci == 0 ? 0 : (ci == 1 ? b1 : b2)), lane, wave, rs, stream_of(item),
                  stream_of(nxt < nitems ? nxt : item), lds_pool, Q, grabbed);
         if (tid == 0) {
-            if (grabbed >= nitems && nxt >= nitems) grabbed = sad::itemq_steal(Q, nitems);   // own queue empty and nothing in hand
+            if (mp.nq == 0) grabbed = nxt + (int)gridDim.x;
+            else if (grabbed >= nitems && nxt >= nitems) grabbed = sad::itemq_steal(Q, nitems);   // own queue empty and nothing in hand
             s_next[0] = grabbed;
         }
         __syncthreads();
@@ -339,7 +345,7 @@ __global__ __launch_bounds__(WAVES * 64, FAMILY == 2 ? 2 : 3) void mlp_coop_kern
         if (blockIdx.x < 16 && lane == 0) g_cstamps[(blockIdx.x * 4 + wave) * 16 + 12] += 1;
 #endif
     }
-    if (tid == 0) sad::itemq_done(Q, (int)gridDim.x);             // the last workgroup out re-arms the queues for the next launch
+    if (tid == 0 && mp.nq) sad::itemq_done(Q, (int)gridDim.x);    // the last workgroup out re-arms the queues for the next launch
 #ifdef SAD_COOP_STAMPS
     if (blockIdx.x < 2048 && tid == 0) g_call[blockIdx.x * 4 + 1] = __builtin_amdgcn_s_memrealtime();
     if (blockIdx.x < 16 && lane == 0) {
@@ -391,6 +397,7 @@ static int launch_coop_family(const RegMulti &mp, size_t lds, hipStream_t st) {
     if (grid > cap) grid = cap < 1 ? 1 : cap;
     RegMulti mq = mp;
     if (grid < 64) mq.nq = 1;                                   // (a small grid may leave XCDs without a workgroup: one queue)
+    if (get_option(OPT_MLP_STATIC) == 1) mq.nq = 0;             // A/B knob: static round-robin deal
     hipLaunchKernelGGL((mlp_coop_kernel<FAMILY>), dim3((unsigned)grid), dim3(WAVES * 64), lds, st, mq);
     return check_launch("sad_mlp_chain_f32 (cooperative register-resident chain)");
 }
