@@ -67,8 +67,6 @@ struct LayerJob {
 struct LayerMulti {
     LayerJob j[2];
     int n;
-    int *counter;                  // zeroed item queues of this launch (see ItemQueue), NULL: static deal
-    int nq;
 };
 int launch_layers(const LayerMulti &lm, long long max_items, hipStream_t st);
 int reg_shape_id(int L, const int *kp, const int *np);   // -1: no compiled shape

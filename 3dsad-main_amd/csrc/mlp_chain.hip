@@ -1125,8 +1125,6 @@ struct Prepared {
     bool layered;       // geometry 3: layer-streamed chain (csrc/mlp_layer.hip); lj[0..nl) are its launches
     sad::LayerJob lj[MAXL];
     int nl;
-    int *layer_counters;   // item queues (ItemQueue) shared by the chain's layer launches, or NULL
-    int layer_nq;
     long long layer_items[MAXL];
     int reg_shape;
     long long reg_tiles;   // upper bound of the tile count
@@ -1251,8 +1249,6 @@ static int prepare_chain(const sad_mlp_args *a, sad_stream_t stream, Prepared &q
         }
         float *ha = a->L > 1 ? (float *)((char *)a->scratch + 64) : nullptr;
         float *hb = ha ? ha + rows_max * wa : nullptr;
-        q.layer_counters = nullptr;
-        q.layer_nq = 1;
         q.nl = a->L;
         for (int l = 0; l < a->L; ++l) {
             sad::LayerJob &j = q.lj[l];
@@ -1289,8 +1285,6 @@ static int prepare_chain(const sad_mlp_args *a, sad_stream_t stream, Prepared &q
             int &w = (l & 1) ? wb : wa;
             w = g.np[l] > w ? g.np[l] : w;
         }
-        q.layer_counters = tab + 2;                  // zeroed by the chain's rowscan
-        q.layer_nq = (int)p.total_groups + 1 >= sad::ITEMQ_INTS ? 8 : 1;
         float *ha = (float *)((char *)a->scratch + 64);
         float *hb = ha + rows_max * wa;
         q.nl = a->L;
@@ -1495,7 +1489,7 @@ int launch_reg_chains(const Prepared *const *qs, int n, hipStream_t st) {
     return qs[0]->coop ? sad::launch_coop(mp, st) : sad::launch_reg(mp, st);
 }
 
-// Layer-streamed chains (one or two with the same number of layers): counters zeroed, one scan, then one
+// Layer-streamed chains (one or two with the same number of layers): one scan, then one
 // launch per layer carrying that layer of every chain.
 int launch_layered_chains(const Prepared *const *qs, int n, hipStream_t st) {
     if (int e = launch_pending_scans(qs, n, st)) return e;
@@ -1504,8 +1498,8 @@ int launch_layered_chains(const Prepared *const *qs, int n, hipStream_t st) {
         lm.n = n;
         long long items = 0;
         for (int i = 0; i < n; ++i) { lm.j[i] = qs[i]->lj[l]; items += qs[i]->layer_items[l]; }
-        lm.counter = nullptr;                        // (items are dealt statically: pulling them from the per-XCD queues the
-        lm.nq = 1;                                   // cooperative kernel uses cost the pipeline 2.5 %)
+        // (items of a layer launch are dealt statically: pulling them from per-XCD queues as the cooperative kernel does
+        // cost the pipeline 2.5 %)
         if (int e = sad::launch_layers(lm, items, st)) return e;
     }
     return SAD_OK;
