@@ -1103,6 +1103,22 @@ SAD_API size_t sad_mlp_scratch_bytes(int B, int M, int S, int L, const int *dims
     return 64 + sizeof(float) * rows_max * (size_t)(wa + wb);
 }
 
+SAD_API int sad_mlp_preferred_geometry(int L, const int *dims) {
+    if (L < 1 || L > MAXL || !dims) return 0;
+    for (int l = 0; l <= L; ++l)
+        if (dims[l] < 1 || dims[l] > 4096) return 0;
+    if (dims[0] < 3) return 0;
+    const Geometry g = geometry(L, dims, 1);
+    const int shape = sad::reg_shape_id(L, g.kp, g.np);
+    const int C = dims[0] - 3;
+    const bool rows16 = C >= 4 && C % 4 == 0;               // 16-byte feature rows (the caller's ld_feat must agree)
+    if (shape >= 0 && sad::coop_shape(shape) && g.stream_off >= 0 && rows16) return 4;
+    if (shape >= 0 && (C == 0 || C == 1 || rows16)) return 2;
+    bool wide = rows16;
+    for (int l = 0; l < L; ++l) wide = wide && g.np[l] % 128 == 0 && (l == 0 || g.kp[l] == g.np[l - 1]);
+    return wide ? 3 : 0;
+}
+
 SAD_API size_t sad_mlp_workspace_bytes(int B, int M, int S) {
     if (B < 1 || M < 1 || S < 1) return 0;
     const size_t ng = (size_t)B * M;
@@ -1175,7 +1191,8 @@ static int prepare_chain(const sad_mlp_args *a, sad_stream_t stream, Prepared &q
     p.sp_shift = sp_shift;
     p.total_rows = (long long)a->B * a->M << sp_shift;   // plain mode: rows; VALU kernel: padded rows
     p.total_groups = (long long)a->B * a->M;
-    int geom_all = a->geometry ? a->geometry : sad::get_option(sad::OPT_MLP_FORCE);
+    // (the mlp_force knob of tests / sweeps wins over the per-call field)
+    int geom_all = sad::get_option(sad::OPT_MLP_FORCE) ? sad::get_option(sad::OPT_MLP_FORCE) : a->geometry;
     const int flex_code = (geom_all / 100000) % 10;          // bit 0 = flexible item distribution, bit 1 = two output tiles per wave (both need RW == 1)
     const int dyn_code = (geom_all / 10000) % 10;            // 0 = heuristic, 1 = global packing, 2 = per-workgroup packing
     const int fcode = (geom_all / 1000) % 10;                // 0 = default

@@ -327,7 +327,12 @@ class PackedMLP:
                  name: str = ""):
         self.name = name
         self._geom = {}              # shape key -> geometry picked by the autotuner
-        self.default_geometry = 0    # used for shapes never tuned (0 = built-in heuristic); see SADDetector.set_geometry
+        # used for shapes never tuned (0 = built-in heuristic of the tiled kernel); see SADDetector.set_geometry
+        self.default_geometry = 0
+        # ... grouped calls that come with counts (cnt) and are not tuned use the kernel the library prefers for the shape
+        # (register-resident / cooperative / layer-streamed chain; 0 = tiled): the un-tuned path is then within a few per
+        # cent of the tuned one on the benchmark shapes
+        self.preferred_geometry = 0
         if not 1 <= len(layers) <= _lib.MAX_LAYERS:
             raise ValueError(f"1..{_lib.MAX_LAYERS} layers supported")
         self.device = torch.device(device)
@@ -352,6 +357,8 @@ class PackedMLP:
                                          self.packed.data_ptr(), _stream()), "sad_mlp_pack_f32")
             torch.cuda.current_stream().synchronize()  # ws/bs may be freed after this returns
         self.out_channels = self.dims[-1]
+        if self.first_has_xyz:
+            self.preferred_geometry = int(lib().sad_mlp_preferred_geometry(self.L, dims_c))
         # geometry 3 (layer-streamed chain, csrc/mlp_layer.hip) applies when every layer's padded width is a
         # multiple of 128 channels; it needs scratch for the activations between layers
         # (plain rows: also C % 8 == 0 and an unpadded C_out, whole 128-channel blocks are stored)
@@ -375,7 +382,7 @@ class PackedMLP:
         if geom is None and AUTOTUNE:
             geom = self._tune(a)
             self._geom[key] = geom
-        a.geometry = geom or self.default_geometry
+        a.geometry = geom or self.default_geometry or a.geometry      # (a.geometry: the preferred kernel of an un-tuned grouped call)
         with _timed("mlp", self.name):
             check(lib().sad_mlp_chain_f32(ctypes.byref(a), _stream()), "sad_mlp_chain_f32")
         if RERUN_LOG is not None:
@@ -462,6 +469,7 @@ class PackedMLP:
         _, M, S = idx.shape
         a = self._args()
         keep = [xyz, new_xyz, idx]
+        feat_ok16 = True
         if feat_pm is None:
             C = 0
         else:
@@ -473,6 +481,9 @@ class PackedMLP:
             a.feat = feat_pm.data_ptr()
             a.ld_feat = feat_pm.stride(1)
             keep.append(feat_pm)
+            # (the register-resident / layer-streamed kernels read feature rows as 16-byte chunks; a single strided
+            # channel is the other layout they take)
+            feat_ok16 = C == 1 or (C % 4 == 0 and a.ld_feat % 4 == 0 and feat_pm.data_ptr() % 16 == 0)
         if self.dims[0] != C + 3:
             raise ValueError(f"MLP expects {self.dims[0] - 3} feature channels, got {C}")
         if out is None:   # the kernel max-combines into the buffer: it must start at zero
@@ -497,6 +508,8 @@ class PackedMLP:
         a.B, a.N, a.M, a.S, a.C = B, N, M, S, C
         a.out, a.ld_out, a.col_off = out.data_ptr(), out.stride(-2), col_off
         a.geometry = self._geom.get((bool(a.idx), a.B, a.N, a.M, a.S, a.ld_out)) or self.default_geometry
+        if not a.geometry and cnt is not None and not AUTOTUNE and feat_ok16:
+            a.geometry = self.preferred_geometry
         if self._layered_ok and cnt is not None and (a.geometry == 3 or AUTOTUNE):
             dims_c = (ctypes.c_int * (self.L + 1))(*self.dims)
             nbytes = lib().sad_mlp_scratch_bytes(B, M, S, self.L, dims_c)
