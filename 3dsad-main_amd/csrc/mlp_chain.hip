@@ -1112,7 +1112,7 @@ SAD_API int sad_mlp_preferred_geometry(int L, const int *dims) {
     const int shape = sad::reg_shape_id(L, g.kp, g.np);
     const int C = dims[0] - 3;
     const bool rows16 = C >= 4 && C % 4 == 0;               // 16-byte feature rows (the caller's ld_feat must agree)
-    if (shape >= 0 && sad::coop_shape(shape) && g.stream_off >= 0 && rows16) return 4;
+    if (shape >= 0 && sad::coop_shape(shape) && sad::reg_family(shape) == 2 && g.stream_off >= 0 && rows16) return 4;   // (SA3; SA2 is as fast on 2)
     if (shape >= 0 && (C == 0 || C == 1 || rows16)) return 2;
     bool wide = rows16;
     for (int l = 0; l < L; ++l) wide = wide && g.np[l] % 128 == 0 && (l == 0 || g.kp[l] == g.np[l - 1]);

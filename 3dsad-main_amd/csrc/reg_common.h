@@ -87,6 +87,9 @@ __device__ __forceinline__ PoolMasks pool_masks(int key) {   // key >= 1 for liv
 // read-after-write wait states are covered by the other registers' work (a register-by-register scan is a
 // chain of ten dependent instructions per register: ~4000 cycles per tile instead of ~700).
 __device__ __forceinline__ f32x16 seg_max16(f32x16 t, const PoolMasks &pm) {
+#ifdef SAD_NOSCAN           // measurement build: no pooling arithmetic (wrong results)
+    return t;
+#endif
     unsigned x[16];
 #pragma unroll
     for (int g = 0; g < 16; ++g) {

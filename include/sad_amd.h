@@ -213,7 +213,7 @@ int sad_mlp_rowscan(int n, const int32_t *const *cnt, const int32_t *const *idx,
                     int M, void *const *workspace, sad_stream_t stream);
 size_t sad_mlp_scratch_bytes(int B, int M, int S, int L, const int *dims);
 /* The `geometry` a caller that does not autotune should pass for a GROUPED chain of this shape when it provides
- * cnt + workspace (+ scratch for 3): 4 (cooperative register-resident chain: SA2 / SA3 shapes), 2 (register-resident
+ * cnt + workspace (+ scratch for 3): 4 (cooperative register-resident chain: the SA3 shapes), 2 (register-resident
  * chain: the other compiled shapes), 3 (layer-streamed chain: every padded width a multiple of 128) or 0 (tiled kernel,
  * built-in heuristic).  Matches what the autotuner picks on the KITTI-shaped benchmark. */
 int sad_mlp_preferred_geometry(int L, const int *dims);
