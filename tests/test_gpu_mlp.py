@@ -548,6 +548,56 @@ def test_cooperative_three_chain_dispatch(orc, sad, dev):
         assert np.array_equal(got[:, :, 256 * bi:256 * (bi + 1)], wants[bi]), f"branch {bi}"
 
 
+def test_cooperative_dispatch_rearms_its_item_queues(orc, sad, dev):
+    """The cooperative kernel pulls its work items from per-XCD queues in the header of the row-packing table and
+    the last workgroup out re-arms them: the same prescanned tables serve any number of launches (a queue left
+    exhausted would make the next launch compute nothing), also when two streams run dispatches side by side on
+    tables of their own."""
+    import torch
+    from sad_amd import ops, synth
+    rng = np.random.default_rng(99)
+    B, N, M, C = 4, 1024, 512, 128
+    xyz = rng.uniform(0, 1, (B, N, 3)).astype(np.float32)
+    feat = rng.normal(size=(B, N, C)).astype(np.float32)
+    new_xyz = np.ascontiguousarray(xyz[:, :M])
+    X, F, Cn = _t(xyz, dev), _t(feat, dev), _t(new_xyz, dev)
+    radii, ns = (0.15, 0.3), (32, 32)
+    mlps = ([128, 128, 256], [128, 256, 256])
+    idxs, cnts = ops.ball_query_multi(radii, ns, X, Cn, return_counts=True)
+    nets, wants = [], []
+    for bi, mlp in enumerate(mlps):
+        layers = synth.make_mlp_weights([C + 3] + mlp, rng)
+        net = ops.PackedMLP(layers, True, dev)
+        net.default_geometry = 4
+        nets.append(net)
+        wants.append(orc.sa_group_mlp_max(xyz, feat, new_xyz, idxs[bi].cpu().numpy(), layers))
+    want = np.concatenate(wants, axis=2)
+
+    def dispatch(wss, out):
+        ops.grouped_multi([(nets[bi], X, F, Cn, idxs[bi], out, 256 * bi, cnts[bi], wss[bi]) for bi in range(2)])
+
+    wss = ops.rowscan_multi(idxs, cnts, N)
+    for rep in range(6):                                     # one table, many launches
+        out = torch.zeros((B, M, 512), device=dev)
+        dispatch(wss, out)
+        assert np.array_equal(out.cpu().numpy(), want), f"launch {rep} on the same tables"
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    wa, wb = ops.rowscan_multi(idxs, cnts, N), ops.rowscan_multi(idxs, cnts, N)
+    torch.cuda.synchronize()
+    outs = []
+    for rep in range(4):                                     # two streams, a table set each
+        oa, ob = torch.zeros((B, M, 512), device=dev), torch.zeros((B, M, 512), device=dev)
+        torch.cuda.synchronize()
+        with torch.cuda.stream(s1):
+            dispatch(wa, oa)
+        with torch.cuda.stream(s2):
+            dispatch(wb, ob)
+        torch.cuda.synchronize()
+        outs += [oa, ob]
+    for i, o in enumerate(outs):
+        assert np.array_equal(o.cpu().numpy(), want), f"concurrent dispatch {i}"
+
+
 def test_register_chain_refuses_other_shapes(orc, sad, dev):
     """A chain without a compiled shape is refused with SAD_EUNSUPPORTED (autotuners skip it), never wrong."""
     from sad_amd import _lib, ops, synth
