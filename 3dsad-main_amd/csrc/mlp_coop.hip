@@ -327,8 +327,10 @@ __global__ __launch_bounds__(WAVES * 64, FAMILY == 2 ? 2 : 3) void mlp_coop_kern
         int grabbed = 0;                            // the item after the next: pulled inside the tile, in flight while it runs
         const int ci = __builtin_amdgcn_readfirstlane(item < t0 ? 0 : (item < t1 ? 1 : 2));
         const int tg = item - (ci == 0 ? 0 : (ci == 1 ? t0 : t1));
+        // the tile's last two stages fetch the first two of the stream it expects to run next
+        const float4 *expect = stream_of(nxt < nitems ? nxt : item);
         run_coop<FAMILY>(mp.c[ci], mp.shape[ci], tg * WAVES + wave, sbias + (ci == 0 ? 0 : (ci == 1 ? b1 : b2)), lane, wave, rs, stream_of(item),
-                 stream_of(nxt < nitems ? nxt : item), lds_pool, Q, grabbed);
+                 expect, lds_pool, Q, grabbed);
         if (tid == 0) {
             if (mp.nq == 0) grabbed = nxt + (int)gridDim.x;
             else if (grabbed >= nitems && nxt >= nitems) grabbed = sad::itemq_steal(Q, nitems);   // own queue empty and nothing in hand
@@ -340,6 +342,18 @@ __global__ __launch_bounds__(WAVES * 64, FAMILY == 2 ? 2 : 3) void mlp_coop_kern
         if (item >= nitems) {                       // (the item in hand was past the end, the stolen one is not)
             item = nxt;
             nxt = nitems;
+        }
+        if (item < nitems && stream_of(item) != expect) {
+            // an item taken from another queue may belong to another chain than the one whose first stages the ring
+            // holds (tail of a dispatch only): fill the two ring slots again (the barrier above closed every read)
+            const float4 *sp = stream_of(item) + (size_t)(FPW * wave) * 64;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const int sl = rs.slot + s >= NS ? rs.slot + s - NS : rs.slot + s;
+#pragma unroll
+                for (int e = 0; e < FPW; ++e) ring[(sl * S + FPW * wave + e) * 64 + lane] = (sp + (size_t)(s * S + e) * 64)[ulane];
+            }
+            __syncthreads();
         }
 #ifdef SAD_COOP_STAMPS
         if (blockIdx.x < 16 && lane == 0) g_cstamps[(blockIdx.x * 4 + wave) * 16 + 12] += 1;

@@ -576,8 +576,10 @@ def test_cooperative_dispatch_rearms_its_item_queues(orc, sad, dev):
     def dispatch(wss, out):
         ops.grouped_multi([(nets[bi], X, F, Cn, idxs[bi], out, 256 * bi, cnts[bi], wss[bi]) for bi in range(2)])
 
+    import os
+    stress = int(os.environ.get("SAD_STRESS", "1"))          # SAD_STRESS=20: a longer soak of the same checks
     wss = ops.rowscan_multi(idxs, cnts, N)
-    for rep in range(6):                                     # one table, many launches
+    for rep in range(6 * stress):                            # one table, many launches
         out = torch.zeros((B, M, 512), device=dev)
         dispatch(wss, out)
         assert np.array_equal(out.cpu().numpy(), want), f"launch {rep} on the same tables"
@@ -585,7 +587,7 @@ def test_cooperative_dispatch_rearms_its_item_queues(orc, sad, dev):
     wa, wb = ops.rowscan_multi(idxs, cnts, N), ops.rowscan_multi(idxs, cnts, N)
     torch.cuda.synchronize()
     outs = []
-    for rep in range(4):                                     # two streams, a table set each
+    for rep in range(4 * stress):                            # two streams, a table set each
         oa, ob = torch.zeros((B, M, 512), device=dev), torch.zeros((B, M, 512), device=dev)
         torch.cuda.synchronize()
         with torch.cuda.stream(s1):
