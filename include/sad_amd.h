@@ -154,7 +154,10 @@ typedef struct sad_mlp_args {
     /* optional, grouped mode with cnt: sad_mlp_workspace_bytes(B, M, S) bytes of 16-byte aligned
      * device scratch.  The surviving rows of ALL groups are then packed globally (one prefix-sum
      * workgroup) and a persistent grid pulls full passes from a work counter; without it each
-     * workgroup packs only its own groups. */
+     * workgroup packs only its own groups.  The table also holds the work counters / item queues of the
+     * kernel that consumes it, so ONE dispatch at a time may use a given workspace (dispatches that run
+     * side by side on different streams need a workspace each; a prescanned table may be reused by
+     * consecutive launches of geometry 2 / 3 / 4 on one stream — they re-arm what they use). */
     void *workspace;
     /* features: grouped mode: point-major [B,N,C] with row stride ld_feat (NULL iff C == 0);
      * plain mode (idx == NULL): rows [B*M, C] with row stride ld_feat */
