@@ -78,7 +78,9 @@ class SAModuleMSG(nn.Module):
         only, so a caller may run it ahead on another stream)."""
         st = self.stage
         B, M = new_xyz.shape[0], new_xyz.shape[1]
-        q = query if query is not None else self.query(xyz, new_xyz, radius_pc, radii)
+        # (own query: with the row-packing scan behind it, as the detector's sampling stream does — the MLP dispatch is
+        # then the same launches in every mode)
+        q = query if query is not None else self.query(xyz, new_xyz, radius_pc, radii, prescan=not ops.AUTOTUNE)
         idxs, cnts = q[0], q[1]
         wss = q[2] if len(q) > 2 else [None] * len(idxs)
         if keep is not None:

@@ -11,8 +11,10 @@ Inputs (both produced by tools/profile_r02.sh and committed under profiles/):
     a step, in launch order) and `mlp_launches[name].executed_gflop` (flops the kernels execute — ball-query
     padding rows are skipped exactly; the batch is the same seeded synthetic batch in both runs).
 Per step the MLP kernels are grouped into dispatches in launch order: a row-packing scan
-(rowscan_sums + rowscan_write) opens the dispatch it feeds, consecutive mlp_layer_kernel launches (one per
-layer) belong together, every other mlp_* kernel is its own dispatch.  Prints per-dispatch duration and
+(rowscan_sums + rowscan_write) that is DIRECTLY followed by an MLP kernel was launched by that dispatch and opens
+it (the cluster layer); a scan followed by other kernels first (the SA stages: it runs behind the ball query, on
+the sampling stream in the timed configuration) is not part of any MLP dispatch; consecutive mlp_layer_kernel
+launches (one per layer) belong together, every other mlp_* kernel is its own dispatch.  Prints per-dispatch duration and
 TFLOP/s and the total fraction of the dense f32 MFMA peak (157.3 TFLOP/s)."""
 import csv
 import json
@@ -29,8 +31,18 @@ def main():
     trace, bench = sys.argv[1], sys.argv[2]
     steps = int(sys.argv[3]) if len(sys.argv) > 3 else None
     rows = sorted(csv.DictReader(open(trace)), key=lambda r: int(r["Start_Timestamp"]))
-    ks = [(short(r["Kernel_Name"]), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3) for r in rows]
-    ks = [(n, d) for n, d in ks if n.startswith(("mlp_", "rowscan_")) and n not in ("mlp_pack_kernel",)]
+    allk = [(short(r["Kernel_Name"]), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3) for r in rows]
+    ks = []
+    for i, (n, d) in enumerate(allk):
+        if n == "mlp_pack_kernel" or not n.startswith(("mlp_", "rowscan_")):
+            continue
+        if n == "rowscan_sums_kernel":      # part of an MLP dispatch only if sums, write, MLP kernel follow each other directly
+            own = i + 2 < len(allk) and allk[i + 1][0] == "rowscan_write_kernel" and allk[i + 2][0].startswith("mlp_")
+            if not own:
+                continue
+        if n == "rowscan_write_kernel" and not (ks and ks[-1][0] == "rowscan_sums_kernel" and i > 0 and allk[i - 1][0] == "rowscan_sums_kernel"):
+            continue
+        ks.append((n, d))
     groups, cur = [], None          # a group = [names..., total us]
     for n, d in ks:
         if n == "rowscan_sums_kernel":
