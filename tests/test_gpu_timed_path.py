@@ -179,7 +179,13 @@ def test_bench_configuration_b32_submit_autotuned(orc, sad, dev):
     tuned = det.autotune(P)
     assert "cluster.agg+head" in tuned, f"the fused chain was not tuned: {sorted(tuned)}"
     print(f"[parity] tuned geometry: {tuned}")
-    outs = [det.submit(P)[0] for _ in range(4)]
+    import os
+    stress = int(os.environ.get("SAD_STRESS", "1"))     # SAD_STRESS=10: soak (the kernels that pull work from queues,
+    outs = []                                           # overlap of batches on two main + four sampling streams)
+    for _ in range(4 * stress):
+        outs.append(det.submit(P)[0])
+        if len(outs) % 6 == 0:
+            torch.cuda.synchronize()                    # (bounded queue depth, as bench.py)
     torch.cuda.synchronize()
     for i, out in enumerate(outs):
         got = out.cpu().numpy()
