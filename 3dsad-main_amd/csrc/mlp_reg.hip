@@ -355,7 +355,7 @@ __device__ __forceinline__ void run_tile(const RegChain &c, int shape, int tile,
 __host__ __device__ constexpr int in0_f4(int family) { return family == 2 ? 17 * 64 : (family == 1 ? 9 * 64 : 256); }
 
 template <int FAMILY>
-__global__ __launch_bounds__(WAVES * 64, 2) void mlp_reg_kernel(const RegMulti mp) {   // at least two waves per SIMD: <= 256 registers
+__device__ __forceinline__ void reg_body(const RegMulti &mp) {
     // [families 1, 2: per wave a private image of the layer-0 operands, 9 / 17 k-groups x 64 lanes x 16 B] then
     // per chain the bias blocks of the three layers
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -395,14 +395,28 @@ __global__ __launch_bounds__(WAVES * 64, 2) void mlp_reg_kernel(const RegMulti m
 }
 
 template <int FAMILY>
+__global__ __launch_bounds__(WAVES * 64, 2) void mlp_reg_kernel(const RegMulti mp) {   // at least two waves per SIMD: <= 256 registers
+    reg_body<FAMILY>(mp);
+}
+// the narrow SA1 chains are latency / vector-ALU bound: six waves per SIMD instead of five (<= 80 registers)
+__global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(6, 6))) void mlp_reg_kernel_narrow(const RegMulti mp) {
+    reg_body<0>(mp);
+}
+template <int FAMILY>
+constexpr auto reg_kernel_of() {
+    if constexpr (FAMILY == 0) return &mlp_reg_kernel_narrow;
+    else return &mlp_reg_kernel<FAMILY>;
+}
+
+template <int FAMILY>
 int launch_family(const RegMulti &mp, size_t lds, hipStream_t st) {
     static std::atomic<uint64_t> attr_done{0};
-    sad::lds_attr_once(attr_done, reinterpret_cast<const void *>(&mlp_reg_kernel<FAMILY>), 160 * 1024);
+    sad::lds_attr_once(attr_done, reinterpret_cast<const void *>(reg_kernel_of<FAMILY>()), 160 * 1024);
     static std::atomic<int> per_cu{0};      // resident workgroups per CU (occupancy query once per process: same on every device of a node)
     int pc = per_cu.load(std::memory_order_relaxed);
     if (pc == 0) {
         int nb = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, mlp_reg_kernel<FAMILY>, WAVES * 64, lds) != hipSuccess || nb < 1) {
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reg_kernel_of<FAMILY>(), WAVES * 64, lds) != hipSuccess || nb < 1) {
             (void)hipGetLastError();
             nb = 2;
         }
@@ -419,7 +433,7 @@ int launch_family(const RegMulti &mp, size_t lds, hipStream_t st) {
     long long grid = (long long)cus * pc;
     const long long cap = (mp.max_tiles + WAVES - 1) / WAVES;      // never more waves than tiles could exist
     if (grid > cap) grid = cap < 1 ? 1 : cap;
-    hipLaunchKernelGGL((mlp_reg_kernel<FAMILY>), dim3((unsigned)grid), dim3(WAVES * 64), lds, st, mp);
+    hipLaunchKernelGGL(reg_kernel_of<FAMILY>(), dim3((unsigned)grid), dim3(WAVES * 64), lds, st, mp);
     return sad::check_launch("sad_mlp_chain_f32 (register-resident chain)");
 }
 
