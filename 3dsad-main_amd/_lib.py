@@ -15,6 +15,9 @@ SO_PATH = os.environ.get("SAD_AMD_LIB") or os.path.join(CSRC, "libsad_amd.so")
 
 MAX_LAYERS = 4
 MAX_RADII = 4
+ABI_VERSION = 2            # SAD_ABI_VERSION of include/sad_amd.h this binding was written against
+# instrumentation ints of a row-packing table (include/sad_amd.h, SAD_WS_*)
+WS_REFILLS, WS_INUSE, WS_CONFLICT = 5, 6, 7
 
 c_f32p = ctypes.POINTER(ctypes.c_float)
 c_i32p = ctypes.POINTER(ctypes.c_int32)
@@ -24,6 +27,7 @@ vp = ctypes.c_void_p
 class MlpArgs(ctypes.Structure):
     """``struct sad_mlp_args`` (include/sad_amd.h)."""
     _fields_ = [
+        ("struct_size", ctypes.c_size_t),
         ("xyz", vp), ("new_xyz", vp), ("idx", vp), ("cnt", vp), ("workspace", vp), ("feat", vp),
         ("ld_feat", ctypes.c_int),
         ("B", ctypes.c_int), ("N", ctypes.c_int), ("M", ctypes.c_int), ("S", ctypes.c_int),
@@ -40,6 +44,7 @@ class MlpArgs(ctypes.Structure):
 class MlpBf16Args(ctypes.Structure):
     """``struct sad_mlp_bf16_args`` (include/sad_amd.h)."""
     _fields_ = [
+        ("struct_size", ctypes.c_size_t),
         ("xyz", vp), ("new_xyz", vp), ("idx", vp), ("feat", vp),
         ("feat_bf16", ctypes.c_int), ("ld_feat", ctypes.c_int),
         ("B", ctypes.c_int), ("N", ctypes.c_int), ("M", ctypes.c_int), ("S", ctypes.c_int),
@@ -134,6 +139,9 @@ def lib():
             fn = getattr(handle, name)  # AttributeError here = header/library mismatch
             fn.restype = res
             fn.argtypes = args
+        if handle.sad_version() != ABI_VERSION:
+            raise RuntimeError(f"{SO_PATH}: ABI version {handle.sad_version()}, this binding needs {ABI_VERSION} "
+                               "(stale build: run __graft_entry__.build())")
         _lib = handle
     return _lib
 

@@ -14,13 +14,14 @@ namespace sad {
 
 void set_error(const char *fmt, ...);
 int get_option(int which);
-// row-packing scan of one chain / of up to three chains in the same two launches (csrc/mlp_chain.hip)
+// row-packing scan of one chain / of up to SAD_MAX_RADII chains in the same two launches (csrc/mlp_chain.hip)
 struct ScanJob {
     const int32_t *cnt, *idx;
     int *tab, *blk_sum, *row_src, *row_gid;
     int ngroups, S, N, M, nodedup, R, blk0;
 };
-struct ScanMulti { ScanJob j[3]; int n; };
+constexpr int SCAN_MAX_CHAINS = SAD_MAX_RADII;     // the branches of one multi-radius stage
+struct ScanMulti { ScanJob j[SCAN_MAX_CHAINS]; int n; };
 ScanJob make_scan_job(const int32_t *cnt, int ngroups, int S, int R, int *tab, int nodedup, const int32_t *idx, int N, int M);
 int launch_rowscan_multi(const ScanJob *jobs, int n, hipStream_t st);
 int launch_rowscan(const int32_t *cnt, int ngroups, int S, int R, int *tab, hipStream_t st, int nodedup = 0,
@@ -48,6 +49,8 @@ struct RegMulti {
     int *counter;                  // zeroed item queues (see ItemQueue; tiles of all chains form one list)
     int nq;                        // 8: one queue per XCD, 1: a single counter
     long long max_tiles;           // upper bound of the tile count (grid sizing)
+    int steal_after;               // test knob mlp_steal_after (0 = off): see launch_coop
+    int check_id;                  // test knob mlp_check_inuse: this dispatch's id for the in-use marker (0 = off)
 };
 // Layer-streamed chain kernel (csrc/mlp_layer.hip): one layer of one chain / one layer of up to two chains
 struct LayerJob {
@@ -76,7 +79,7 @@ int launch_reg(const RegMulti &mp, hipStream_t st);
 bool coop_shape(int shape);
 long long coop_stream_frags(int shape, const int *kp, const int *np);   // fragments (1 KB) of the stream image, 0 = none
 int launch_coop(const RegMulti &mp, hipStream_t st);
-enum { OPT_FPS_DPP = 0, OPT_MLP_RW = 1, OPT_MLP_BUDGET_KB = 2, OPT_BQ_VARIANT = 3, OPT_FPS_VARIANT = 4, OPT_MLP_FORCE = 5, OPT_MLP_DEDUP_F = 6, OPT_MLP_NODEDUP = 7, OPT_FPS_THREADS = 8, OPT_MLP_STATIC = 9, OPT_GROUP_VARIANT = 10, OPT_MLP_DYN_SLOTS = 11, OPT_MLP_NOXCD = 12, OPT_COUNT };
+enum { OPT_FPS_DPP = 0, OPT_MLP_RW = 1, OPT_MLP_BUDGET_KB = 2, OPT_BQ_VARIANT = 3, OPT_FPS_VARIANT = 4, OPT_MLP_FORCE = 5, OPT_MLP_DEDUP_F = 6, OPT_MLP_NODEDUP = 7, OPT_FPS_THREADS = 8, OPT_MLP_STATIC = 9, OPT_GROUP_VARIANT = 10, OPT_MLP_DYN_SLOTS = 11, OPT_MLP_NOXCD = 12, OPT_MLP_STEAL_AFTER = 13, OPT_MLP_CHECK_INUSE = 14, OPT_COUNT };
 
 inline int fail(int code, const char *fmt, ...) {
     char buf[480];
@@ -118,6 +121,12 @@ inline int check_launch(const char *what) {
 // no workgroup has its items taken by the rest.  Layout (ints, in the header of the row-packing table): q[0] the
 // single counter used when nq == 1 (small tables / grids), q[1] workgroups finished (the last one out re-arms
 // everything for the next launch), q[2 + 32 x] the counter of XCD x (one 128-byte line each).
+// With nq == 8 three more ints of the header are test instrumentation (zeroed by the row-packing scan, never re-armed:
+// they accumulate over the launches that reuse a table; ints 5, 6, 7 of the workspace, see include/sad_amd.h):
+// q[ITEMQ_REFILLS] weight-ring refills of the cooperative kernel (an item of another chain than the one prefetched),
+// q[ITEMQ_INUSE] id of the dispatch that owns the queues right now (mlp_check_inuse), q[ITEMQ_CONFLICT] set when a
+// dispatch found another one's id there.
+constexpr int ITEMQ_REFILLS = 3, ITEMQ_INUSE = 4, ITEMQ_CONFLICT = 5;
 struct ItemQueue {
     int *q;
     int nq, own;
@@ -153,8 +162,16 @@ __device__ __forceinline__ void itemq_done(const ItemQueue &Q, int workgroups) {
     if (atomicAdd(Q.q + 1, 1) != workgroups - 1) return;
     Q.q[0] = 0;
     Q.q[1] = 0;
-    if (Q.nq == 8)
+    if (Q.nq == 8) {
         for (int x = 0; x < 8; ++x) Q.q[2 + 32 * x] = 0;
+        Q.q[ITEMQ_INUSE] = 0;
+    }
+}
+// test knob mlp_check_inuse: one thread per workgroup, before its first pull — claims the queues for dispatch `id`
+__device__ __forceinline__ void itemq_claim(const ItemQueue &Q, int id) {
+    if (Q.nq != 8 || id == 0) return;
+    const int old = atomicCAS(Q.q + ITEMQ_INUSE, 0, id);
+    if (old != 0 && old != id) atomicExch(Q.q + ITEMQ_CONFLICT, 1);
 }
 
 // SPEC.md §1 — the one squared-distance expression every index decision uses.  The library is

@@ -506,6 +506,8 @@ struct BfPrepared {
 // Validation, tile size, row-packing scan of one chain; fills `q` for the launch.
 static int prepare_bf16(const sad_mlp_bf16_args *a, sad_stream_t stream, BfPrepared &prep) {
     SAD_REQUIRE(a, "sad_mlp_chain_bf16: NULL args");
+    SAD_REQUIRE(a->struct_size == sizeof(sad_mlp_bf16_args), "sad_mlp_chain_bf16: struct_size=%zu, this library's sad_mlp_bf16_args has %zu bytes "
+                "(caller built against another sad_amd.h; ABI version %d)", a->struct_size, sizeof(sad_mlp_bf16_args), SAD_ABI_VERSION);
     SAD_REQUIRE(a->L >= 1 && a->L <= SAD_MAX_LAYERS && a->packed && a->out, "sad_mlp_chain_bf16: bad argument");
     SAD_REQUIRE((uintptr_t)a->packed % 16 == 0, "sad_mlp_chain_bf16: packed must be 16-byte aligned");
     SAD_REQUIRE(a->B >= 1 && a->M >= 1 && a->C >= 0, "sad_mlp_chain_bf16: bad sizes");

@@ -312,8 +312,12 @@ __global__ __launch_bounds__(SCAN_T) void rowscan_write_kernel(const sad::ScanMu
         jb.tab[1] = (total + jb.R - 1) / jb.R;
         jb.tab[2] = 0;                           // item queues of the kernels that deal items dynamically (common.h, ItemQueue;
         jb.tab[3] = 0;                           // they re-arm them when they finish): single counter, finished workgroups,
-        if (jb.ngroups + 1 >= sad::ITEMQ_INTS)   // and one counter per XCD in the (otherwise unused) row_start area
+        if (jb.ngroups + 1 >= sad::ITEMQ_INTS) { // and one counter per XCD in the (otherwise unused) row_start area
             for (int x = 0; x < 8; ++x) jb.tab[4 + 32 * x] = 0;
+            jb.tab[2 + sad::ITEMQ_REFILLS] = 0;  // test instrumentation (common.h)
+            jb.tab[2 + sad::ITEMQ_INUSE] = 0;
+            jb.tab[2 + sad::ITEMQ_CONFLICT] = 0;
+        }
     }
     if (!jb.row_src) return;
     // row map of rows [base, base + blk_rows), by destination row
@@ -1055,7 +1059,7 @@ ScanJob make_scan_job(const int32_t *cnt, int ngroups, int S, int R, int *tab, i
     return jb;
 }
 
-// Prefix-sums the per-group row counts of up to three chains with two launches (shared with the bf16 chain).
+// Prefix-sums the per-group row counts of up to SCAN_MAX_CHAINS chains with two launches (shared with the bf16 chain).
 int launch_rowscan_multi(const ScanJob *jobs, int n, hipStream_t st) {
     ScanMulti sm{};
     sm.n = n;
@@ -1079,9 +1083,9 @@ int launch_rowscan(const int32_t *cnt, int ngroups, int S, int R, int *tab, hipS
 
 SAD_API int sad_mlp_rowscan(int n, const int32_t *const *cnt, const int32_t *const *idx, const int *S, int B, int N,
                             int M, void *const *workspace, sad_stream_t stream) {
-    SAD_REQUIRE(n >= 1 && n <= 3 && cnt && idx && S && workspace, "sad_mlp_rowscan: need 1..3 chains and non-NULL arrays");
+    SAD_REQUIRE(n >= 1 && n <= sad::SCAN_MAX_CHAINS && cnt && idx && S && workspace, "sad_mlp_rowscan: need 1..%d chains and non-NULL arrays", sad::SCAN_MAX_CHAINS);
     SAD_REQUIRE(B >= 1 && N >= 1 && M >= 1 && (long long)B * M < (1LL << 30), "sad_mlp_rowscan: bad B/N/M");
-    sad::ScanJob jobs[3];
+    sad::ScanJob jobs[sad::SCAN_MAX_CHAINS];
     for (int i = 0; i < n; ++i) {
         SAD_REQUIRE(cnt[i] && idx[i] && workspace[i] && S[i] >= 1 && S[i] <= 64, "sad_mlp_rowscan: chain %d: NULL pointer or bad nsample", i);
         SAD_REQUIRE((uintptr_t)workspace[i] % 16 == 0, "sad_mlp_rowscan: workspace must be 16-byte aligned");
@@ -1148,6 +1152,16 @@ struct Prepared {
 int launch_prepared(const Prepared &q, hipStream_t st);
 }  // namespace
 
+// mlp_layer.hip forms the byte offset of an input row as a 32-bit product (row * ld * 4): the first layer's rows
+// (`in_rows` feature rows of stride `in_ld`) and every hidden activation matrix (rows_max x np[l]) must stay below 4 GiB.
+static bool layer_offsets_fit(long long in_rows, long long in_ld, long long rows_max, int L, const int *np) {
+    const long long lim = 1LL << 32;
+    if (in_rows * in_ld * 4 >= lim) return false;
+    for (int l = 0; l + 1 < L; ++l)
+        if (rows_max * np[l] * 4 >= lim) return false;
+    return true;
+}
+
 // Validation, geometry choice and the row-packing scan of one chain; fills `q` for the launch.
 static int prepare_chain(const sad_mlp_args *a, sad_stream_t stream, Prepared &q) {
     q.launched = false;
@@ -1156,6 +1170,8 @@ static int prepare_chain(const sad_mlp_args *a, sad_stream_t stream, Prepared &q
     q.layered = false;
     q.prescanned = a && a->prescanned != 0;
     SAD_REQUIRE(a, "sad_mlp_chain_f32: NULL args");
+    SAD_REQUIRE(a->struct_size == sizeof(sad_mlp_args), "sad_mlp_chain_f32: struct_size=%zu, this library's sad_mlp_args has %zu bytes "
+                "(caller built against another sad_amd.h; ABI version %d)", a->struct_size, sizeof(sad_mlp_args), SAD_ABI_VERSION);
     if (int e = check_dims("sad_mlp_chain_f32", a->L, a->dims)) return e;
     const bool grouped = a->idx != nullptr;
     SAD_REQUIRE(a->packed && a->out, "sad_mlp_chain_f32: NULL packed/out");
@@ -1264,6 +1280,10 @@ static int prepare_chain(const sad_mlp_args *a, sad_stream_t stream, Prepared &q
             int &w = (l & 1) ? wb : wa;
             w = g.np[l] > w ? g.np[l] : w;
         }
+        // mlp_layer_kernel addresses a layer's input rows with 32-bit byte offsets (row * ld * 4)
+        if (!layer_offsets_fit(p.total_rows, a->ld_feat, rows_max, a->L, g.np))
+            return sad::fail(SAD_EUNSUPPORTED, "sad_mlp_chain_f32: geometry 3 (layer-streamed chain): rows x row stride x 4 must stay below 4 GiB "
+                                               "(%lld rows); split the call or use the tiled kernel", p.total_rows);
         float *ha = a->L > 1 ? (float *)((char *)a->scratch + 64) : nullptr;
         float *hb = ha ? ha + rows_max * wa : nullptr;
         q.nl = a->L;
@@ -1302,6 +1322,10 @@ static int prepare_chain(const sad_mlp_args *a, sad_stream_t stream, Prepared &q
             int &w = (l & 1) ? wb : wa;
             w = g.np[l] > w ? g.np[l] : w;
         }
+        if (!layer_offsets_fit((long long)a->B * a->N, a->ld_feat, rows_max, a->L, g.np))
+            return sad::fail(SAD_EUNSUPPORTED, "sad_mlp_chain_f32: geometry 3 (layer-streamed chain): rows x row stride x 4 must stay below 4 GiB "
+                                               "(B*N = %lld feature rows, %lld grouped rows); split the call or use the tiled kernel",
+                             (long long)a->B * a->N, rows_max);
         float *ha = (float *)((char *)a->scratch + 64);
         float *hb = ha + rows_max * wa;
         q.nl = a->L;

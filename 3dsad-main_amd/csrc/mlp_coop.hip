@@ -277,10 +277,30 @@ __global__ __launch_bounds__(WAVES * 64, FAMILY == 2 ? 2 : 3) void mlp_coop_kern
     const int nitems = mp.n > 2 ? t1 + ((mp.c[2].rowtab[0] + 31) / 32 + WAVES - 1) / WAVES : t1;
     int *s_next = reinterpret_cast<int *>(sbias + ((bo + 3) & ~3));      // [0], [1]: item indices handed from thread 0 to the workgroup
     const sad::ItemQueue Q = sad::itemq_init(mp.counter, mp.nq);
+    // Test knob mlp_steal_after = v > 0 (eight queues only): the own queue counts as empty after v - 1 items, items are
+    // then taken from the OTHER queues one at a time with nothing prefetched — consecutive items of a workgroup change chain
+    // wherever the queues do, so the ring refill below runs at every such change instead of only at the tail of a dispatch.
+    // When nothing is left elsewhere the own queue is used after all: every item is taken exactly once under any placement.
+    const bool steal_mode = mp.steal_after > 0 && mp.nq == 8;
+    int own_budget = mp.steal_after - 1;            // (thread 0)
+    auto take = [&]() -> int {
+        int it = nitems;
+        if (own_budget > 0) {
+            it = sad::itemq_item(Q, Q.own, sad::itemq_pull(Q));
+            --own_budget;
+        }
+        if (it >= nitems) it = sad::itemq_steal(Q, nitems);
+        if (it >= nitems) it = sad::itemq_item(Q, Q.own, sad::itemq_pull(Q));
+        return it < nitems ? it : nitems;
+    };
     if (tid == 0) {
+        sad::itemq_claim(Q, mp.check_id);           // (test knob mlp_check_inuse; nothing when check_id == 0)
         if (mp.nq == 0) {                           // A/B knob (mlp_static=1): static round-robin deal
             s_next[0] = (int)blockIdx.x;
             s_next[1] = (int)(blockIdx.x + gridDim.x);
+        } else if (steal_mode) {
+            s_next[0] = take();
+            s_next[1] = nitems;
         } else {
             const int pos = sad::itemq_pull(Q, 2);  // the first two items with one atomic
             int first = sad::itemq_item(Q, Q.own, pos), second = sad::itemq_item(Q, Q.own, pos + 1);
@@ -323,6 +343,7 @@ __global__ __launch_bounds__(WAVES * 64, FAMILY == 2 ? 2 : 3) void mlp_coop_kern
     }
     __syncthreads();
     RingState rs{ring, 0};
+    const sad::ItemQueue Qoff{Q.q, 0, Q.own};       // (steal mode: the tile pulls nothing ahead)
     while (item < nitems) {                         // (workgroup-uniform)
         int grabbed = 0;                            // the item after the next: pulled inside the tile, in flight while it runs
         const int ci = __builtin_amdgcn_readfirstlane(item < t0 ? 0 : (item < t1 ? 1 : 2));
@@ -330,9 +351,10 @@ __global__ __launch_bounds__(WAVES * 64, FAMILY == 2 ? 2 : 3) void mlp_coop_kern
         // the tile's last two stages fetch the first two of the stream it expects to run next
         const float4 *expect = stream_of(nxt < nitems ? nxt : item);
         run_coop<FAMILY>(mp.c[ci], mp.shape[ci], tg * WAVES + wave, sbias + (ci == 0 ? 0 : (ci == 1 ? b1 : b2)), lane, wave, rs, stream_of(item),
-                 expect, lds_pool, Q, grabbed);
+                 expect, lds_pool, steal_mode ? Qoff : Q, grabbed);
         if (tid == 0) {
             if (mp.nq == 0) grabbed = nxt + (int)gridDim.x;
+            else if (steal_mode) grabbed = take();
             else if (grabbed >= nitems && nxt >= nitems) grabbed = sad::itemq_steal(Q, nitems);   // own queue empty and nothing in hand
             s_next[0] = grabbed;
         }
@@ -353,6 +375,7 @@ __global__ __launch_bounds__(WAVES * 64, FAMILY == 2 ? 2 : 3) void mlp_coop_kern
 #pragma unroll
                 for (int e = 0; e < FPW; ++e) ring[(sl * S + FPW * wave + e) * 64 + lane] = (sp + (size_t)(s * S + e) * 64)[ulane];
             }
+            if (tid == 0 && mp.nq == 8) atomicAdd(Q.q + sad::ITEMQ_REFILLS, 1);   // test instrumentation (common.h)
             __syncthreads();
         }
 #ifdef SAD_COOP_STAMPS
@@ -412,6 +435,9 @@ static int launch_coop_family(const RegMulti &mp, size_t lds, hipStream_t st) {
     RegMulti mq = mp;
     if (grid < 64) mq.nq = 1;                                   // (a small grid may leave XCDs without a workgroup: one queue)
     if (get_option(OPT_MLP_STATIC) == 1) mq.nq = 0;             // A/B knob: static round-robin deal
+    mq.steal_after = mq.nq == 8 ? get_option(OPT_MLP_STEAL_AFTER) : 0;   // test knobs (see the kernel / common.h)
+    static std::atomic<int> dispatch_id{0};
+    mq.check_id = mq.nq == 8 && get_option(OPT_MLP_CHECK_INUSE) ? 1 + (dispatch_id.fetch_add(1, std::memory_order_relaxed) & 0x3FFFFFFF) : 0;
     hipLaunchKernelGGL((mlp_coop_kernel<FAMILY>), dim3((unsigned)grid), dim3(WAVES * 64), lds, st, mq);
     return check_launch("sad_mlp_chain_f32 (cooperative register-resident chain)");
 }

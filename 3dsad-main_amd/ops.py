@@ -254,13 +254,13 @@ def ball_query_multi(radii: Sequence[float], nsamples: Sequence[int], xyz: torch
 
 
 def rowscan_multi(idxs: Sequence[torch.Tensor], cnts: Sequence[torch.Tensor], N: int) -> List[torch.Tensor]:
-    """Row-packing tables (prefix sum of the per-group counts + row map) of up to three branches of one ball
+    """Row-packing tables (prefix sum of the per-group counts + row map) of up to four branches of one ball
     query, two launches for all of them.  Needs only what the ball query produced, so it can run on the stream
     that ran the query (the sampling stream), off the MLP stream's critical path; pass table i as the last
     element of branch i's ``grouped_multi`` call (``PackedMLP.grouped(..., ws=table)``)."""
     n = len(idxs)
-    if n != len(cnts) or not 1 <= n <= 3:
-        raise ValueError("need 1..3 (idx, cnt) pairs")
+    if n != len(cnts) or not 1 <= n <= _lib.MAX_RADII:
+        raise ValueError(f"need 1..{_lib.MAX_RADII} (idx, cnt) pairs")
     B, M = cnts[0].shape
     wss = []
     for idx, cnt in zip(idxs, cnts):
@@ -275,6 +275,23 @@ def rowscan_multi(idxs: Sequence[torch.Tensor], cnts: Sequence[torch.Tensor], N:
     w_arr = (vp * n)(*[w.data_ptr() for w in wss])
     check(lib().sad_mlp_rowscan(n, c_arr, i_arr, s_arr, B, int(N), M, w_arr, _stream()), "sad_mlp_rowscan")
     return wss
+
+
+def workspace_status(ws: torch.Tensor) -> dict:
+    """Instrumentation ints of a row-packing table (include/sad_amd.h, SAD_WS_*): weight-ring refills of the
+    cooperative chain kernel, the id of the dispatch that owns the item queues right now and the conflict flag of the
+    ``mlp_check_inuse`` knob.  Synchronises the device (a test / debugging helper, never on the measured path)."""
+    torch.cuda.synchronize(ws.device)
+    hdr = ws[:32].view(torch.int32).cpu()
+    return {"refills": int(hdr[_lib.WS_REFILLS]), "in_use": int(hdr[_lib.WS_INUSE]), "conflict": int(hdr[_lib.WS_CONFLICT])}
+
+
+def check_workspace(ws: torch.Tensor) -> None:
+    """Raises if two dispatches were seen sharing ``ws`` at the same time (needs ``mlp_check_inuse=1``)."""
+    st = workspace_status(ws)
+    if st["conflict"]:
+        raise RuntimeError("row-packing workspace was used by two dispatches at the same time (one dispatch at a time per "
+                           "workspace: sad_mlp_args.workspace in include/sad_amd.h)")
 
 
 def knn_query(k: int, xyz: torch.Tensor, new_xyz: torch.Tensor) -> torch.Tensor:
@@ -438,12 +455,21 @@ class PackedMLP:
 
     def _args(self) -> MlpArgs:
         a = MlpArgs()
+        a.struct_size = ctypes.sizeof(MlpArgs)
         a.L = self.L
         for i, d in enumerate(self.dims):
             a.dims[i] = d
         a.packed = self.packed.data_ptr()
         a.relu_mask = self.relu_mask
         return a
+
+    def wants_prescan(self, B: int, N: int, M: int, S: int, ld_out: int, C: int) -> bool:
+        """Will a grouped call of this shape (with counts) run a kernel that consumes a caller-made row-packing table
+        (geometries 2 / 3 / 4)?  The tiled kernel packs with its own tile height: a table made for it would be wasted."""
+        geom = self._geom.get((True, B, N, M, S, ld_out)) or self.default_geometry
+        if not geom and not AUTOTUNE and (C == 1 or C % 4 == 0):
+            geom = self.preferred_geometry
+        return geom % 1000 in (2, 3, 4)
 
     def grouped(self, xyz: torch.Tensor, feat_pm: Optional[torch.Tensor], new_xyz: torch.Tensor,
                 idx: torch.Tensor, out: Optional[torch.Tensor] = None, col_off: int = 0,
@@ -686,6 +712,7 @@ class PackedMLPBf16:
 
     def _args(self) -> _lib.MlpBf16Args:
         a = _lib.MlpBf16Args()
+        a.struct_size = ctypes.sizeof(_lib.MlpBf16Args)
         a.L = self.L
         for i, d in enumerate(self.dims):
             a.dims[i] = d

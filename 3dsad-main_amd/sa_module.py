@@ -65,8 +65,16 @@ class SAModuleMSG(nn.Module):
                                           radius_pc, return_counts=True)
         if prescan and self.dtype == "f32":
             # the row-packing scan needs only the query's output: run it here (on the sampling stream when the
-            # detector overlaps), so the MLP stream launches no small latency-bound kernels before its chains
-            return idxs, cnts, ops.rowscan_multi(idxs, cnts, xyz.shape[1])
+            # detector overlaps), so the MLP stream launches no small latency-bound kernels before its chains;
+            # only for the branches whose kernel consumes such a table (the tiled kernel packs for itself)
+            B, N, M = xyz.shape[0], xyz.shape[1], new_xyz.shape[1]
+            pick = [i for i, (mlp, s) in enumerate(zip(self.branches, st.nsamples))
+                    if mlp.wants_prescan(B, N, M, s, self.cat_channels, self.in_channels)]
+            wss = [None] * len(idxs)
+            if pick:
+                for i, w in zip(pick, ops.rowscan_multi([idxs[i] for i in pick], [cnts[i] for i in pick], N)):
+                    wss[i] = w
+            return idxs, cnts, wss
         return idxs, cnts
 
     def group_and_pool(self, xyz: torch.Tensor, feat_pm: Optional[torch.Tensor],

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py — scenes/sec of the SA + size-adaptive-cluster + head path on N MI355X (one node).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W        (N > 1: starts its own N ranks with torch.distributed.run)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 Workload (BASELINE.json metric / configs[1..3]): per GPU a resident batch of 32 synthetic
@@ -154,6 +154,48 @@ def flops_of(name, per_flops):
     return sum(per_flops.get(x, 0) for x in name.split("+"))
 
 
+def launch_command(argv, n, port):
+    """The command a parent `python bench.py --gpus N` (N > 1, no WORLD_SIZE in the environment) runs as a CHILD process:
+    one rank per GPU under torch.distributed.run, same bench.py arguments."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(cmd, env=None):
+    """Run `cmd` (the torchrun command of launch_command) as a child, relay rank 0's JSON line to stdout (everything else
+    the ranks print goes to stderr) and return the child's exit code.  The parent never touches the GPU: it starts a child
+    process instead of exec'ing, so nothing that initialised HIP is ever replaced."""
+    import subprocess
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=None, text=True, env=env)
+    line_out = None
+    for line in proc.stdout:
+        t = line.strip()
+        rec = None
+        if t.startswith("{") and t.endswith("}"):
+            try:
+                rec = json.loads(t)
+            except ValueError:
+                rec = None
+        if isinstance(rec, dict) and "metric" in rec and "value" in rec:
+            line_out = t                      # (the last one wins; rank 0 prints exactly one)
+        else:
+            sys.stderr.write(line)
+    rc = proc.wait()
+    if line_out is not None:
+        print(line_out, flush=True)
+    elif rc == 0:
+        sys.stderr.write("bench.py: the ranks exited 0 but printed no result line\n")
+        rc = 1
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -184,6 +226,11 @@ def main():
     ap.add_argument("--opt", action="append", default=[], help="tuning knob key=value (sad_set_option)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` as the driver runs it: start the N ranks ourselves (as a child process, before
+        # anything here has imported torch or touched the GPU), relay rank 0's line and exit with the child's code
+        raise SystemExit(self_launch(launch_command(sys.argv[1:], args.gpus, free_port())))
+
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -196,8 +243,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch `python bench.py --gpus N` (it starts its own "
+                         "ranks) or torch.distributed.run with --nproc-per-node N")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path is the only path (no CPU fallback)")
     if os.environ.get("SAD_BENCH_ONE_DEVICE"):      # rehearsal of the N>1 path on a one-GPU box

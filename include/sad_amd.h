@@ -39,6 +39,10 @@ extern "C" {
 
 typedef void *sad_stream_t; /* hipStream_t */
 
+/* ABI version: bumped whenever a public struct layout or a signature changes (2 = sad_mlp_args / sad_mlp_bf16_args
+ * start with struct_size).  The structs additionally carry their own size: a caller built against another header is
+ * refused with SAD_EINVAL instead of being read past its end. */
+#define SAD_ABI_VERSION 2
 int sad_version(void);
 const char *sad_last_error(void);
 /* Tuning / A-B knobs (process-wide; defaults 0 = automatic).  Returns SAD_EINVAL for an unknown key.
@@ -48,7 +52,19 @@ const char *sad_last_error(void);
  *   bq_variant   reserved (grid vs scan is the caller's choice: sad_ball_query_grid_f32 / sad_ball_query_multi_f32)
  *   group_variant 1 = L2-gather group_points kernel only (no LDS staging)
  *   mlp_rw, mlp_budget_kb, mlp_force, mlp_dedup_f, mlp_nodedup, mlp_static, mlp_dyn_slots, mlp_noxcd: f32 chain geometry overrides
- *                (see sad_mlp_args.geometry; mlp_nodedup = 1 computes the padding rows too) */
+ *                (see sad_mlp_args.geometry; mlp_nodedup = 1 computes the padding rows too)
+ * Test knobs of the item queues of the cooperative chain kernel (geometry 4; tables of >= 257 groups):
+ *   mlp_steal_after v > 0: a workgroup treats the queue of its own XCD as empty after v - 1 items and takes its items from
+ *                the other queues, one at a time and with nothing prefetched, so the cross-queue / weight-ring refill
+ *                path that normally runs only at the tail of a dispatch runs all the time (same results);
+ *   mlp_check_inuse 1: every dispatch stamps its id into the queue header and flags a conflict when it finds another
+ *                dispatch's id there (two dispatches sharing one workspace at the same time).
+ * Instrumentation ints of a row-packing table (sad_mlp_args.workspace as int32[]; zeroed by the row-packing scan,
+ * accumulated by the launches that reuse the table): [5] weight-ring refills, [6] id of the dispatch that owns the
+ * queues right now (0 = none), [7] != 0: a conflict was seen. */
+#define SAD_WS_REFILLS 5
+#define SAD_WS_INUSE 6
+#define SAD_WS_CONFLICT 7
 int sad_set_option(const char *key, int value);
 
 /* SPEC.md §2.  xyz[B,N,3] -> idx[B,M].  N < 2048 needs no workspace; otherwise pass
@@ -144,6 +160,7 @@ int sad_mlp_pack_f32(int L, const int *dims, int first_has_xyz, const float *con
                      const float *const *bias, float *packed, sad_stream_t stream);
 
 typedef struct sad_mlp_args {
+    size_t struct_size;   /* = sizeof(sad_mlp_args) of the header the caller was built against */
     /* grouped mode (idx != NULL): rows are (b, m, s); input row = [xyz[idx]-new_xyz || feat[idx]] */
     const float *xyz;     /* [B,N,3]                                   (grouped mode) */
     const float *new_xyz; /* [B,M,3]                                   (grouped mode) */
@@ -209,7 +226,7 @@ typedef struct sad_mlp_args {
     int prescanned;
 } sad_mlp_args;
 size_t sad_mlp_workspace_bytes(int B, int M, int S);
-/* Row-packing tables of n (<= 3) chains over the same (B, N, M): cnt[i] [B,M] and idx[i] [B,M,S[i]] from the
+/* Row-packing tables of n (<= SAD_MAX_RADII) chains over the same (B, N, M): cnt[i] [B,M] and idx[i] [B,M,S[i]] from the
  * ball query -> workspace[i] (sad_mlp_workspace_bytes(B, M, S[i]) bytes each, 16-byte aligned).  Two launches
  * for all n.  Pass the workspaces to sad_mlp_chain_f32 with prescanned = 1. */
 int sad_mlp_rowscan(int n, const int32_t *const *cnt, const int32_t *const *idx, const int *S, int B, int N,
@@ -236,6 +253,7 @@ size_t sad_mlp_packed_bytes_bf16(int L, const int *dims, int first_has_xyz);
 int sad_mlp_pack_bf16(int L, const int *dims, int first_has_xyz, const float *const *W,
                       const float *const *bias, void *packed, sad_stream_t stream);
 typedef struct sad_mlp_bf16_args {
+    size_t struct_size;   /* = sizeof(sad_mlp_bf16_args) */
     const float *xyz;     /* [B,N,3] f32                               (grouped mode) */
     const float *new_xyz; /* [B,M,3] f32                               (grouped mode) */
     const int32_t *idx;   /* [B,M,S] or NULL (plain mode)                             */

@@ -24,7 +24,7 @@ def test_header_symbols_exported(sad):
     for n in names:
         assert hasattr(handle, n), f"{n} declared in include/sad_amd.h but not exported"
     assert set(names) == set(_lib.SIGNATURES), "ctypes signature table out of sync with the header"
-    assert _lib.lib().sad_version() == 1
+    assert _lib.lib().sad_version() == _lib.ABI_VERSION == 2
 
 
 def test_no_oracle_in_product_path():
@@ -63,6 +63,50 @@ def test_host_side_argument_errors(sad):
     npad = [256, 512, 1024]
     raw = sum(-(-ci * co // 4) * 4 + -(-co // 4) * 4 for ci, co in zip((259, 256, 512), (256, 512, 1024)))
     assert n == sum(a + a * k for a, k in zip(npad, kp)) + raw   # MFMA fragments + plain k-major copy
+
+
+def test_struct_size_mismatch_is_refused(sad):
+    """a caller built against another header (shorter / longer sad_mlp_args) is refused with SAD_EINVAL
+    before any field behind the common prefix is read; the ctypes mirrors have the C sizes."""
+    from sad_amd import _lib
+    L = _lib.lib()
+    for cls, fn in ((_lib.MlpArgs, L.sad_mlp_chain_f32), (_lib.MlpBf16Args, L.sad_mlp_chain_bf16)):
+        a = cls()
+        a.struct_size = ctypes.sizeof(cls) - 8          # e.g. the round-1 struct without its trailing fields
+        assert fn(ctypes.byref(a), None) == -1
+        assert b"struct_size" in L.sad_last_error()
+        a.struct_size = ctypes.sizeof(cls)              # right size, NULL everything: the next check fails instead
+        assert fn(ctypes.byref(a), None) == -1
+        assert b"struct_size" not in L.sad_last_error()
+
+
+def test_layer_streamed_chain_refuses_rows_beyond_4gib(sad):
+    """mlp_layer_kernel forms row byte offsets in 32 bits; a plain-row call whose rows x stride x 4
+    reaches 4 GiB is refused with SAD_EUNSUPPORTED on the host (nothing is launched, nothing wraps)."""
+    from sad_amd import _lib
+    L = _lib.lib()
+    a = _lib.MlpArgs()
+    a.struct_size = ctypes.sizeof(_lib.MlpArgs)
+    a.feat, a.packed, a.out = 0x10000, 0x20000, 0x30000      # never dereferenced: the call fails on the host
+    a.L, a.S, a.B, a.relu_mask, a.geometry = 1, 1, 1, 1, 3
+    a.dims[0], a.dims[1] = 512, 128
+    a.C, a.ld_feat, a.ld_out = 512, 512, 128
+    a.M = 2 * 1024 * 1024 + 128                               # x 512 floats x 4 bytes = 4 GiB + 256 KiB
+    assert L.sad_mlp_chain_f32(ctypes.byref(a), None) == -2
+    assert b"4 GiB" in L.sad_last_error()
+    # grouped form: 64 nuScenes-sized scenes dense (VERDICT's example): hidden activations 2.1 M rows x 2 KiB
+    g = _lib.MlpArgs()
+    g.struct_size = ctypes.sizeof(_lib.MlpArgs)
+    for f in ("xyz", "new_xyz", "idx", "cnt", "workspace", "feat", "packed", "out", "scratch"):
+        setattr(g, f, 0x10000)
+    g.L, g.B, g.N, g.M, g.S, g.C, g.ld_feat = 3, 64, 2048, 1024, 32, 256, 256
+    for i, d in enumerate((259, 256, 512, 1024)):
+        g.dims[i] = d
+    g.relu_mask, g.geometry, g.ld_out = 7, 3, 1024
+    dims = (ctypes.c_int * 4)(259, 256, 512, 1024)
+    g.scratch_bytes = L.sad_mlp_scratch_bytes(64, 1024, 32, 3, dims)
+    assert L.sad_mlp_chain_f32(ctypes.byref(g), None) == -2
+    assert b"4 GiB" in L.sad_last_error()
 
 
 def test_ops_refuse_cpu_tensors(sad):

@@ -1,0 +1,84 @@
+"""CPU-side checks of `python bench.py --gpus N` starting its own ranks:
+the torchrun command it builds, and the relay of rank 0's JSON line and of the child's exit code."""
+import json
+import os
+import subprocess
+import sys
+import tempfile
+
+from conftest import ROOT
+
+sys.path.insert(0, ROOT)
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _bench():
+    import importlib
+    return importlib.import_module("bench")
+
+
+def test_launch_command_is_torchrun_with_the_same_arguments():
+    b = _bench()
+    argv = ["--gpus", "4", "--steps", "20", "--warmup", "5", "--no-cpu"]
+    cmd = b.launch_command(argv, 4, 29777)
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nnodes=1" in cmd and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29777"
+    i = cmd.index(BENCH)
+    assert cmd[i + 1:] == argv
+    p = b.free_port()
+    assert 1024 < p < 65536
+
+
+def test_self_launch_relays_one_json_line_and_the_exit_code(capfd):
+    b = _bench()
+    line = json.dumps({"metric": "scenes/sec", "value": 1.5, "n_gpus": 2})
+    with tempfile.TemporaryDirectory() as td:
+        child = os.path.join(td, "child.py")
+        with open(child, "w") as f:
+            f.write("import sys\n"
+                    "print('rank chatter')\n"
+                    "print('{\"not\": \"the result\"}')\n"
+                    f"print({line!r})\n"
+                    "sys.stderr.write('warn\\n')\n"
+                    "sys.exit(3)\n")
+        rc = b.self_launch([sys.executable, child])
+        out, err = capfd.readouterr()
+        assert rc == 3
+        assert out.strip() == line                        # exactly one line on stdout: rank 0's result
+        assert "rank chatter" in err and "not" in err
+        quiet = os.path.join(td, "quiet.py")
+        with open(quiet, "w") as f:
+            f.write("print('no result here')\n")
+        rc = b.self_launch([sys.executable, quiet])
+        out, err = capfd.readouterr()
+        assert rc == 1 and out == "" and "no result line" in err
+
+
+def test_parent_launches_before_importing_torch():
+    """`python bench.py --gpus 2` without WORLD_SIZE must start its ranks before anything imports torch (and with it
+    the GPU runtime) in the parent: run it with a stub `torch` on PYTHONPATH whose import FAILS in the parent process
+    and whose `torch.distributed.run` prints the arguments it was started with."""
+    with tempfile.TemporaryDirectory() as td:
+        os.makedirs(os.path.join(td, "torch", "distributed"))
+        with open(os.path.join(td, "torch", "__init__.py"), "w") as f:
+            f.write("import os\n"
+                    "if os.environ.get('SAD_TEST_PARENT_PID') == str(os.getpid()):\n"
+                    "    raise ImportError('the parent imported torch')\n")
+        open(os.path.join(td, "torch", "distributed", "__init__.py"), "w").close()
+        with open(os.path.join(td, "torch", "distributed", "run.py"), "w") as f:
+            f.write("import json, sys\n"
+                    "print(json.dumps({'metric': 'm', 'value': 2.0, 'argv': sys.argv[1:]}))\n")
+        parent = os.path.join(td, "parent.py")
+        with open(parent, "w") as f:
+            f.write("import os, runpy, sys\n"
+                    "os.environ['SAD_TEST_PARENT_PID'] = str(os.getpid())\n"
+                    f"sys.argv = [{BENCH!r}, '--gpus', '2', '--steps', '20', '--warmup', '5']\n"
+                    f"runpy.run_path({BENCH!r}, run_name='__main__')\n")
+        env = dict(os.environ, PYTHONPATH=td)
+        env.pop("WORLD_SIZE", None)
+        r = subprocess.run([sys.executable, parent], env=env, capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, r.stderr[-2000:]
+        rec = json.loads(r.stdout.strip())
+        assert rec["argv"][:2] == ["--nnodes=1", "--nproc-per-node=2"]
+        assert rec["argv"][-6:] == ["--gpus", "2", "--steps", "20", "--warmup", "5"]

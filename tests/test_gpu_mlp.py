@@ -190,6 +190,44 @@ def test_sa_module_msg_dropin_surface(orc, sad, dev):
     _close(nf.transpose(1, 2).cpu().numpy(), onf, "sa_module MSG")
 
 
+def test_sa_module_msg_four_radii(orc, sad, dev):
+    """a 4-radius stage (SAD_MAX_RADII = 4) on the default, non-autotuned path — the row-packing
+    prescan serves four chains; branches 0-2 have compiled register-resident shapes, branch 3 ([48, 80]) has none
+    and runs the tiled kernel, which must get no prescanned table.  Bit-exact vs the oracle."""
+    from sad_amd import config, ops
+    from sad_amd import synth
+    from sad_amd.sa_module import SAModuleMSG
+    assert not ops.AUTOTUNE
+    st = config.SAStage(256, (0.8, 1.6, 2.4, 3.2), (32, 32, 64, 16),
+                        ((64, 64, 128), (64, 64, 128), (64, 96, 128), (48, 80)), 96)
+    rng = np.random.default_rng(11)
+    w = {f"b{i}": synth.make_mlp_weights([64 + 3] + list(m), rng) for i, m in enumerate(st.mlps)}
+    w["agg"] = synth.make_mlp_weights([sum(m[-1] for m in st.mlps), st.agg], rng)
+    pts = synth.make_tiny_batch(70, 2, 1024)
+    xyz = np.ascontiguousarray(pts[:, :, :3])
+    feat_cm = rng.normal(size=(2, 64, 1024)).astype(np.float32)
+    mod = SAModuleMSG(64, st, dev, w)
+    X = _t(xyz, dev)
+    q = mod.query(X, X[:, :st.npoint].contiguous(), prescan=True)
+    assert [t is not None for t in q[2]] == [True, True, True, False], "prescan tables: only for kernels that consume them"
+    nx, nf = mod(X, _t(feat_cm, dev))
+    ow = {f"sa.b{i}": w[f"b{i}"] for i in range(4)}
+    ow["sa.agg"] = w["agg"]
+    onx, onf = orc.sa_module(xyz, np.ascontiguousarray(feat_cm.transpose(0, 2, 1)), st, ow, "sa", {})
+    np.testing.assert_array_equal(nx.cpu().numpy(), onx)
+    assert np.array_equal(nf.transpose(1, 2).cpu().numpy(), onf), "4-radius SA module differs from the oracle"
+    # four chains of one compiled shape family: the prescan really carries four tables
+    st4 = config.SAStage(256, (0.8, 1.6, 2.4, 3.2), (32, 32, 64, 32),
+                         ((64, 64, 128), (64, 64, 128), (64, 96, 128), (64, 64, 128)), 0)
+    w4 = {f"b{i}": synth.make_mlp_weights([64 + 3] + list(m), rng) for i, m in enumerate(st4.mlps)}
+    mod4 = SAModuleMSG(64, st4, dev, w4)
+    q4 = mod4.query(X, X[:, :st4.npoint].contiguous(), prescan=True)
+    assert all(t is not None for t in q4[2])
+    nx4, nf4 = mod4(X, _t(feat_cm, dev))
+    onx4, onf4 = orc.sa_module(xyz, np.ascontiguousarray(feat_cm.transpose(0, 2, 1)), st4, {f"sa.b{i}": w4[f"b{i}"] for i in range(4)}, "sa", {})
+    assert np.array_equal(nf4.transpose(1, 2).cpu().numpy(), onf4)
+
+
 @pytest.mark.parametrize("overlap", [False, True])
 def test_detector_tiny_end_to_end(orc, sad, dev, overlap):
     """3 SA stages -> size-adaptive cluster layer -> head, TINY topology, vs oracle and golden."""
@@ -548,13 +586,117 @@ def test_cooperative_three_chain_dispatch(orc, sad, dev):
         assert np.array_equal(got[:, :, 256 * bi:256 * (bi + 1)], wants[bi]), f"branch {bi}"
 
 
-def test_cooperative_dispatch_rearms_its_item_queues(orc, sad, dev):
+def test_cooperative_steal_refill_is_exercised(orc, sad, dev):
+    """the cross-queue steal + weight-ring refill branch of mlp_coop_kernel (csrc/mlp_coop.hip; the
+    intermittent wrong-rows bug fixed in 4c2dbaa lived there) normally runs only at the tail of a dispatch, when a
+    workgroup whose own queue is empty takes an item of another chain than the one whose first stages it prefetched.
+    ``mlp_steal_after`` makes every workgroup take its items from the OTHER queues from the start (v = 1) or after
+    two own items (v = 3), one at a time, so the branch runs at every chain change of every workgroup; the refill
+    counter in the table header proves it ran.  Three chains of different shapes, bit-exact vs the oracle (SPEC.md §6)."""
+    import torch
+    from sad_amd import _lib, ops, synth
+    rng = np.random.default_rng(4242)
+    B, N, M, C = 4, 1024, 512, 128
+    xyz = rng.uniform(0, 1, (B, N, 3)).astype(np.float32)
+    feat = rng.normal(size=(B, N, C)).astype(np.float32)
+    new_xyz = np.ascontiguousarray(xyz[:, :M])
+    X, F, Cn = _t(xyz, dev), _t(feat, dev), _t(new_xyz, dev)
+    radii, ns = (0.45, 0.6, 0.8), (32, 32, 32)          # mostly full groups: ~500 work items per chain
+    mlps = ([128, 128, 256], [128, 192, 256], [128, 256, 256])
+    idxs, cnts = ops.ball_query_multi(radii, ns, X, Cn, return_counts=True)
+    nets, wants = [], []
+    for bi, mlp in enumerate(mlps):
+        layers = synth.make_mlp_weights([C + 3] + mlp, rng)
+        net = ops.PackedMLP(layers, True, dev)
+        net.default_geometry = 4
+        nets.append(net)
+        wants.append(orc.sa_group_mlp_max(xyz, feat, new_xyz, idxs[bi].cpu().numpy(), layers))
+    want = np.concatenate(wants, axis=2)
+    items = [int(-(-int(c.clamp(min=1).sum().item()) // 128)) for c in cnts]
+
+    def run(wss):
+        out = torch.zeros((B, M, 768), device=dev)
+        ops.grouped_multi([(nets[bi], X, F, Cn, idxs[bi], out, 256 * bi, cnts[bi], wss[bi]) for bi in range(3)])
+        return out.cpu().numpy()
+
+    def refills(wss):
+        return sum(ops.workspace_status(w)["refills"] for w in wss)
+
+    wss = ops.rowscan_multi(idxs, cnts, N)
+    base = run(wss)
+    assert np.array_equal(base, want), "plain dispatch"
+    r_plain = refills(wss)
+    _lib.set_option("mlp_dyn_slots", 1)                  # 256 workgroups: several items each
+    try:
+        for v in (1, 3):
+            _lib.set_option("mlp_steal_after", v)
+            wss = ops.rowscan_multi(idxs, cnts, N)
+            for rep in range(3):                         # the same tables again: the queues are re-armed in this mode too
+                got = run(wss)
+                assert np.array_equal(got, want), f"mlp_steal_after={v}, launch {rep}: max diff {np.abs(got - want).max():.3e}"
+            r = refills(wss)
+            print(f"[steal/refill] items per chain {items}, mlp_steal_after={v}: {r} ring refills in 3 launches "
+                  f"(plain dispatch: {r_plain}), bit-exact")
+            assert r >= 3 * 64, f"mlp_steal_after={v}: the refill branch ran only {r} times"
+    finally:
+        _lib.set_option("mlp_steal_after", 0)
+        _lib.set_option("mlp_dyn_slots", 0)
+
+
+def test_workspace_in_use_marker(orc, sad, dev):
+    """"one dispatch at a time per row-packing workspace" is checked, not only documented: with
+    ``mlp_check_inuse`` a dispatch that finds another dispatch's id in the queue header raises the conflict flag
+    (forged here, so the test does not depend on two launches really overlapping); an undisturbed dispatch leaves the
+    header clean and releases it."""
+    import torch
+    from sad_amd import _lib, ops, synth
+    rng = np.random.default_rng(17)
+    B, N, M, C = 2, 1024, 512, 128
+    xyz = rng.uniform(0, 1, (B, N, 3)).astype(np.float32)
+    feat = rng.normal(size=(B, N, C)).astype(np.float32)
+    X, F = _t(xyz, dev), _t(feat, dev)
+    Cn = X[:, :M].contiguous()
+    idxs, cnts = ops.ball_query_multi((0.3,), (32,), X, Cn, return_counts=True)
+    net = ops.PackedMLP(synth.make_mlp_weights([C + 3, 128, 128, 256], rng), True, dev)
+    net.default_geometry = 4
+    _lib.set_option("mlp_check_inuse", 1)
+    try:
+        ws = ops.rowscan_multi(idxs, cnts, N)[0]
+        ref = net.grouped(X, F, Cn, idxs[0], cnt=cnts[0], ws=ws)
+        st = ops.workspace_status(ws)
+        assert st["conflict"] == 0 and st["in_use"] == 0, st
+        ops.check_workspace(ws)
+        ws.view(torch.int32)[_lib.WS_INUSE] = 0x12345          # "another dispatch owns these queues"
+        net.grouped(X, F, Cn, idxs[0], cnt=cnts[0], ws=ws)
+        st = ops.workspace_status(ws)
+        assert st["conflict"] == 1, st
+        with pytest.raises(RuntimeError, match="two dispatches"):
+            ops.check_workspace(ws)
+        assert st["in_use"] == 0, "the last workgroup out releases the marker"
+        ws2 = ops.rowscan_multi(idxs, cnts, N)[0]              # a fresh table: clean again, same result
+        again = net.grouped(X, F, Cn, idxs[0], cnt=cnts[0], ws=ws2)
+        assert ops.workspace_status(ws2)["conflict"] == 0 and torch.equal(again, ref)
+    finally:
+        _lib.set_option("mlp_check_inuse", 0)
+
+
+@pytest.mark.parametrize("steal_after", [0, 1])
+def test_cooperative_dispatch_rearms_its_item_queues(orc, sad, dev, steal_after):
     """The cooperative kernel pulls its work items from per-XCD queues in the header of the row-packing table and
     the last workgroup out re-arms them: the same prescanned tables serve any number of launches (a queue left
     exhausted would make the next launch compute nothing), also when two streams run dispatches side by side on
-    tables of their own."""
+    tables of their own.  ``steal_after=1``: the same with every item taken from another XCD's queue (the steal /
+    refill path, see test_cooperative_steal_refill_is_exercised)."""
     import torch
-    from sad_amd import ops, synth
+    from sad_amd import _lib, ops, synth
+    _lib.set_option("mlp_steal_after", steal_after)
+    try:
+        _rearm_body(orc, dev, torch, ops, synth)
+    finally:
+        _lib.set_option("mlp_steal_after", 0)
+
+
+def _rearm_body(orc, dev, torch, ops, synth):
     rng = np.random.default_rng(99)
     B, N, M, C = 4, 1024, 512, 128
     xyz = rng.uniform(0, 1, (B, N, 3)).astype(np.float32)
