@@ -52,7 +52,7 @@ class MlpBf16Args(ctypes.Structure):
         ("L", ctypes.c_int), ("dims", ctypes.c_int * (MAX_LAYERS + 1)),
         ("packed", vp), ("relu_mask", ctypes.c_int),
         ("out", vp), ("out_bf16", ctypes.c_int), ("ld_out", ctypes.c_int), ("col_off", ctypes.c_int),
-        ("cnt", vp), ("workspace", vp), ("geometry", ctypes.c_int),
+        ("cnt", vp), ("workspace", vp), ("geometry", ctypes.c_int), ("prescanned", ctypes.c_int),
     ]
 
 
@@ -99,6 +99,7 @@ SIGNATURES = {
     "sad_mlp_packed_bytes_bf16": (ctypes.c_size_t, [ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.c_int]),
     "sad_mlp_pack_bf16": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.c_int,
                                         ctypes.POINTER(vp), ctypes.POINTER(vp), vp, vp]),
+    "sad_mlp_preferred_geometry_bf16": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(ctypes.c_int)]),
     "sad_mlp_chain_bf16": (ctypes.c_int, [ctypes.POINTER(MlpBf16Args), vp]),
     "sad_mlp_chain_multi_bf16": (ctypes.c_int, [ctypes.POINTER(ctypes.POINTER(MlpBf16Args)), ctypes.c_int, vp]),
     "sad_candidates_f32": (ctypes.c_int, [vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int,

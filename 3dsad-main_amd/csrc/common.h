@@ -79,6 +79,31 @@ int launch_reg(const RegMulti &mp, hipStream_t st);
 bool coop_shape(int shape);
 long long coop_stream_frags(int shape, const int *kp, const int *np);   // fragments (1 KB) of the stream image, 0 = none
 int launch_coop(const RegMulti &mp, hipStream_t st);
+// Register-resident bf16 chain kernel (csrc/mlp_bf16_reg.hip): one chain of a dispatch / up to REG_MAX_CHAINS chains
+struct BfRegChain {
+    const float *xyz, *new_xyz;
+    const void *feat;              // point-major rows, bf16 (feat_bf16) or f32
+    int feat_bf16, ld_feat, C;     // ld_feat in elements
+    const void *stream;            // fragment stream image (sad_mlp_pack_bf16)
+    int stream_frags;              // its 1-KB fragments (filled by launch_bfreg)
+    const float *bias[3];          // padded to multiples of 32
+    int np[3];                     // padded output channels of layer l
+    float *out;
+    int ld_out, col_off, cout_last;
+    const int *rowtab, *row_src, *row_gid;
+};
+struct BfRegMulti {
+    BfRegChain c[REG_MAX_CHAINS];
+    int shape[REG_MAX_CHAINS];
+    int n;
+    long long max_tiles;
+    int static_f4;                 // family 0: float4 of all chains' stream images held in LDS (filled by launch_bfreg)
+};
+int bfreg_shape_id(int L, const int *dims);        // dims = {C + 3, C1, C2, C3}; -1: no compiled shape
+int bfreg_family(int shape);
+long long bfreg_stream_frags(int shape);           // 1-KB fragments of the stream image (whole stages)
+int bfreg_pack(int shape, const int *dims, int first_has_xyz, const float *const *W, void *dst, hipStream_t st);
+int launch_bfreg(const BfRegMulti &mp, hipStream_t st);
 enum { OPT_FPS_DPP = 0, OPT_MLP_RW = 1, OPT_MLP_BUDGET_KB = 2, OPT_BQ_VARIANT = 3, OPT_FPS_VARIANT = 4, OPT_MLP_FORCE = 5, OPT_MLP_DEDUP_F = 6, OPT_MLP_NODEDUP = 7, OPT_FPS_THREADS = 8, OPT_MLP_STATIC = 9, OPT_GROUP_VARIANT = 10, OPT_MLP_DYN_SLOTS = 11, OPT_MLP_NOXCD = 12, OPT_MLP_STEAL_AFTER = 13, OPT_MLP_CHECK_INUSE = 14, OPT_COUNT };
 
 inline int fail(int code, const char *fmt, ...) {

@@ -465,15 +465,26 @@ inline size_t align16(size_t v) { return (v + 15) & ~(size_t)15; }
 
 }  // namespace
 
-SAD_API size_t sad_mlp_packed_bytes_bf16(int L, const int *dims, int first_has_xyz) {
-    (void)first_has_xyz;
-    if (L < 1 || L > SAD_MAX_LAYERS || !dims) return 0;
+// bytes of the per-layer images (fragment image + padded bias of every layer); the stream image of the register-resident
+// chain kernel (mlp_bf16_reg.hip) follows them for grouped 3-layer chains with a compiled shape
+static size_t layer_images_bytes(int L, const int *dims) {
     size_t n = 0;
     for (int l = 0; l < L; ++l) {
         const int CT = (dims[l + 1] + 31) / 32;
         n += align16((size_t)CT * 32 * kpad(l, dims[l]) * 2) + align16((size_t)CT * 32 * 4);
     }
     return n;
+}
+
+SAD_API size_t sad_mlp_packed_bytes_bf16(int L, const int *dims, int first_has_xyz) {
+    if (L < 1 || L > SAD_MAX_LAYERS || !dims) return 0;
+    size_t n = layer_images_bytes(L, dims);
+    if (first_has_xyz) n += (size_t)sad::bfreg_stream_frags(sad::bfreg_shape_id(L, dims)) * 1024;
+    return n;
+}
+
+SAD_API int sad_mlp_preferred_geometry_bf16(int L, const int *dims) {
+    return sad::bfreg_shape_id(L, dims) >= 0 ? 2 : 0;
 }
 
 SAD_API int sad_mlp_pack_bf16(int L, const int *dims, int first_has_xyz, const float *const *W,
@@ -492,6 +503,11 @@ SAD_API int sad_mlp_pack_bf16(int L, const int *dims, int first_has_xyz, const f
         hipLaunchKernelGGL(pack_bf16_kernel, dim3(64), dim3(256), 0, (hipStream_t)stream, W[l], bias[l], dims[l],
                            dims[l + 1], kp, (l == 0 && first_has_xyz) ? 1 : 0, wout, bout);
     }
+    if (first_has_xyz) {
+        const int shape = sad::bfreg_shape_id(L, dims);
+        if (shape >= 0)
+            if (int e = sad::bfreg_pack(shape, dims, 1, W, (unsigned char *)packed + layer_images_bytes(L, dims), (hipStream_t)stream)) return e;
+    }
     return sad::check_launch("sad_mlp_pack_bf16");
 }
 
@@ -500,6 +516,12 @@ struct BfPrepared {
     BfParams p;
     size_t lds;
     int grid;
+    bool reg;               // geometry 2: register-resident chain (mlp_bf16_reg.hip); `rc` is filled, p is not
+    sad::BfRegChain rc;
+    int reg_shape;
+    long long reg_tiles;
+    sad::ScanJob scan;      // row-packing scan the chain needs before its kernel ...
+    bool prescanned;        // ... unless the caller ran sad_mlp_rowscan on the workspace
 };
 }  // namespace
 
@@ -532,6 +554,41 @@ static int prepare_bf16(const sad_mlp_bf16_args *a, sad_stream_t stream, BfPrepa
     p.N = a->N; p.M = a->M; p.S = a->S; p.C = a->C;
     p.L = a->L; p.relu_mask = a->relu_mask;
     p.out = a->out; p.out_bf16 = a->out_bf16; p.ld_out = a->ld_out; p.col_off = a->col_off;
+    prep.reg = false;
+    prep.prescanned = a->prescanned != 0;
+    if (a->geometry == 2) {
+        // ---- register-resident chain: one wave per 32-row tile, activations in registers, weights through an LDS ring ----
+        const int shape = grouped ? sad::bfreg_shape_id(a->L, a->dims) : -1;
+        const bool vec = a->feat_bf16 && (a->C & 7) == 0 && (a->ld_feat & 7) == 0 && a->C >= 8;
+        if (shape < 0 || !a->cnt || !a->workspace || (a->dims[0] > 16 && !vec))
+            return sad::fail(SAD_EUNSUPPORTED, "sad_mlp_chain_bf16: geometry 2 (register-resident chain) needs a compiled grouped 3-layer shape, "
+                                               "cnt + workspace and, for more than 13 feature channels, 16-byte bf16 feature rows");
+        SAD_REQUIRE((uintptr_t)a->workspace % 16 == 0, "sad_mlp_chain_bf16: workspace must be 16-byte aligned");
+        SAD_REQUIRE(!vec || (uintptr_t)a->feat % 16 == 0, "sad_mlp_chain_bf16: feat must be 16-byte aligned");
+        SAD_REQUIRE((long long)a->B * a->M < (1LL << 30), "sad_mlp_chain_bf16: too many groups");
+        SAD_REQUIRE((long long)a->B * a->N < (1LL << 31), "sad_mlp_chain_bf16: B*N too large");
+        const int ngroups = a->B * a->M;
+        int *tab = (int *)a->workspace;
+        prep.scan = sad::make_scan_job(a->cnt, ngroups, a->S, 32, tab, 0, a->idx, a->N, a->M);
+        sad::BfRegChain &rc = prep.rc;
+        rc = sad::BfRegChain{};
+        rc.xyz = a->xyz; rc.new_xyz = a->new_xyz; rc.feat = a->feat; rc.feat_bf16 = a->feat_bf16; rc.ld_feat = a->ld_feat; rc.C = a->C;
+        const unsigned char *q = (const unsigned char *)a->packed;
+        for (int l = 0; l < 3; ++l) {
+            const int CT = (a->dims[l + 1] + 31) / 32;
+            q += align16((size_t)CT * 32 * kpad(l, a->dims[l]) * 2);
+            rc.bias[l] = (const float *)q;
+            rc.np[l] = CT * 32;
+            q += align16((size_t)CT * 32 * 4);
+        }
+        rc.stream = q;
+        rc.out = (float *)a->out; rc.ld_out = a->ld_out; rc.col_off = a->col_off; rc.cout_last = a->dims[3];
+        rc.rowtab = tab; rc.row_src = prep.scan.row_src; rc.row_gid = prep.scan.row_gid;
+        prep.reg = true;
+        prep.reg_shape = shape;
+        prep.reg_tiles = ((long long)ngroups * a->S + 31) / 32;
+        return SAD_OK;
+    }
     const bool packed = grouped && a->cnt && a->workspace;
     if (packed) {
         SAD_REQUIRE((uintptr_t)a->workspace % 16 == 0, "sad_mlp_chain_bf16: workspace must be 16-byte aligned");
@@ -555,7 +612,7 @@ static int prepare_bf16(const sad_mlp_bf16_args *a, sad_stream_t stream, BfPrepa
     const size_t budget = 150 * 1024;
     int R = 128;
     auto lds_of = [&](int r) { return (((size_t)r * 2 * (ldA + ldB) + 15) & ~(size_t)15) + (size_t)(2 * r + 4) * sizeof(int); };
-    if (a->geometry) {     // forced rows per tile (autotuners): 32 / 64 / 128 / 256
+    if (a->geometry) {     // forced rows per tile (autotuners): 32 / 64 / 128 / 256 (2 = the register-resident chain, above)
         SAD_REQUIRE(a->geometry == 32 || a->geometry == 64 || a->geometry == 128 || a->geometry == 256,
                     "sad_mlp_chain_bf16: geometry (rows per tile) must be 32, 64, 128 or 256");
         R = a->geometry;
@@ -593,9 +650,31 @@ static void bf16_attrs() {
     sad::lds_attr_once(attr_done2, reinterpret_cast<const void *>(&mlp_bf16_multi_kernel), 160 * 1024);
 }
 
+// register-resident chains of one shape family (<= REG_MAX_CHAINS): pending scans in one pair of launches, then one dispatch
+static int launch_bfreg_chains(const BfPrepared *const *qs, int n, hipStream_t st) {
+    sad::ScanJob jobs[sad::REG_MAX_CHAINS];
+    int m = 0;
+    for (int i = 0; i < n; ++i)
+        if (!qs[i]->prescanned) jobs[m++] = qs[i]->scan;
+    if (m)
+        if (int e = sad::launch_rowscan_multi(jobs, m, st)) return e;
+    sad::BfRegMulti mp{};
+    mp.n = n;
+    for (int i = 0; i < n; ++i) {
+        mp.c[i] = qs[i]->rc;
+        mp.shape[i] = qs[i]->reg_shape;
+        mp.max_tiles += qs[i]->reg_tiles;
+    }
+    return sad::launch_bfreg(mp, st);
+}
+
 SAD_API int sad_mlp_chain_bf16(const sad_mlp_bf16_args *a, sad_stream_t stream) {
     BfPrepared q;
     if (int e = prepare_bf16(a, stream, q)) return e;
+    if (q.reg) {
+        const BfPrepared *one = &q;
+        return launch_bfreg_chains(&one, 1, (hipStream_t)stream);
+    }
     bf16_attrs();
     hipLaunchKernelGGL(mlp_bf16_kernel, dim3(q.grid), dim3(BF_T), q.lds, (hipStream_t)stream, q.p);
     return sad::check_launch("sad_mlp_chain_bf16");
@@ -611,6 +690,33 @@ SAD_API int sad_mlp_chain_multi_bf16(const sad_mlp_bf16_args *const *args, int n
     BfPrepared q[BF_MULTI_MAX];
     for (int i = 0; i < n; ++i)
         if (int e = prepare_bf16(args[i], stream, q[i])) return e;
+    {   // register-resident chains: one dispatch per shape family, heaviest chain first
+        bool any_reg = false;
+        for (int i = 0; i < n; ++i) any_reg = any_reg || q[i].reg;
+        if (any_reg) {
+            bool done[BF_MULTI_MAX] = {};
+            for (int i = 0; i < n; ++i) {
+                if (done[i]) continue;
+                if (!q[i].reg) {
+                    bf16_attrs();
+                    hipLaunchKernelGGL(mlp_bf16_kernel, dim3(q[i].grid), dim3(BF_T), q[i].lds, (hipStream_t)stream, q[i].p);
+                    if (int e = sad::check_launch("sad_mlp_chain_bf16")) return e;
+                    done[i] = true;
+                    continue;
+                }
+                const BfPrepared *ord[sad::REG_MAX_CHAINS];
+                int m = 0;
+                for (int k = i; k < n && m < sad::REG_MAX_CHAINS; ++k)
+                    if (!done[k] && q[k].reg && sad::bfreg_family(q[k].reg_shape) == sad::bfreg_family(q[i].reg_shape)) { ord[m++] = &q[k]; done[k] = true; }
+                auto heavy = [](const BfPrepared *s) { return (double)sad::bfreg_stream_frags(s->reg_shape) * (double)s->reg_tiles; };
+                for (int x = 0; x < m; ++x)
+                    for (int y = x + 1; y < m; ++y)
+                        if (heavy(ord[y]) > heavy(ord[x])) { const BfPrepared *t = ord[x]; ord[x] = ord[y]; ord[y] = t; }
+                if (int e = launch_bfreg_chains(ord, m, (hipStream_t)stream)) return e;
+            }
+            return SAD_OK;
+        }
+    }
     bf16_attrs();
     if (n == 1) {
         hipLaunchKernelGGL(mlp_bf16_kernel, dim3(q[0].grid), dim3(BF_T), q[0].lds, (hipStream_t)stream, q[0].p);

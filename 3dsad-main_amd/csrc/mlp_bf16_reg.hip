@@ -1,0 +1,496 @@
+// Register-resident fused group -> shared-MLP -> max-pool in bfloat16 on the gfx950 matrix cores: "geometry 2" of
+// sad_mlp_chain_bf16 (SPEC.md §14, BASELINE.json configs[4]).  No reference source exists
+// (/root/reference/README.md:1-2 is the whole upstream repository).
+//
+// mlp_bf16.hip (round 1) keeps a tile's activations in LDS, streams every weight fragment L2 -> VGPR per wave and
+// max-pools with one atomic per (row run, channel): at v_mfma_f32_32x32x16_bf16 rates (32 cycles per 32x32x16
+// product) it spent ~50 us per 128-row tile of which ~3 us were MFMAs.  Here ONE WAVE carries a tile of 32 packed rows
+// through a 3-layer chain and the activations never leave its registers:
+//   * a hidden layer runs as D[cout, row] = W . X^T: the row stays on the lane, the 32 output channels of a tile land
+//     in the 16 accumulator registers, and ReLU + v_cvt_pk_bf16 turn registers 8s .. 8s+7 into the operand of k-step s
+//     of the next layer IN PLACE (no lane movement, no LDS): element j of lane half h is channel 16s + 8(j>>2) + 4h +
+//     (j&3) of the tile, so the next layer's weight fragments are stored with their k in that order (pack time);
+//   * the last layer runs as D[row, cout] = X . W^T: the channel is on the lane and a lane half holds 16 rows in its 16
+//     registers.  Lane r carries packed row pi(r) = 16*((r>>2)&1) + 4*(r>>3) + (r&3) of the tile from the gather on,
+//     which makes those 16 rows CONSECUTIVE rows of the packed order (rows 16h .. 16h+15 in register order): max-pooling
+//     the rows of a group is a running max across registers with wave-half-uniform group boundaries, and a group's result
+//     leaves as one 128-byte store per lane half (an atomic max only for a group that continues in another half-tile);
+//   * the weight fragments of a tile form one fixed stream; the waves of a workgroup walk their tiles in lockstep and
+//     share the stream through a three-slot LDS ring (one global load per wave and NW fragments, prefetched two stages
+//     ahead, never drained: the last stages of an item fetch the first of the next);
+//   * the layer-0 operand is gathered straight from the bf16 feature rows in fragment form (16-byte loads), the relative
+//     coordinates are formed in binary32 and rounded once (SPEC.md §14).
+// Accumulation is binary32 inside the matrix core; SPEC §14 leaves its order free: parity is a stated tolerance.
+#include "common.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+using sad::BfRegChain;
+using sad::BfRegMulti;
+
+constexpr int WHOLE_BIT = 1 << 30;
+constexpr int RS = 16;               // fragments (1 KB each) per ring stage
+constexpr int RNS = 3;               // ring slots: being read / complete / being written
+constexpr int RING_F4 = RNS * RS * 64;
+constexpr int PFD = 4;               // ring reads run this many fragments ahead of the MFMA that consumes them
+
+__device__ __forceinline__ void atomic_max_pos(float *addr, float v) {
+    atomicMax(reinterpret_cast<unsigned *>(addr), __builtin_bit_cast(unsigned, v));
+}
+
+__device__ __forceinline__ bf16x8 as_bf(const float4 v) { return __builtin_bit_cast(bf16x8, v); }
+
+// ReLU + round: registers 8s .. 8s+7 of a hidden tile -> operand of k-step s of the next layer
+__device__ __forceinline__ bf16x8 pack8(const f32x16 &t, int s) {
+    bf16x8 v;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float f = t[8 * s + j];
+        v[j] = (__bf16)(f > 0.f ? f : 0.f);
+    }
+    return v;
+}
+
+struct Ring {
+    float4 *ring;       // [RNS][RS][64 lanes]
+    int slot;           // slot of the stage being consumed (wave-uniform)
+};
+
+// Pooling bookkeeping of one tile for this lane's half (rows 16h .. 16h+15 of the tile, in register order)
+struct PoolInfo {
+    unsigned cont;      // bit i: row i continues the group of row i - 1 (bit 0 clear)
+    unsigned ends;      // bit i: row i is live and the last row of its group inside this half
+    unsigned atom;      // bit i (ends only): the group has rows outside this half -> atomic max
+    float *optr;        // out + group(first row) * ld_out + col_off + (lane & 31)
+};
+
+// STATICW: the chain's whole fragment stream sits in LDS for the lifetime of the workgroup (the narrow first-stage chains:
+// 3 - 22 fragments) — no ring, no barriers, the waves of a workgroup are independent; `rs.ring` then points at that image.
+template <int KS0, int NO0, int NO1, int NO2, bool VEC0, int NW, bool STATICW>
+__device__ __forceinline__ void br_tile(const BfRegChain &c, const int tile, const float *__restrict__ sbias, const int lane, const int wave,
+                                        Ring &rs, const float4 *__restrict__ sbase, const float4 *__restrict__ nbase) {
+    constexpr int KS1 = 2 * NO0, KS2 = 2 * NO1;
+    constexpr int P0 = NO0 * KS0, P1 = NO1 * KS1, P2 = NO2 * KS2, P = P0 + P1 + P2;
+    constexpr int NSTG = (P + RS - 1) / RS;
+    constexpr int FPW = RS / NW;
+    constexpr bool ROLL2 = (KS2 % RS == 0) && NO2 > 4;      // layer-2 tiles span whole stages: loop over them stays rolled
+    const int r = lane & 31, h = lane >> 5;
+    const int total = c.rowtab[0];
+    // ---- rows: lane r carries packed row pi(r) of the tile --------------------------------------------------
+    const int rho = 16 * ((r >> 2) & 1) + 4 * (r >> 3) + (r & 3);
+    int q = tile * 32 + rho;
+    if (q >= total) q = total - 1;                  // rows past the end (and whole tiles past it) repeat the last row and store nothing
+    const int src = c.row_src[q];
+    const int grp = c.row_gid[q] & (WHOLE_BIT - 1);
+    float rel[3];
+    {
+        const float *pq = c.xyz + (long long)src * 3;
+        const float *pc = c.new_xyz + (long long)grp * 3;
+        rel[0] = pq[0] - pc[0]; rel[1] = pq[1] - pc[1]; rel[2] = pq[2] - pc[2];
+    }
+    // ---- layer-0 operand: k-step ks, half h = 16-byte chunk 2 ks + h of [feat(C) | dx dy dz | 0 ...] ----------
+    bf16x8 x0[KS0];
+    {
+        const int C = c.C;
+#pragma unroll
+        for (int ks = 0; ks < KS0; ++ks) {
+            bf16x8 v = {};
+            const int ch = 2 * ks + h;
+            if constexpr (VEC0) {                    // bf16 rows, C % 8 == 0: whole chunks
+                const __bf16 *row = reinterpret_cast<const __bf16 *>(c.feat) + (long long)src * c.ld_feat;
+                if (ch * 8 < C) v = *reinterpret_cast<const bf16x8 *>(row + ch * 8);
+                else if (ch * 8 == C) { v[0] = (__bf16)rel[0]; v[1] = (__bf16)rel[1]; v[2] = (__bf16)rel[2]; }
+            } else {                                 // any layout (narrow first stage): element by element
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int k = ch * 8 + j;
+                    float f = 0.f;
+                    if (k < C) {
+                        f = c.feat_bf16 ? (float)reinterpret_cast<const __bf16 *>(c.feat)[(long long)src * c.ld_feat + k]
+                                        : reinterpret_cast<const float *>(c.feat)[(long long)src * c.ld_feat + k];
+                    } else if (k < C + 3) {
+                        f = k == C ? rel[0] : (k == C + 1 ? rel[1] : rel[2]);
+                    }
+                    v[j] = (__bf16)f;
+                }
+            }
+            x0[ks] = v;
+        }
+    }
+    // ---- pooling bookkeeping (lane t < 32 looks at tile row t in natural order; both halves compute the same) ----
+    PoolInfo pi;
+    {
+        int qt = tile * 32 + r;
+        const bool live = qt < total;
+        if (!live) qt = total - 1;
+        const int gv = c.row_gid[qt];
+        const int g = gv & (WHOLE_BIT - 1);
+        const int gprev = __shfl_up(g, 1, 64), gnext = __shfl_down(g, 1, 64);
+        const int lnext = __shfl_down((int)live, 1, 64);
+        const bool same_prev = r > 0 && gprev == g;
+        const bool real_end = r == 31 || !lnext || gnext != g;           // the group's last row (in this tile)
+        const bool end = live && (real_end || (r & 15) == 15);           // ... or the last row of a half: flushed there too
+        const unsigned contm = (unsigned)__ballot(same_prev && lane < 32);
+        // start of this row's run inside the tile: highest t' <= t whose cont bit is clear
+        const unsigned starts = ~contm & (0xFFFFFFFFu >> (31 - r));
+        const int a = 31 - __builtin_clz(starts);
+        // plain store only when every row of the group lies in this half of this tile
+        const bool inhalf = (gv & WHOLE_BIT) != 0 && (a >> 4) == (r >> 4) && real_end;
+        const unsigned endm = (unsigned)__ballot(end && lane < 32);
+        const unsigned atomm = (unsigned)__ballot(end && !inhalf && lane < 32);
+        pi.cont = (contm >> (16 * h)) & 0xFFFEu;
+        pi.ends = (endm >> (16 * h)) & 0xFFFFu;
+        pi.atom = (atomm >> (16 * h)) & 0xFFFFu;
+        const int g0 = __builtin_amdgcn_readlane(g, 0), g16 = __builtin_amdgcn_readlane(g, 16);
+        pi.optr = c.out + (long long)(h ? g16 : g0) * c.ld_out + c.col_off + r;
+    }
+    const float *sb0 = sbias, *sb1 = sbias + NO0 * 32, *sb2 = sb1 + NO1 * 32;
+
+    // ---- the ring ---------------------------------------------------------------------------------------------
+    float4 *const ring = rs.ring;
+    int slot = rs.slot;
+    int srel = 0;
+    static_assert(FPW == 2 || FPW == 4, "two or four fragments per wave and stage");
+    float4 T0, T1, T2, T3;                          // this wave's fragments of stage srel + 2, in flight (named: an array
+    T2 = T3 = make_float4(0.f, 0.f, 0.f, 0.f);      // captured by the lambdas below may end up in scratch)
+    const unsigned ulane = (unsigned)lane;
+    auto stage_begin = [&]() {
+        if constexpr (STATICW) return;
+        const int s2 = srel + 2;
+        const float4 *sp = s2 < NSTG ? sbase + (size_t)(s2 * RS + FPW * wave) * 64 : nbase + (size_t)((s2 - NSTG) * RS + FPW * wave) * 64;
+        T0 = sp[ulane];
+        T1 = (sp + 64)[ulane];
+        if constexpr (FPW == 4) {
+            T2 = (sp + 128)[ulane];
+            T3 = (sp + 192)[ulane];
+        }
+    };
+    auto stage_end = [&]() {
+        if constexpr (STATICW) return;
+        const int ws = slot + 2 >= RNS ? slot + 2 - RNS : slot + 2;
+        float4 *wp = ring + (ws * RS + FPW * wave) * 64 + lane;
+        wp[0] = T0;
+        wp[64] = T1;
+        if constexpr (FPW == 4) {
+            wp[128] = T2;
+            wp[192] = T3;
+        }
+        __syncthreads();
+        slot = slot + 1 == RNS ? 0 : slot + 1;
+        ++srel;
+    };
+    // fragment at position pp of this tile's stream, read while position p0 is being consumed (pp >= p0)
+    auto frag_at = [&](int pp, int p0) -> float4 {
+        if constexpr (STATICW) return ring[pp * 64 + lane];          // (the image is padded to whole stages: pp < P + RS)
+        int sl = slot + (pp / RS - p0 / RS);                          // the stage 0 / 1 ahead of the one being consumed
+        sl = sl >= RNS ? sl - RNS : sl;
+        return ring[(sl * RS + pp % RS) * 64 + lane];
+    };
+    float4 a[PFD];
+#pragma unroll
+    for (int u = 0; u < PFD; ++u) a[u] = frag_at(u, 0);
+    // one fragment position: the weight operand of position p, the read PFD positions ahead, stage bookkeeping
+#define BR_BEGIN(p) do { if ((p) % RS == 0) stage_begin(); } while (0)
+#define BR_NEXT(p) do { a[(p) % PFD] = frag_at((p) + PFD, (p)); \
+                        if ((p) % RS == RS - 1) stage_end(); } while (0)
+
+    bf16x8 x1[KS1];
+    // ---- layer 0 ----------------------------------------------------------------------------------------------
+#pragma unroll
+    for (int o = 0; o < NO0; ++o) {
+        f32x16 acc;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 bv = *reinterpret_cast<const float4 *>(sb0 + o * 32 + 8 * g + 4 * h);
+            acc[4 * g] = bv.x; acc[4 * g + 1] = bv.y; acc[4 * g + 2] = bv.z; acc[4 * g + 3] = bv.w;
+        }
+#pragma unroll
+        for (int ks = 0; ks < KS0; ++ks) {
+            const int p = o * KS0 + ks;
+            BR_BEGIN(p);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(a[p % PFD]), x0[ks], acc, 0, 0, 0);
+            BR_NEXT(p);
+        }
+        x1[2 * o] = pack8(acc, 0);
+        x1[2 * o + 1] = pack8(acc, 1);
+    }
+    bf16x8 x2[KS2];
+    // ---- layer 1 ----------------------------------------------------------------------------------------------
+#pragma unroll
+    for (int o = 0; o < NO1; ++o) {
+        f32x16 acc;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 bv = *reinterpret_cast<const float4 *>(sb1 + o * 32 + 8 * g + 4 * h);
+            acc[4 * g] = bv.x; acc[4 * g + 1] = bv.y; acc[4 * g + 2] = bv.z; acc[4 * g + 3] = bv.w;
+        }
+#pragma unroll
+        for (int ks = 0; ks < KS1; ++ks) {
+            const int p = P0 + o * KS1 + ks;
+            BR_BEGIN(p);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(a[p % PFD]), x1[ks], acc, 0, 0, 0);
+            BR_NEXT(p);
+        }
+        x2[2 * o] = pack8(acc, 0);
+        x2[2 * o + 1] = pack8(acc, 1);
+    }
+    // ---- layer 2: D[row, cout] = X . W^T, pooled over the rows of each group -------------------------------------
+    auto l2_tile = [&](const int o, const int p0) {   // p0: position of the tile's first fragment (modulo the stage size when rolled)
+        f32x16 acc;
+        {
+            const float bv = sb2[o * 32 + r];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] = bv;
+        }
+#pragma unroll
+        for (int ks = 0; ks < KS2; ++ks) {
+            const int p = p0 + ks;
+            BR_BEGIN(p);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x2[ks], as_bf(a[p % PFD]), acc, 0, 0, 0);
+            BR_NEXT(p);
+        }
+        // register i of this lane half = row 16h + i of the tile, channel 32 o + r
+        float *op = pi.optr + 32 * o;
+        const bool cok = 32 * o + r < c.cout_last;
+        float m = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            float v = acc[i];
+            v = v > 0.f ? v : 0.f;
+            m = ((pi.cont >> i) & 1u) ? (v > m ? v : m) : v;
+            if ((pi.ends >> i) & 1u) {
+                if (cok) {
+                    if ((pi.atom >> i) & 1u) atomic_max_pos(op, m);
+                    else *op = m;
+                }
+                op += c.ld_out;
+            }
+        }
+    };
+    if constexpr (ROLL2) {
+        static_assert(RS % PFD == 0 && KS2 % RS == 0, "a rolled tile must start at the same position modulo the stage and the read queue");
+#pragma unroll 1
+        for (int o = 0; o < NO2; ++o) l2_tile(o, (P0 + P1) % RS);
+    } else {
+#pragma unroll
+        for (int o = 0; o < NO2; ++o) l2_tile(o, P0 + P1 + o * KS2);
+    }
+    if (!STATICW && P % RS != 0) stage_end();       // the padded last stage
+#undef BR_BEGIN
+#undef BR_NEXT
+    rs.slot = slot;
+}
+
+// Shapes (sad::bfreg_shape_id):  KS0, NO0, NO1, NO2
+//  0: <=16 -> 16 -> 16 -> 32 (SA1 narrow)    1: <=16 -> 32 -> 32 -> 64 (SA1 wide)     7: <=16 -> 64 -> 64 -> 128 (configs[0])
+//  2: 67 -> 64 -> 64 -> 128 (SA2)            3: 67 -> 64 -> 96 -> 128
+//  4: 131 -> 128 -> 128 -> 256 (SA3)         5: 131 -> 128 -> 192 -> 256             6: 131 -> 128 -> 256 -> 256
+//  8: 259 -> 256 -> 256 -> 512 (cluster)     9: 259 -> 256 -> 512 -> 1024
+template <int FAMILY, int NW>
+__device__ __forceinline__ void run_br(const BfRegChain &c, int shape, int tile, const float *sb, int lane, int wave, Ring &rs,
+                                       const float4 *sbase, const float4 *nbase) {
+    if constexpr (FAMILY == 0) {
+        if (shape == 0) br_tile<1, 1, 1, 1, false, NW, true>(c, tile, sb, lane, wave, rs, sbase, nbase);
+        else if (shape == 1) br_tile<1, 1, 1, 2, false, NW, true>(c, tile, sb, lane, wave, rs, sbase, nbase);
+        else br_tile<1, 2, 2, 4, false, NW, true>(c, tile, sb, lane, wave, rs, sbase, nbase);
+    } else if constexpr (FAMILY == 1) {
+        if (shape == 2) br_tile<5, 2, 2, 4, true, NW, false>(c, tile, sb, lane, wave, rs, sbase, nbase);
+        else br_tile<5, 2, 3, 4, true, NW, false>(c, tile, sb, lane, wave, rs, sbase, nbase);
+    } else if constexpr (FAMILY == 2) {
+        if (shape == 4) br_tile<9, 4, 4, 8, true, NW, false>(c, tile, sb, lane, wave, rs, sbase, nbase);
+        else if (shape == 5) br_tile<9, 4, 6, 8, true, NW, false>(c, tile, sb, lane, wave, rs, sbase, nbase);
+        else br_tile<9, 4, 8, 8, true, NW, false>(c, tile, sb, lane, wave, rs, sbase, nbase);
+    } else {
+        if (shape == 8) br_tile<17, 8, 8, 16, true, NW, false>(c, tile, sb, lane, wave, rs, sbase, nbase);
+        else br_tile<17, 8, 16, 32, true, NW, false>(c, tile, sb, lane, wave, rs, sbase, nbase);
+    }
+}
+
+constexpr int BR_NW = 4;
+
+template <int FAMILY>
+__global__ __launch_bounds__(BR_NW * 64, FAMILY == 3 ? 1 : 2) void mlp_bf16_reg_kernel(const BfRegMulti mp) {
+    constexpr int NW = BR_NW;
+    constexpr int FPW = RS / NW;
+    constexpr bool STATICW = FAMILY == 0;
+    // [ring: RNS stages x RS fragments x 1 KB | family 0: the stream images of all chains][per chain: biases of the three layers]
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float4 *ring = reinterpret_cast<float4 *>(smem);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float *sbias = smem + (STATICW ? mp.static_f4 : RING_F4) * 4;
+    static_assert(sad::REG_MAX_CHAINS == 3, "chain selection below is written out for three chains");
+    int bo = 0, b1 = 0, b2 = 0;
+    for (int ci = 0; ci < mp.n; ++ci) {
+        const BfRegChain &c = mp.c[ci];
+        if (ci == 1) b1 = bo;
+        if (ci == 2) b2 = bo;
+        for (int l = 0; l < 3; ++l) {
+            for (int i = tid; i < c.np[l]; i += NW * 64) sbias[bo + i] = c.bias[l][i];
+            bo += c.np[l];
+        }
+    }
+    // items = NW consecutive tiles of one chain, chain 0 first (heaviest); static round-robin deal
+    const int t0 = ((mp.c[0].rowtab[0] + 31) / 32 + NW - 1) / NW;
+    const int t1 = mp.n > 1 ? t0 + ((mp.c[1].rowtab[0] + 31) / 32 + NW - 1) / NW : t0;
+    const int nitems = mp.n > 2 ? t1 + ((mp.c[2].rowtab[0] + 31) / 32 + NW - 1) / NW : t1;
+    const unsigned ulane = (unsigned)lane;
+    auto stream_of = [&](int it) -> const float4 * {
+        const int ci = it < t0 ? 0 : (it < t1 ? 1 : 2);
+        return reinterpret_cast<const float4 *>(mp.c[ci].stream);
+    };
+    int item = (int)blockIdx.x;
+    int w1 = 0, w2 = 0;                              // family 0: float4 offsets of the images of chains 1 and 2
+    if constexpr (STATICW) {
+        int wo = 0;
+        for (int ci = 0; ci < mp.n; ++ci) {
+            if (ci == 1) w1 = wo;
+            if (ci == 2) w2 = wo;
+            const int n4 = mp.c[ci].stream_frags * 64;
+            const float4 *sp = reinterpret_cast<const float4 *>(mp.c[ci].stream);
+            for (int i = tid; i < n4; i += NW * 64) ring[wo + i] = sp[i];
+            wo += n4;
+        }
+    } else if (item < nitems) {   // prologue: stages 0 and 1 of the first item
+        const float4 *sp = stream_of(item) + (size_t)(FPW * wave) * 64;
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int e = 0; e < FPW; ++e) ring[(s * RS + FPW * wave + e) * 64 + lane] = (sp + (size_t)(s * RS + e) * 64)[ulane];
+    }
+    __syncthreads();                                // (also: the biases are in place)
+    Ring rs{ring, 0};
+    for (; item < nitems; item += (int)gridDim.x) { // (workgroup-uniform)
+        const int ci = __builtin_amdgcn_readfirstlane(item < t0 ? 0 : (item < t1 ? 1 : 2));
+        const int tg = item - (ci == 0 ? 0 : (ci == 1 ? t0 : t1));
+        const int nxt = item + (int)gridDim.x;
+        // the tile's last two stages fetch the first two of the next item (any valid stream when there is none)
+        if constexpr (STATICW) rs.ring = ring + (ci == 0 ? 0 : (ci == 1 ? w1 : w2));
+        run_br<FAMILY, NW>(mp.c[ci], mp.shape[ci], tg * NW + wave, sbias + (ci == 0 ? 0 : (ci == 1 ? b1 : b2)), lane, wave, rs,
+                           stream_of(item), stream_of(nxt < nitems ? nxt : item));
+    }
+}
+
+// fragment stream of one chain in consumption order (see the header): layer 0 in natural k order, layers 1 and 2 in the
+// order the previous layer's accumulators provide their k; zero fragments pad the last stage
+__global__ __launch_bounds__(256) void bfreg_pack_kernel(const float *__restrict__ W0, const float *__restrict__ W1, const float *__restrict__ W2,
+                                                         int cin0, int c0, int c1, int c2, int KS0, int NO0, int NO1, int NO2, int xyz_first,
+                                                         long long nfrag, __bf16 *__restrict__ dst) {
+    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;      // one bf16 per thread
+    if (e >= nfrag * 512) return;
+    const int j = (int)(e & 7), lane = (int)((e >> 3) & 63);
+    const long long p = e >> 9;
+    const int r = lane & 31, h = lane >> 5;
+    const int KS1 = 2 * NO0, KS2 = 2 * NO1;
+    const long long P0 = (long long)NO0 * KS0, P1 = (long long)NO1 * KS1, P2 = (long long)NO2 * KS2;
+    float v = 0.f;
+    if (p < P0) {
+        const int o = (int)(p / KS0), ks = (int)(p % KS0);
+        const int co = 32 * o + r, k = 16 * ks + 8 * h + j;          // internal input order [feat(C) | xyz(3)]
+        if (co < c0 && k < cin0) {
+            int col = k;
+            if (xyz_first) col = k < cin0 - 3 ? k + 3 : k - (cin0 - 3);
+            v = W0[(size_t)co * cin0 + col];
+        }
+    } else if (p < P0 + P1 + P2) {
+        const bool l1 = p < P0 + P1;
+        const long long pp = l1 ? p - P0 : p - P0 - P1;
+        const int KS = l1 ? KS1 : KS2, cin = l1 ? c0 : c1, cout = l1 ? c1 : c2;
+        const float *W = l1 ? W1 : W2;
+        const int o = (int)(pp / KS), ks = (int)(pp % KS);
+        const int co = 32 * o + r;
+        const int k = 32 * (ks >> 1) + 16 * (ks & 1) + 8 * (j >> 2) + 4 * h + (j & 3);   // channel behind element j of half h
+        if (co < cout && k < cin) v = W[(size_t)co * cin + k];
+    }
+    dst[e] = (__bf16)v;
+}
+
+struct Shape { int cmax, d1, d2, d3, KS0, NO0, NO1, NO2, family; };
+const Shape kShapes[10] = {
+    {16, 16, 16, 32, 1, 1, 1, 1, 0},      {16, 32, 32, 64, 1, 1, 1, 2, 0},      {67, 64, 64, 128, 5, 2, 2, 4, 1},     {67, 64, 96, 128, 5, 2, 3, 4, 1},
+    {131, 128, 128, 256, 9, 4, 4, 8, 2},  {131, 128, 192, 256, 9, 4, 6, 8, 2},  {131, 128, 256, 256, 9, 4, 8, 8, 2},  {16, 64, 64, 128, 1, 2, 2, 4, 0},
+    {259, 256, 256, 512, 17, 8, 8, 16, 3}, {259, 256, 512, 1024, 17, 8, 16, 32, 3}};
+
+}  // namespace
+
+namespace sad {
+
+// dims = {C + 3, C1, C2, C3} of a grouped 3-layer chain -> compiled shape, or -1
+int bfreg_shape_id(int L, const int *dims) {
+    if (L != 3 || !dims) return -1;
+    for (int i = 0; i < 10; ++i) {
+        const Shape &s = kShapes[i];
+        const bool in_ok = s.KS0 == 1 ? (dims[0] >= 3 && dims[0] <= s.cmax) : dims[0] == s.cmax;
+        if (in_ok && dims[1] == s.d1 && dims[2] == s.d2 && dims[3] == s.d3) return i;
+    }
+    return -1;
+}
+int bfreg_family(int shape) { return shape >= 0 && shape < 10 ? kShapes[shape].family : -1; }
+
+long long bfreg_stream_frags(int shape) {
+    if (shape < 0 || shape >= 10) return 0;
+    const Shape &s = kShapes[shape];
+    const long long P = (long long)s.NO0 * s.KS0 + (long long)s.NO1 * 2 * s.NO0 + (long long)s.NO2 * 2 * s.NO1;
+    return (P + RS - 1) / RS * RS;
+}
+
+int bfreg_pack(int shape, const int *dims, int first_has_xyz, const float *const *W, void *dst, hipStream_t st) {
+    const Shape &s = kShapes[shape];
+    const long long nfrag = bfreg_stream_frags(shape);
+    const long long n = nfrag * 512;
+    hipLaunchKernelGGL(bfreg_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, W[0], W[1], W[2], dims[0], dims[1], dims[2], dims[3],
+                       s.KS0, s.NO0, s.NO1, s.NO2, first_has_xyz, nfrag, (__bf16 *)dst);
+    return check_launch("sad_mlp_pack_bf16 (stream image)");
+}
+
+template <int FAMILY>
+static int launch_bfreg_family(const BfRegMulti &mp, size_t lds, hipStream_t st) {
+    static std::atomic<uint64_t> attr_done{0};
+    lds_attr_once(attr_done, reinterpret_cast<const void *>(&mlp_bf16_reg_kernel<FAMILY>), 160 * 1024);
+    static std::atomic<int> per_cu{0};
+    int pc = per_cu.load(std::memory_order_relaxed);
+    if (pc == 0) {
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, mlp_bf16_reg_kernel<FAMILY>, BR_NW * 64, lds) != hipSuccess || nb < 1) {
+            (void)hipGetLastError();
+            nb = 1;
+        }
+        pc = nb > 3 ? 3 : nb;
+        per_cu.store(pc, std::memory_order_relaxed);
+    }
+    if (get_option(OPT_MLP_DYN_SLOTS) > 0 && get_option(OPT_MLP_DYN_SLOTS) < pc) pc = get_option(OPT_MLP_DYN_SLOTS);   // A/B knob
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+    }
+    (void)hipGetLastError();
+    long long grid = (long long)cus * pc;
+    const long long cap = mp.max_tiles / BR_NW + mp.n;           // never more workgroups than items could exist
+    if (grid > cap) grid = cap < 1 ? 1 : cap;
+    hipLaunchKernelGGL((mlp_bf16_reg_kernel<FAMILY>), dim3((unsigned)grid), dim3(BR_NW * 64), lds, st, mp);
+    return check_launch("sad_mlp_chain_bf16 (register-resident chain)");
+}
+
+int launch_bfreg(const BfRegMulti &mp, hipStream_t st) {
+    const int fam = bfreg_family(mp.shape[0]);
+    BfRegMulti mq = mp;
+    mq.static_f4 = 0;
+    size_t lds = 0;
+    for (int i = 0; i < mq.n; ++i) {
+        lds += sizeof(float) * (size_t)(mq.c[i].np[0] + mq.c[i].np[1] + mq.c[i].np[2]);
+        if (bfreg_family(mq.shape[i]) != fam) return fail(SAD_EINVAL, "launch_bfreg: chains of different shape families in one dispatch");
+        mq.c[i].stream_frags = (int)bfreg_stream_frags(mq.shape[i]);
+        mq.static_f4 += mq.c[i].stream_frags * 64;
+    }
+    lds += sizeof(float4) * (size_t)(fam == 0 ? mq.static_f4 : RING_F4);
+    switch (fam) {
+        case 0: return launch_bfreg_family<0>(mq, lds, st);
+        case 1: return launch_bfreg_family<1>(mq, lds, st);
+        case 2: return launch_bfreg_family<2>(mq, lds, st);
+        default: return launch_bfreg_family<3>(mq, lds, st);
+    }
+}
+
+}  // namespace sad

@@ -218,7 +218,8 @@ class SADDetector(nn.Module):
                 if q is not None:
                     for part in q:
                         for t in part:
-                            t.record_stream(main)
+                            if t is not None:          # (a branch whose kernel packs for itself has no prescanned table)
+                                t.record_stream(main)
             zeros.record_stream(main)
             main.wait_event(ev_xyz)
         else:

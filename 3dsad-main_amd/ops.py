@@ -607,10 +607,7 @@ def grouped_multi(calls) -> None:
     for c in calls:
         mlp, xyz, feat_pm, new_xyz, idx, out, col_off, cnt = c[:8]
         ws = c[8] if len(c) > 8 else None
-        if ws is not None and isinstance(mlp, PackedMLP):
-            a, _, k = mlp._grouped_args(xyz, feat_pm, new_xyz, idx, out, col_off, cnt, ws)
-        else:
-            a, _, k = mlp._grouped_args(xyz, feat_pm, new_xyz, idx, out, col_off, cnt)
+        a, _, k = mlp._grouped_args(xyz, feat_pm, new_xyz, idx, out, col_off, cnt, ws)
         args.append(a)
         keep.append(k)
     bf16 = isinstance(calls[0][0], PackedMLPBf16)
@@ -709,6 +706,24 @@ class PackedMLPBf16:
                                           self.packed.data_ptr(), _stream()), "sad_mlp_pack_bf16")
             torch.cuda.current_stream().synchronize()
         self.out_channels = self.dims[-1]
+        # grouped calls that come with counts use the register-resident chain kernel (geometry 2, csrc/mlp_bf16_reg.hip)
+        # where the library has the shape compiled
+        self.preferred_geometry = int(lib().sad_mlp_preferred_geometry_bf16(self.L, dims_c)) if self.first_has_xyz else 0
+
+    def _feat_ok_reg(self, feat_pm) -> bool:
+        if feat_pm is None:
+            return True
+        C = feat_pm.shape[2]
+        if C <= 13:
+            return True
+        return (feat_pm.dtype == torch.bfloat16 and C % 8 == 0 and feat_pm.stride(1) % 8 == 0 and feat_pm.data_ptr() % 16 == 0)
+
+    def wants_prescan(self, B: int, N: int, M: int, S: int, ld_out: int, C: int) -> bool:
+        """See ``PackedMLP.wants_prescan``: geometry 2 consumes a caller-made row-packing table."""
+        geom = self._geom.get((True, B, N, M, S, ld_out)) or self.default_geometry
+        if not geom and not AUTOTUNE:
+            geom = self.preferred_geometry
+        return geom == 2
 
     def _args(self) -> _lib.MlpBf16Args:
         a = _lib.MlpBf16Args()
@@ -728,16 +743,17 @@ class PackedMLPBf16:
 
     def grouped(self, xyz: torch.Tensor, feat_pm: Optional[torch.Tensor], new_xyz: torch.Tensor,
                 idx: torch.Tensor, out: Optional[torch.Tensor] = None, col_off: int = 0,
-                cnt: Optional[torch.Tensor] = None) -> torch.Tensor:
+                cnt: Optional[torch.Tensor] = None, ws: Optional[torch.Tensor] = None) -> torch.Tensor:
         """xyz [B,N,3] f32; feat_pm point-major [B,N,C] bf16/f32 (or None); new_xyz [B,M,3]; idx
         [B,M,S] -> out[:, :, col_off:col_off+C_out] of a ZERO-initialised float32 [B,M,ld] buffer.
         With ``cnt`` ([B,M] int32 from ball_query_multi(return_counts=True)) only the leading cnt
-        rows of each group are computed — the ball query's padding rows cannot change the max."""
-        a, out, _keep = self._grouped_args(xyz, feat_pm, new_xyz, idx, out, col_off, cnt)
+        rows of each group are computed — the ball query's padding rows cannot change the max.
+        ``ws``: the row-packing table of (idx, cnt) from ``rowscan_multi`` (geometry 2 then launches no scan)."""
+        a, out, _keep = self._grouped_args(xyz, feat_pm, new_xyz, idx, out, col_off, cnt, ws)
         self._launch(a)
         return out
 
-    def _grouped_args(self, xyz, feat_pm, new_xyz, idx, out, col_off, cnt):
+    def _grouped_args(self, xyz, feat_pm, new_xyz, idx, out, col_off, cnt, ws=None):
         """Validated ``MlpBf16Args`` of a grouped call + the output tensor + tensors to keep alive."""
         if not self.first_has_xyz:
             raise RuntimeError("this PackedMLPBf16 was packed without the xyz prefix")
@@ -771,20 +787,29 @@ class PackedMLPBf16:
             cnt = _need(cnt, "cnt", torch.int32, 2)
             if tuple(cnt.shape) != (B, M):
                 raise ValueError("cnt must be [B,M]")
-            ws = torch.empty((lib().sad_mlp_workspace_bytes(B, M, S),), dtype=torch.uint8, device=xyz.device)
+            given = ws is not None
+            if not given:
+                ws = torch.empty((lib().sad_mlp_workspace_bytes(B, M, S),), dtype=torch.uint8, device=xyz.device)
+            elif ws.numel() < lib().sad_mlp_workspace_bytes(B, M, S):
+                raise ValueError("ws: too small for this (B, M, S)")
             a.cnt, a.workspace = cnt.data_ptr(), ws.data_ptr()
             keep += [cnt, ws]
         a.geometry = self._geom.get((bool(a.idx), a.B, a.N, a.M, a.S, a.ld_out)) or self.default_geometry
+        if not a.geometry and cnt is not None and not AUTOTUNE and self._feat_ok_reg(feat_pm):
+            a.geometry = self.preferred_geometry
+        if cnt is not None and given and a.geometry == 2:
+            a.prescanned = 1          # (the tiled kernel packs with its own tile height and scans for itself)
         return a, out, keep
 
     def _launch(self, a) -> None:
         """Enqueue; with AUTOTUNE on, the first call for a shape times 64 / 128 / 256 rows per tile."""
         key = (bool(a.idx), a.B, a.N, a.M, a.S, a.ld_out)
         geom = self._geom.get(key)
+        preferred = a.geometry          # the un-tuned choice of _grouped_args (0 while autotuning)
         if geom is None and AUTOTUNE:
             stream = torch.cuda.current_stream()
             best, best_ms = 0, None
-            for code in (0, 64, 128, 256):
+            for code in (0, 64, 128, 256) + ((2,) if a.cnt and a.workspace and not a.prescanned else ()):
                 a.geometry = code
                 if lib().sad_mlp_chain_bf16(ctypes.byref(a), _stream()) != 0:
                     continue
@@ -803,7 +828,8 @@ class PackedMLPBf16:
                     best, best_ms = code, ms_best
             geom = best
             self._geom[key] = geom
-        a.geometry = geom or self.default_geometry
+            preferred = 0
+        a.geometry = geom or self.default_geometry or preferred
         with _timed("mlp", self.name):
             check(lib().sad_mlp_chain_bf16(ctypes.byref(a), _stream()), "sad_mlp_chain_bf16")
 

@@ -63,7 +63,7 @@ class SAModuleMSG(nn.Module):
         st = self.stage
         idxs, cnts = ops.ball_query_multi(radii if radii is not None else st.radii, st.nsamples, xyz, new_xyz,
                                           radius_pc, return_counts=True)
-        if prescan and self.dtype == "f32":
+        if prescan:
             # the row-packing scan needs only the query's output: run it here (on the sampling stream when the
             # detector overlaps), so the MLP stream launches no small latency-bound kernels before its chains;
             # only for the branches whose kernel consumes such a table (the tiled kernel packs for itself)

@@ -275,9 +275,17 @@ typedef struct sad_mlp_bf16_args {
     const int32_t *cnt;
     void *workspace;
     /* 0 = built-in choice (128 rows per tile, fewer if LDS demands); else rows per tile 32/64/128/256
-     * (more rows amortise the per-tile gather latency of narrow chains; SAD_EUNSUPPORTED if LDS is short) */
+     * (more rows amortise the per-tile gather latency of narrow chains; SAD_EUNSUPPORTED if LDS is short);
+     * 2 = register-resident chain (grouped 3-layer chains with cnt + workspace whose shape is compiled: the SA stages
+     *     and the cluster layer of the KITTI / nuScenes / TINY topologies and configs[0]; 16-byte bf16 feature rows,
+     *     or at most 13 feature channels of either type): one wave carries a 32-row tile through the chain in
+     *     registers, weights through an LDS ring, pooled rows leave as 128-byte stores */
     int geometry;
+    /* != 0: `workspace` already holds the row-packing table of (cnt, idx) from sad_mlp_rowscan (geometry 2 only) */
+    int prescanned;
 } sad_mlp_bf16_args;
+/* 2 when sad_mlp_chain_bf16 has a register-resident kernel for this grouped chain (dims[0] = C + 3), else 0 */
+int sad_mlp_preferred_geometry_bf16(int L, const int *dims);
 int sad_mlp_chain_bf16(const sad_mlp_bf16_args *args, sad_stream_t stream);
 /* n independent bf16 chains in one dispatch (see sad_mlp_chain_multi_f32). */
 int sad_mlp_chain_multi_bf16(const sad_mlp_bf16_args *const *args, int n, sad_stream_t stream);

@@ -90,8 +90,101 @@ def test_grouped_bf16(orc, sad, dev, B, N, M, S, C, mlp, radius):
     # row's result does not depend on its tile position -> identical bits
     idxs, cnts = ops.ball_query_multi([radius], [S], _t(xyz, dev), _t(new_xyz, dev), return_counts=True)
     np.testing.assert_array_equal(idxs[0].cpu().numpy(), idx)
+    m.default_geometry = 32 if m.preferred_geometry == 2 else 0      # the tiled kernel (an explicit tile height)
     packed = m.grouped(_t(xyz, dev), ft, _t(new_xyz, dev), idxs[0], cnt=cnts[0]).cpu().numpy()
-    assert np.array_equal(packed, got), f"packed vs dense: {np.abs(packed - got).max()}"
+    if m.default_geometry == 0:
+        assert np.array_equal(packed, got), f"packed vs dense: {np.abs(packed - got).max()}"
+    else:
+        _close(packed, want, "packed rows, tiled kernel")
+    m.default_geometry = 0
+    if m.preferred_geometry == 2:    # compiled shape: calls with counts run the register-resident chain (other summation order)
+        reg = m.grouped(_t(xyz, dev), ft, _t(new_xyz, dev), idxs[0], cnt=cnts[0]).cpu().numpy()
+        _close(reg, want, "register-resident chain (geometry 2)")
+
+
+REG_BF16 = [
+    # (B, N, M, S, C, mlp, radius, feat dtype) — every compiled shape of the register-resident bf16 chain (geometry 2)
+    (2, 3000, 700, 32, 1, [16, 16, 32], 0.08, "f32"),       # SA1 narrow (KITTI: one f32 channel, strided view)
+    (8, 8192, 4096, 32, 1, [16, 16, 32], 0.05, "f32"),      # ... many items per workgroup
+    (2, 3000, 700, 64, 1, [32, 32, 64], 0.15, "f32"),       # SA1 wide, nsample 64
+    (2, 3000, 500, 32, 4, [16, 16, 32], 0.1, "f32"),        # nuScenes SA1 (4 f32 channels, row stride 7)
+    (1, 1024, 256, 32, 0, [64, 64, 128], 0.2, None),        # BASELINE configs[0] (no features)
+    (2, 2000, 400, 32, 64, [64, 64, 128], 0.2, "bf16"),     # SA2
+    (2, 2000, 400, 64, 64, [64, 96, 128], 0.35, "bf16"),
+    (2, 1024, 300, 32, 128, [128, 128, 256], 0.3, "bf16"),  # SA3
+    (2, 1024, 300, 32, 128, [128, 192, 256], 0.5, "bf16"),
+    (2, 1024, 300, 32, 128, [128, 256, 256], 0.7, "bf16"),
+    (2, 512, 256, 16, 256, [256, 256, 512], 0.25, "bf16"),  # cluster
+    (2, 512, 256, 32, 256, [256, 512, 1024], 0.35, "bf16"),
+    (1, 200, 19, 8, 1, [16, 16, 32], 0.5, "f32"),           # fewer rows than one tile
+    (3, 2048, 512, 32, 128, [128, 128, 256], 0.9, "bf16"),  # full groups: a group = a whole tile, many tiles per workgroup
+]
+
+
+@pytest.mark.parametrize("B,N,M,S,C,mlp,r,fdt", REG_BF16)
+def test_register_chain_bf16(orc, sad, dev, B, N, M, S, C, mlp, r, fdt):
+    """geometry 2 of sad_mlp_chain_bf16 (csrc/mlp_bf16_reg.hip): one wave carries a 32-row tile through the chain in
+    registers.  Ragged groups, groups that straddle half-tiles and tiles (atomic max merge), rows past the end;
+    with the chain's own row-packing scan and with a table made by rowscan_multi.  SPEC.md §14 tolerance."""
+    import torch
+    from sad_amd import ops, synth
+    rng = np.random.default_rng(N + M + S + C + sum(mlp))
+    xyz = rng.uniform(0, 1, (B, N, 3)).astype(np.float32)
+    new_xyz = np.ascontiguousarray(xyz[:, :M])
+    X, Cn = _t(xyz, dev), _t(new_xyz, dev)
+    feat, F = None, None
+    if C:
+        if fdt == "f32":     # a strided view of the point rows, as the detector's first stage reads them
+            pts = rng.uniform(0, 1, (B, N, 3 + C)).astype(np.float32)
+            pts[:, :, 3:] = orc.bf16_round(pts[:, :, 3:])
+            feat = np.ascontiguousarray(pts[:, :, 3:])
+            F = _t(pts, dev)[:, :, 3:]
+        else:
+            feat = orc.bf16_round(rng.normal(size=(B, N, C)).astype(np.float32))
+            F = _t(feat, dev).bfloat16()
+    idxs, cnts = ops.ball_query_multi((r,), (S,), X, Cn, return_counts=True)
+    layers = synth.make_mlp_weights([C + 3] + mlp, rng)
+    want = orc.sa_group_mlp_max_bf16(xyz, feat, new_xyz, idxs[0].cpu().numpy(), layers)
+    net = ops.PackedMLPBf16(layers, True, dev)
+    assert net.preferred_geometry == 2
+    net.default_geometry = 2
+    got = net.grouped(X, F, Cn, idxs[0], cnt=cnts[0]).cpu().numpy()
+    rows = int(cnts[0].clamp(min=1).sum().item())
+    _close(got, want, f"register chain bf16 {[C + 3] + mlp} S={S} ({rows} packed rows)")
+    ws = ops.rowscan_multi(idxs, cnts, N)[0]
+    again = net.grouped(X, F, Cn, idxs[0], cnt=cnts[0], ws=ws).cpu().numpy()
+    assert np.array_equal(again, got), "prescanned table: different bits"
+
+
+def test_register_chain_bf16_three_chain_dispatch(orc, sad, dev):
+    """The three SA3 branches as ONE register-resident dispatch (sad_mlp_chain_multi_bf16) with prescanned tables:
+    chains of different shapes follow each other in a workgroup's item list and the weight ring carries over."""
+    import torch
+    from sad_amd import ops, synth
+    rng = np.random.default_rng(78)
+    B, N, M, C = 3, 1024, 384, 128
+    xyz = rng.uniform(0, 1, (B, N, 3)).astype(np.float32)
+    feat = orc.bf16_round(rng.normal(size=(B, N, C)).astype(np.float32))
+    new_xyz = np.ascontiguousarray(xyz[:, :M])
+    X, F, Cn = _t(xyz, dev), _t(feat, dev).bfloat16(), _t(new_xyz, dev)
+    radii, ns = (0.2, 0.35, 0.6), (32, 32, 32)
+    mlps = ([128, 128, 256], [128, 192, 256], [128, 256, 256])
+    idxs, cnts = ops.ball_query_multi(radii, ns, X, Cn, return_counts=True)
+    wss = ops.rowscan_multi(idxs, cnts, N)
+    out = torch.zeros((B, M, 768), device=dev)
+    calls, wants = [], []
+    for bi, mlp in enumerate(mlps):
+        layers = synth.make_mlp_weights([C + 3] + mlp, rng)
+        net = ops.PackedMLPBf16(layers, True, dev)
+        calls.append((net, X, F, Cn, idxs[bi], out, 256 * bi, cnts[bi], wss[bi]))
+        wants.append(orc.sa_group_mlp_max_bf16(xyz, feat, new_xyz, idxs[bi].cpu().numpy(), layers))
+    ops.grouped_multi(calls)
+    got = out.cpu().numpy()
+    for bi in range(3):
+        _close(got[:, :, 256 * bi:256 * (bi + 1)], wants[bi], f"merged dispatch, branch {bi}")
+    out2 = torch.zeros((B, M, 768), device=dev)       # the same tables again (nothing in them is consumed)
+    ops.grouped_multi([c[:5] + (out2,) + c[6:] for c in calls])
+    assert torch.equal(out, out2)
 
 
 def test_nuscenes_stage_bf16(orc, sad, dev):
