@@ -35,6 +35,17 @@ constexpr int RS = 16;               // fragments (1 KB each) per ring stage
 constexpr int RNS = 3;               // ring slots: being read / complete / being written
 constexpr int RING_F4 = RNS * RS * 64;
 constexpr int PFD = 4;               // ring reads run this many fragments ahead of the MFMA that consumes them
+// Staged pooled output.  A wave owns 4 KB of LDS: STAGE_F floats = slots x CB channels, slot = ordinal of a group inside
+// the tile, CB = 128 / 64 / 32 channels per block for tiles with <= 8 / 16 / 32 groups.  EVERY row of an output tile
+// max-combines into its group's slot with one LDS atomic per register (ds_max_u32 on the bit patterns: values are >= +0
+// after the ReLU) — no running max, no per-row control flow — and after the last output tile of a block each group
+// leaves as one row of CB channels: coalesced 16-byte stores (64 lanes cover 256 / CB groups), an atomic max only for the
+// first / last group of a tile when it continues in another tile.  The first version walked the 16 registers with a
+// running max and stored 128 bytes per (group end, lane half, output tile): 16 exec-masked branches per output tile cost
+// ~2 700 cycles against 512 of MFMAs (tools/probe/bf16_stamps.py), and half-tile atomics ran at the memory pipeline's
+// instruction rate.
+constexpr int STAGE_F = 1024;        // floats of pooled-output staging per wave
+__host__ __device__ constexpr int stage_cb(int no2) { return no2 * 32 < 128 ? no2 * 32 : 128; }
 
 __device__ __forceinline__ void atomic_max_pos(float *addr, float v) {
     atomicMax(reinterpret_cast<unsigned *>(addr), __builtin_bit_cast(unsigned, v));
@@ -42,41 +53,58 @@ __device__ __forceinline__ void atomic_max_pos(float *addr, float v) {
 
 __device__ __forceinline__ bf16x8 as_bf(const float4 v) { return __builtin_bit_cast(bf16x8, v); }
 
-// ReLU + round: registers 8s .. 8s+7 of a hidden tile -> operand of k-step s of the next layer
+// max(x, lo) for lo >= 0 as ONE v_med3_f32 (x, lo, +inf).  A builtin, not inline asm: the operand is an MFMA result and
+// hipcc pads the MFMA -> VALU wait states only for instructions it knows (a v_max in an asm statement read stale
+// accumulators on the narrow chains); the `x > lo ? x : lo` form costs a canonicalising v_max in front of the compare.
+__device__ __forceinline__ float max_pos(float x, float lo) { return __builtin_amdgcn_fmed3f(x, lo, __builtin_inff()); }
+__device__ __forceinline__ float relu1(float x) { return max_pos(x, 0.f); }
 __device__ __forceinline__ bf16x8 pack8(const f32x16 &t, int s) {
     bf16x8 v;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const float f = t[8 * s + j];
-        v[j] = (__bf16)(f > 0.f ? f : 0.f);
+        v[j] = (__bf16)relu1(f);
     }
     return v;
 }
+
+#ifdef SAD_BR_STAMPS   // measurement build only (tools/probe/bf16_stamps.py): s_memtime sums per phase over a wave's tiles
+__device__ unsigned long long g_brst[1024 * 16];
+#define SAD_BSTAMP(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
+#define SAD_BACC(i, t1, t0) do { if (blockIdx.x < 256 && lane == 0) g_brst[(blockIdx.x * 4 + wave) * 16 + (i)] += (t1) - (t0); } while (0)
+#else
+#define SAD_BSTAMP(var)
+#define SAD_BACC(i, t1, t0)
+#endif
 
 struct Ring {
     float4 *ring;       // [RNS][RS][64 lanes]
     int slot;           // slot of the stage being consumed (wave-uniform)
 };
 
-// Pooling bookkeeping of one tile for this lane's half (rows 16h .. 16h+15 of the tile, in register order)
+// Pooling bookkeeping of one tile (wave-uniform unless noted)
 struct PoolInfo {
-    unsigned cont;      // bit i: row i continues the group of row i - 1 (bit 0 clear)
-    unsigned ends;      // bit i: row i is live and the last row of its group inside this half
-    unsigned atom;      // bit i (ends only): the group has rows outside this half -> atomic max
-    float *optr;        // out + group(first row) * ld_out + col_off + (lane & 31)
+    int kind;           // 1: each half of the tile lies inside one group (plain max chain), else general
+    int soff[16];       // (per lane) byte offset of the slot of row 16h + i inside the wave's staging area, + 4 * (lane & 31)
+    int cbs;            // log2 of the block width CB in channels (5, 6, 7)
+    int ngroups;        // groups with live rows in this tile (0: a tile past the end, nothing is stored)
+    int g_first;        // group of the tile's first row (groups are consecutive in the packed order)
+    bool whole_first, whole_last;   // the first / last group of the tile has no rows in another tile
 };
 
 // STATICW: the chain's whole fragment stream sits in LDS for the lifetime of the workgroup (the narrow first-stage chains:
 // 3 - 22 fragments) — no ring, no barriers, the waves of a workgroup are independent; `rs.ring` then points at that image.
 template <int KS0, int NO0, int NO1, int NO2, bool VEC0, int NW, bool STATICW>
 __device__ __forceinline__ void br_tile(const BfRegChain &c, const int tile, const float *__restrict__ sbias, const int lane, const int wave,
-                                        Ring &rs, const float4 *__restrict__ sbase, const float4 *__restrict__ nbase) {
+                                        Ring &rs, const float4 *__restrict__ sbase, const float4 *__restrict__ nbase, float *stage) {
     constexpr int KS1 = 2 * NO0, KS2 = 2 * NO1;
+    constexpr int CB = stage_cb(NO2);                     // widest staged block of this chain (channels)
     constexpr int P0 = NO0 * KS0, P1 = NO1 * KS1, P2 = NO2 * KS2, P = P0 + P1 + P2;
     constexpr int NSTG = (P + RS - 1) / RS;
     constexpr int FPW = RS / NW;
     constexpr bool ROLL2 = (KS2 % RS == 0) && NO2 > 4;      // layer-2 tiles span whole stages: loop over them stays rolled
     const int r = lane & 31, h = lane >> 5;
+    SAD_BSTAMP(ts0);
     const int total = c.rowtab[0];
     // ---- rows: lane r carries packed row pi(r) of the tile --------------------------------------------------
     const int rho = 16 * ((r >> 2) & 1) + 4 * (r >> 3) + (r & 3);
@@ -127,26 +155,32 @@ __device__ __forceinline__ void br_tile(const BfRegChain &c, const int tile, con
         if (!live) qt = total - 1;
         const int gv = c.row_gid[qt];
         const int g = gv & (WHOLE_BIT - 1);
-        const int gprev = __shfl_up(g, 1, 64), gnext = __shfl_down(g, 1, 64);
-        const int lnext = __shfl_down((int)live, 1, 64);
-        const bool same_prev = r > 0 && gprev == g;
-        const bool real_end = r == 31 || !lnext || gnext != g;           // the group's last row (in this tile)
-        const bool end = live && (real_end || (r & 15) == 15);           // ... or the last row of a half: flushed there too
-        const unsigned contm = (unsigned)__ballot(same_prev && lane < 32);
-        // start of this row's run inside the tile: highest t' <= t whose cont bit is clear
-        const unsigned starts = ~contm & (0xFFFFFFFFu >> (31 - r));
-        const int a = 31 - __builtin_clz(starts);
-        // plain store only when every row of the group lies in this half of this tile
-        const bool inhalf = (gv & WHOLE_BIT) != 0 && (a >> 4) == (r >> 4) && real_end;
-        const unsigned endm = (unsigned)__ballot(end && lane < 32);
-        const unsigned atomm = (unsigned)__ballot(end && !inhalf && lane < 32);
-        pi.cont = (contm >> (16 * h)) & 0xFFFEu;
-        pi.ends = (endm >> (16 * h)) & 0xFFFFu;
-        pi.atom = (atomm >> (16 * h)) & 0xFFFFu;
-        const int g0 = __builtin_amdgcn_readlane(g, 0), g16 = __builtin_amdgcn_readlane(g, 16);
-        pi.optr = c.out + (long long)(h ? g16 : g0) * c.ld_out + c.col_off + r;
+        const int gprev = __shfl_up(g, 1, 64);
+        const bool same_prev = r > 0 && gprev == g;                 // (rows past the end repeat the last row: same group)
+        const unsigned startm = ~(unsigned)__ballot(same_prev && lane < 32);      // bit t: row t starts a group (bit 0 set)
+        const unsigned livem = (unsigned)__ballot(live && lane < 32);
+        pi.kind = (~startm & 0xFFFEFFFEu) == 0xFFFEFFFEu ? 1 : 2;   // (rows past the end count as continuing the last group)
+        pi.ngroups = __builtin_amdgcn_readfirstlane(__builtin_popcount(startm & livem));
+        pi.g_first = __builtin_amdgcn_readlane(g, 0);
+        const int nlive = __builtin_popcount(livem);
+        pi.whole_first = (__builtin_amdgcn_readlane(gv, 0) & WHOLE_BIT) != 0;
+        pi.whole_last = (__builtin_amdgcn_readlane(gv, nlive > 0 ? nlive - 1 : 0) & WHOLE_BIT) != 0;
+        constexpr int CBS_MAX = CB == 128 ? 7 : (CB == 64 ? 6 : 5);
+        const int want = pi.ngroups <= 8 ? 7 : (pi.ngroups <= 16 ? 6 : 5);
+        pi.cbs = want < CBS_MAX ? want : CBS_MAX;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int slot = __builtin_popcount(startm & (0xFFFFFFFFu >> (31 - (16 * h + i)))) - 1;
+            pi.soff[i] = (slot << (pi.cbs + 2)) + 4 * r;
+        }
     }
     const float *sb0 = sbias, *sb1 = sbias + NO0 * 32, *sb2 = sb1 + NO1 * 32;
+    // (kernel-argument fields used inside the loops: held in vector registers — left to the compiler they are re-read from
+    // the argument segment at every use, and every scalar load drains the queue of LDS reads with an lgkmcnt(0))
+    int ldo = c.ld_out, cout_last = c.cout_last, col_off = c.col_off;
+    asm volatile("" : "+v"(ldo), "+v"(cout_last), "+v"(col_off));
+    float *const c_out = c.out;
+    const bool vec_out = (c.ld_out % 4 == 0) && (c.col_off % 4 == 0) && ((reinterpret_cast<uintptr_t>(c.out) & 15) == 0);
 
     // ---- the ring ---------------------------------------------------------------------------------------------
     float4 *const ring = rs.ring;
@@ -194,6 +228,7 @@ __device__ __forceinline__ void br_tile(const BfRegChain &c, const int tile, con
     // one fragment position: the weight operand of position p, the read PFD positions ahead, stage bookkeeping
 #define BR_BEGIN(p) do { if ((p) % RS == 0) stage_begin(); } while (0)
 #define BR_NEXT(p) do { a[(p) % PFD] = frag_at((p) + PFD, (p)); \
+                        __builtin_amdgcn_sched_barrier(0);       /* the reads stay PFD positions ahead of their MFMAs */ \
                         if ((p) % RS == RS - 1) stage_end(); } while (0)
 
     bf16x8 x1[KS1];
@@ -216,6 +251,7 @@ __device__ __forceinline__ void br_tile(const BfRegChain &c, const int tile, con
         x1[2 * o] = pack8(acc, 0);
         x1[2 * o + 1] = pack8(acc, 1);
     }
+    SAD_BSTAMP(ts1);
     bf16x8 x2[KS2];
     // ---- layer 1 ----------------------------------------------------------------------------------------------
 #pragma unroll
@@ -236,8 +272,10 @@ __device__ __forceinline__ void br_tile(const BfRegChain &c, const int tile, con
         x2[2 * o] = pack8(acc, 0);
         x2[2 * o + 1] = pack8(acc, 1);
     }
+    SAD_BSTAMP(ts2);
     // ---- layer 2: D[row, cout] = X . W^T, pooled over the rows of each group -------------------------------------
     auto l2_tile = [&](const int o, const int p0) {   // p0: position of the tile's first fragment (modulo the stage size when rolled)
+        SAD_BSTAMP(tk0);
         f32x16 acc;
         {
             const float bv = sb2[o * 32 + r];
@@ -251,23 +289,64 @@ __device__ __forceinline__ void br_tile(const BfRegChain &c, const int tile, con
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x2[ks], as_bf(a[p % PFD]), acc, 0, 0, 0);
             BR_NEXT(p);
         }
+#ifdef SAD_BR_STAMPS
+        asm volatile("" : "+v"(acc));
+        SAD_BSTAMP(tk1);
+        SAD_BACC(6, tk1, tk0);
+#endif
         // register i of this lane half = row 16h + i of the tile, channel 32 o + r
-        float *op = pi.optr + 32 * o;
-        const bool cok = 32 * o + r < c.cout_last;
-        float m = 0.f;
+        if (pi.ngroups > 0) {
+            const int nobm = (1 << (pi.cbs - 5)) - 1;               // output tiles per block - 1
+            const int ob = o & nobm;
+            char *sp = reinterpret_cast<char *>(stage) + 128 * ob;
+            if (pi.kind == 1) {
+                // each half of the tile lies inside one group: a plain max chain across the registers, one LDS atomic per half
+                float m = relu1(acc[0]);
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            float v = acc[i];
-            v = v > 0.f ? v : 0.f;
-            m = ((pi.cont >> i) & 1u) ? (v > m ? v : m) : v;
-            if ((pi.ends >> i) & 1u) {
-                if (cok) {
-                    if ((pi.atom >> i) & 1u) atomic_max_pos(op, m);
-                    else *op = m;
+                for (int i = 1; i < 16; ++i) m = max_pos(acc[i], m);      // (m >= 0: the ReLU is part of the max)
+                atomicMax(reinterpret_cast<unsigned *>(sp + pi.soff[15]), __builtin_bit_cast(unsigned, m));
+            } else {
+                // every row goes to its group's slot: 16 LDS atomics, no control flow.  (Measured alternatives, all slower on
+                // the KITTI-shaped batch: a running max + an atomic only at the rows that end a run, skipped by scalar or by
+                // exec-mask branches — 16 branches per output tile cost more than the 16 - ~5 atomics they save.)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const float v = relu1(acc[i]);
+                    atomicMax(reinterpret_cast<unsigned *>(sp + pi.soff[i]), __builtin_bit_cast(unsigned, v));      // ds_max_u32
                 }
-                op += c.ld_out;
+            }
+            if (ob == nobm) {
+                // block complete: every group leaves as one row of CB channels, then its slot is zero again
+                const int cbs = pi.cbs;
+                const int ch0 = (o >> (cbs - 5)) << cbs;
+                const int lpg = 1 << (cbs - 2);                     // lanes per group (16 bytes per lane)
+                const int ch = ch0 + 4 * (lane & (lpg - 1));
+                for (int s0 = 0; s0 < pi.ngroups; s0 += 64 >> (cbs - 2)) {       // (wave-uniform)
+                    const int sidx = s0 + (lane >> (cbs - 2));
+                    float4 *src = reinterpret_cast<float4 *>(stage + (s0 << cbs)) + lane;
+                    if (sidx < pi.ngroups) {
+                        const float4 v = *src;
+                        *src = make_float4(0.f, 0.f, 0.f, 0.f);
+                        const bool whole = (sidx > 0 || pi.whole_first) && (sidx < pi.ngroups - 1 || pi.whole_last);
+                        float *orow = c_out + (long long)(pi.g_first + sidx) * ldo + col_off + ch;
+                        if (whole && vec_out && ch + 3 < cout_last) {
+                            *reinterpret_cast<float4 *>(orow) = v;
+                        } else if (ch < cout_last) {
+                            const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) {
+                                if (ch + k >= cout_last) continue;
+                                if (whole) orow[k] = e[k];
+                                else atomic_max_pos(orow + k, e[k]);
+                            }
+                        }
+                    }
+                }
             }
         }
+#ifdef SAD_BR_STAMPS
+        { SAD_BSTAMP(tk2); SAD_BACC(7, tk2, tk1); }
+#endif
     };
     if constexpr (ROLL2) {
         static_assert(RS % PFD == 0 && KS2 % RS == 0, "a rolled tile must start at the same position modulo the stage and the read queue");
@@ -281,6 +360,16 @@ __device__ __forceinline__ void br_tile(const BfRegChain &c, const int tile, con
 #undef BR_BEGIN
 #undef BR_NEXT
     rs.slot = slot;
+#ifdef SAD_BR_STAMPS
+    {
+        SAD_BSTAMP(ts3);
+        SAD_BACC(0, ts1, ts0);      // rows, gather, layer 0
+        SAD_BACC(1, ts2, ts1);      // layer 1
+        SAD_BACC(2, ts3, ts2);      // layer 2 + pooling
+        SAD_BACC(3, 1, 0);          // tiles
+        SAD_BACC(4, (unsigned long long)P, 0ull);   // fragments
+    }
+#endif
 }
 
 // Shapes (sad::bfreg_shape_id):  KS0, NO0, NO1, NO2
@@ -290,21 +379,21 @@ __device__ __forceinline__ void br_tile(const BfRegChain &c, const int tile, con
 //  8: 259 -> 256 -> 256 -> 512 (cluster)     9: 259 -> 256 -> 512 -> 1024
 template <int FAMILY, int NW>
 __device__ __forceinline__ void run_br(const BfRegChain &c, int shape, int tile, const float *sb, int lane, int wave, Ring &rs,
-                                       const float4 *sbase, const float4 *nbase) {
+                                       const float4 *sbase, const float4 *nbase, float *stage) {
     if constexpr (FAMILY == 0) {
-        if (shape == 0) br_tile<1, 1, 1, 1, false, NW, true>(c, tile, sb, lane, wave, rs, sbase, nbase);
-        else if (shape == 1) br_tile<1, 1, 1, 2, false, NW, true>(c, tile, sb, lane, wave, rs, sbase, nbase);
-        else br_tile<1, 2, 2, 4, false, NW, true>(c, tile, sb, lane, wave, rs, sbase, nbase);
+        if (shape == 0) br_tile<1, 1, 1, 1, false, NW, true>(c, tile, sb, lane, wave, rs, sbase, nbase, stage);
+        else if (shape == 1) br_tile<1, 1, 1, 2, false, NW, true>(c, tile, sb, lane, wave, rs, sbase, nbase, stage);
+        else br_tile<1, 2, 2, 4, false, NW, true>(c, tile, sb, lane, wave, rs, sbase, nbase, stage);
     } else if constexpr (FAMILY == 1) {
-        if (shape == 2) br_tile<5, 2, 2, 4, true, NW, false>(c, tile, sb, lane, wave, rs, sbase, nbase);
-        else br_tile<5, 2, 3, 4, true, NW, false>(c, tile, sb, lane, wave, rs, sbase, nbase);
+        if (shape == 2) br_tile<5, 2, 2, 4, true, NW, false>(c, tile, sb, lane, wave, rs, sbase, nbase, stage);
+        else br_tile<5, 2, 3, 4, true, NW, false>(c, tile, sb, lane, wave, rs, sbase, nbase, stage);
     } else if constexpr (FAMILY == 2) {
-        if (shape == 4) br_tile<9, 4, 4, 8, true, NW, false>(c, tile, sb, lane, wave, rs, sbase, nbase);
-        else if (shape == 5) br_tile<9, 4, 6, 8, true, NW, false>(c, tile, sb, lane, wave, rs, sbase, nbase);
-        else br_tile<9, 4, 8, 8, true, NW, false>(c, tile, sb, lane, wave, rs, sbase, nbase);
+        if (shape == 4) br_tile<9, 4, 4, 8, true, NW, false>(c, tile, sb, lane, wave, rs, sbase, nbase, stage);
+        else if (shape == 5) br_tile<9, 4, 6, 8, true, NW, false>(c, tile, sb, lane, wave, rs, sbase, nbase, stage);
+        else br_tile<9, 4, 8, 8, true, NW, false>(c, tile, sb, lane, wave, rs, sbase, nbase, stage);
     } else {
-        if (shape == 8) br_tile<17, 8, 8, 16, true, NW, false>(c, tile, sb, lane, wave, rs, sbase, nbase);
-        else br_tile<17, 8, 16, 32, true, NW, false>(c, tile, sb, lane, wave, rs, sbase, nbase);
+        if (shape == 8) br_tile<17, 8, 8, 16, true, NW, false>(c, tile, sb, lane, wave, rs, sbase, nbase, stage);
+        else br_tile<17, 8, 16, 32, true, NW, false>(c, tile, sb, lane, wave, rs, sbase, nbase, stage);
     }
 }
 
@@ -319,7 +408,9 @@ __global__ __launch_bounds__(BR_NW * 64, FAMILY == 3 ? 1 : 2) void mlp_bf16_reg_
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float4 *ring = reinterpret_cast<float4 *>(smem);
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    float *sbias = smem + (STATICW ? mp.static_f4 : RING_F4) * 4;
+    float *stage = smem + (STATICW ? mp.static_f4 : RING_F4) * 4 + wave * STAGE_F;    // pooled-output staging of this wave
+    for (int i = lane; i < STAGE_F; i += 64) stage[i] = 0.f;
+    float *sbias = smem + (STATICW ? mp.static_f4 : RING_F4) * 4 + NW * STAGE_F;
     static_assert(sad::REG_MAX_CHAINS == 3, "chain selection below is written out for three chains");
     int bo = 0, b1 = 0, b2 = 0;
     for (int ci = 0; ci < mp.n; ++ci) {
@@ -361,6 +452,11 @@ __global__ __launch_bounds__(BR_NW * 64, FAMILY == 3 ? 1 : 2) void mlp_bf16_reg_
     }
     __syncthreads();                                // (also: the biases are in place)
     Ring rs{ring, 0};
+#ifdef SAD_BR_STAMPS
+    const unsigned long long tk0 = __builtin_amdgcn_s_memtime(), tr0 = __builtin_amdgcn_s_memrealtime();
+    if (blockIdx.x < 256 && lane == 0)
+        for (int i = 0; i < 16; ++i) g_brst[(blockIdx.x * 4 + wave) * 16 + i] = 0;
+#endif
     for (; item < nitems; item += (int)gridDim.x) { // (workgroup-uniform)
         const int ci = __builtin_amdgcn_readfirstlane(item < t0 ? 0 : (item < t1 ? 1 : 2));
         const int tg = item - (ci == 0 ? 0 : (ci == 1 ? t0 : t1));
@@ -368,8 +464,14 @@ __global__ __launch_bounds__(BR_NW * 64, FAMILY == 3 ? 1 : 2) void mlp_bf16_reg_
         // the tile's last two stages fetch the first two of the next item (any valid stream when there is none)
         if constexpr (STATICW) rs.ring = ring + (ci == 0 ? 0 : (ci == 1 ? w1 : w2));
         run_br<FAMILY, NW>(mp.c[ci], mp.shape[ci], tg * NW + wave, sbias + (ci == 0 ? 0 : (ci == 1 ? b1 : b2)), lane, wave, rs,
-                           stream_of(item), stream_of(nxt < nitems ? nxt : item));
+                           stream_of(item), stream_of(nxt < nitems ? nxt : item), stage);
     }
+#ifdef SAD_BR_STAMPS
+    if (blockIdx.x < 256 && lane == 0) {
+        g_brst[(blockIdx.x * 4 + wave) * 16 + 12] = __builtin_amdgcn_s_memtime() - tk0;
+        g_brst[(blockIdx.x * 4 + wave) * 16 + 13] = __builtin_amdgcn_s_memrealtime() - tr0;
+    }
+#endif
 }
 
 // fragment stream of one chain in consumption order (see the header): layer 0 in natural k order, layers 1 and 2 in the
@@ -484,7 +586,7 @@ int launch_bfreg(const BfRegMulti &mp, hipStream_t st) {
         mq.c[i].stream_frags = (int)bfreg_stream_frags(mq.shape[i]);
         mq.static_f4 += mq.c[i].stream_frags * 64;
     }
-    lds += sizeof(float4) * (size_t)(fam == 0 ? mq.static_f4 : RING_F4);
+    lds += sizeof(float4) * (size_t)(fam == 0 ? mq.static_f4 : RING_F4) + sizeof(float) * (size_t)BR_NW * STAGE_F;
     switch (fam) {
         case 0: return launch_bfreg_family<0>(mq, lds, st);
         case 1: return launch_bfreg_family<1>(mq, lds, st);
@@ -494,3 +596,9 @@ int launch_bfreg(const BfRegMulti &mp, hipStream_t st) {
 }
 
 }  // namespace sad
+
+#ifdef SAD_BR_STAMPS
+extern "C" __attribute__((visibility("default"))) int sad_debug_read_br_stamps(unsigned long long *dst) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_brst), sizeof(unsigned long long) * 1024 * 16);
+}
+#endif

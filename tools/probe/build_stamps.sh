@@ -5,7 +5,7 @@ cd "$(dirname "$0")/../../3dsad-main_amd/csrc" || exit 1
 mkdir -p ../../build
 F="-O3 --offload-arch=gfx950 -ffp-contract=off -fPIC -fvisibility=hidden -std=c++17 -Wno-unused-function"
 X=""
-case $src in mlp_reg.hip|mlp_coop.hip) X="-mllvm -amdgpu-mfma-vgpr-form -mllvm -pragma-unroll-threshold=4000000";; esac
+case $src in mlp_reg.hip|mlp_coop.hip|mlp_bf16_reg.hip) X="-mllvm -amdgpu-mfma-vgpr-form -mllvm -pragma-unroll-threshold=4000000";; esac
 /opt/rocm/bin/hipcc $F $X "$@" -c $src -o ../../build/${name}_${src%.hip}.o || exit 1
 objs=""
 for f in *.hip; do [ "$f" = "$src" ] || objs="$objs ${f%.hip}.o"; done

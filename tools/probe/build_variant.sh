@@ -8,7 +8,7 @@ objs=""
 for f in *.hip; do
   case " $* " in
     *" $f "*)
-      X=""; case $f in mlp_reg.hip|mlp_coop.hip) X="-mllvm -amdgpu-mfma-vgpr-form -mllvm -pragma-unroll-threshold=4000000";; esac
+      X=""; case $f in mlp_reg.hip|mlp_coop.hip|mlp_bf16_reg.hip) X="-mllvm -amdgpu-mfma-vgpr-form -mllvm -pragma-unroll-threshold=4000000";; esac
       /opt/rocm/bin/hipcc $F $X $defs -c $f -o ../../build/${name}_${f%.hip}.o || exit 1
       objs="$objs ../../build/${name}_${f%.hip}.o";;
     *) objs="$objs ${f%.hip}.o";;
