@@ -600,7 +600,7 @@ def grouped_multi(calls) -> None:
         for c in calls:
             mlp, xyz, feat_pm, new_xyz, idx, out, col_off, cnt = c[:8]
             mlp.grouped(xyz, feat_pm, new_xyz, idx, out=out, col_off=col_off, cnt=cnt)
-        if AUTOTUNE and len(calls) >= 2 and isinstance(calls[0][0], PackedMLP):
+        if AUTOTUNE and len(calls) >= 2:
             _tune_stage([c[:8] for c in calls])
         return
     args, keep = [], []
@@ -632,6 +632,9 @@ def _tune_stage(calls) -> None:
     that is slower on its own (few tiles) may still be best inside the merged dispatch.  Times the merged
     dispatch with the per-chain picks against all-2 and all-3 and keeps the fastest assignment."""
     stream = torch.cuda.current_stream()
+    bf16 = isinstance(calls[0][0], PackedMLPBf16)
+    fn = lib().sad_mlp_chain_multi_bf16 if bf16 else lib().sad_mlp_chain_multi_f32
+    args_cls = _lib.MlpBf16Args if bf16 else MlpArgs
     keys = []
     for mlp, xyz, feat_pm, new_xyz, idx, out, col_off, cnt in calls:
         a, _, _ = mlp._grouped_args(xyz, feat_pm, new_xyz, idx, out, col_off, cnt)
@@ -644,8 +647,8 @@ def _tune_stage(calls) -> None:
             a.geometry = code
             args.append(a)
             keep.append(k)
-        arr = (ctypes.POINTER(MlpArgs) * len(args))(*[ctypes.pointer(a) for a in args])
-        if lib().sad_mlp_chain_multi_f32(arr, len(args), _stream()) != 0:
+        arr = (ctypes.POINTER(args_cls) * len(args))(*[ctypes.pointer(a) for a in args])
+        if fn(arr, len(args), _stream()) != 0:
             return None
         stream.synchronize()
         best = None
@@ -653,7 +656,7 @@ def _tune_stage(calls) -> None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(stream)
             for _ in range(4):
-                lib().sad_mlp_chain_multi_f32(arr, len(args), _stream())
+                fn(arr, len(args), _stream())
             e1.record(stream)
             stream.synchronize()
             ms = e0.elapsed_time(e1) / 4
@@ -662,7 +665,7 @@ def _tune_stage(calls) -> None:
 
     picked = [c[0]._geom.get(k) or 0 for c, k in zip(calls, keys)]
     best, t_best = picked, run(picked)
-    for code in (2, 3, 4):           # the kernels whose chains share launches: register-resident, layer-streamed, cooperative
+    for code in ((2,) if bf16 else (2, 3, 4)):   # the kernels whose chains share launches (f32: register-resident, layer-streamed, cooperative)
         if all(p == code for p in picked):
             continue
         t = run([code] * len(calls))

@@ -203,7 +203,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=32, help="scenes per GPU per step")
     ap.add_argument("--no-overlap", action="store_true", help="run FPS on the main stream")
-    ap.add_argument("--fps-streams", type=int, default=2, help="sampling streams used round-robin")
+    ap.add_argument("--fps-streams", type=int, default=None,
+                    help="sampling streams used round-robin (default: 2 for f32, 4 for bf16 - the bf16 MLP dispatches are short "
+                         "enough that the serial FPS chain of a batch, 2.9 ms, bounds the step unless four chains overlap)")
     ap.add_argument("--main-streams", type=int, default=2, help="main streams used round-robin by consecutive steps")
     ap.add_argument("--queue-depth", type=int, default=6, help="steps in flight before the host waits for the oldest")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg (parity_check then uses 4 scenes)")
@@ -225,6 +227,8 @@ def main():
                          "the headline metric is the f32 default")
     ap.add_argument("--opt", action="append", default=[], help="tuning knob key=value (sad_set_option)")
     args = ap.parse_args()
+    if args.fps_streams is None:
+        args.fps_streams = 2 if args.dtype == "f32" else 4
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` as the driver runs it: start the N ranks ourselves (as a child process, before
