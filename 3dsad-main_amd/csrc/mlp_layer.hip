@@ -17,78 +17,15 @@
 
 namespace {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-constexpr int WHOLE_BIT = 1 << 30;
+// MFMA operand shuffles (swap32 / to_operands / mma4), the two-operation DPP segmented max-scan (pool_masks / seg_max16)
+// and atomic_max_pos are the register-resident kernels' (reg_common.h): one copy of each
+#include "reg_common.h"
+
 constexpr int LWAVES = 4;         // waves per workgroup (independent)
 constexpr int SLOTS = 16;         // pooled-output staging slots per wave and row tile (groups ending in the tile)
 
 using sad::LayerJob;
 using sad::LayerMulti;
-
-
-struct Swapped { float lo, hi; };
-__device__ __forceinline__ Swapped swap32(float a, float b) {
-    const auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b), false, false);
-    const unsigned r0 = r[0], r1 = r[1];   // (copy first: bit_cast on r[1] directly reads element 0 with this hipcc)
-    return {__builtin_bit_cast(float, r0), __builtin_bit_cast(float, r1)};
-}
-// (c0..c3 | c4..c7) in v -> operands of the four MFMAs of the k-group: out[e] = (c_{2e} | c_{2e+1})
-__device__ __forceinline__ void to_operands(const float4 v, float *out) {
-    const Swapped s01 = swap32(v.x, v.y), s23 = swap32(v.z, v.w);
-    out[0] = s01.lo; out[1] = s23.lo; out[2] = s01.hi; out[3] = s23.hi;
-}
-__device__ __forceinline__ f32x16 mma4(f32x16 acc, const float4 a, const float *b) {
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b[0], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b[1], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b[2], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b[3], acc, 0, 0, 0);
-    return acc;
-}
-template <int CTRL, int ROWMASK>
-__device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, ROWMASK, 0xF, true); }
-struct PoolMasks {
-    int m[5];
-    bool any[5];     // (wave-uniform) some lane takes part in step k; a step nobody takes part in is skipped (identity)
-};
-__device__ __forceinline__ PoolMasks pool_masks(int key) {
-    PoolMasks pm;
-    pm.m[0] = dpp_i<0x111, 0xF>(key) == key ? -1 : 0;
-    pm.m[1] = dpp_i<0x112, 0xF>(key) == key ? -1 : 0;
-    pm.m[2] = dpp_i<0x114, 0xF>(key) == key ? -1 : 0;
-    pm.m[3] = dpp_i<0x118, 0xF>(key) == key ? -1 : 0;
-    pm.m[4] = dpp_i<0x142, 0xA>(key) == key ? -1 : 0;
-#pragma unroll
-    for (int k = 0; k < 5; ++k) pm.any[k] = __ballot(pm.m[k] != 0) != 0;
-    return pm;
-}
-// segmented inclusive max-scan over the 32 rows (values >= 0), all 16 registers step by step (see mlp_reg.hip)
-__device__ __forceinline__ f32x16 seg_max16(f32x16 t, const PoolMasks &pm) {
-    int x[16];
-#pragma unroll
-    for (int g = 0; g < 16; ++g) {
-        const float f = t[g];
-        x[g] = __builtin_bit_cast(int, f);
-    }
-#define SAD_STEP(CTRL, RM, K)                                       \
-    if (pm.any[K]) {                                                \
-        _Pragma("unroll") for (int g = 0; g < 16; ++g) {            \
-            const int u = dpp_i<CTRL, RM>(x[g]) & pm.m[K];          \
-            x[g] = u > x[g] ? u : x[g];                             \
-        }                                                           \
-    }
-    SAD_STEP(0x111, 0xF, 0)
-    SAD_STEP(0x112, 0xF, 1)
-    SAD_STEP(0x114, 0xF, 2)
-    SAD_STEP(0x118, 0xF, 3)
-    SAD_STEP(0x142, 0xA, 4)
-#undef SAD_STEP
-#pragma unroll
-    for (int g = 0; g < 16; ++g) t[g] = __builtin_bit_cast(float, x[g]);
-    return t;
-}
-__device__ __forceinline__ void atomic_max_pos(float *addr, float v) {
-    atomicMax(reinterpret_cast<unsigned *>(addr), __builtin_bit_cast(unsigned, v));
-}
 
 // ---- workgroup-cooperative layer GEMM --------------------------------------------------------------------
 // Measured on this chip (tools/probe/kloop_probe.hip, kloop2_probe.hip): a wave-wide 16-byte global load costs the
@@ -196,7 +133,7 @@ __device__ __forceinline__ void gemm_item(const LayerJob &jb, const int rb, cons
             }
             if (g >= KG) v = make_float4(0.f, 0.f, 0.f, 0.f);      // padding k-group of the last chunk: x = 0 leaves every chain unchanged
             float ops[4];
-            to_operands(v, ops);
+            to_operands(v.x, v.y, v.z, v.w, ops);
             st[(u * 8 + 4 + wave) * 64 + lane] = make_float4(ops[0], ops[1], ops[2], ops[3]);
         }
     };

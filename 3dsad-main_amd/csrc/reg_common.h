@@ -46,15 +46,14 @@ __device__ __forceinline__ f32x16 bias_tile(const float *sb, int h) {   // sb: 3
     return t;
 }
 
-// x > 0 ? x : 0 as ONE v_max_f32 per register (a NaN gives 0 like the comparison does): written as `x > 0 ? x : 0`
-// the compiler emits a canonicalising v_max_f32 v, v, v in front of it, 16 more vector-ALU operations per tile
+// x > 0 ? x : 0 as ONE vector-ALU operation per register: v_med3_f32(x, 0, +inf).  Written as `x > 0 ? x : 0` the compiler
+// emits a canonicalising v_max_f32 v, v, v in front of the compare, 16 more operations per tile.  Until round 3 this was a
+// v_max_f32 in an asm statement; hipcc pads no MFMA -> VALU wait states for instructions inside asm (the bf16 chain kernel
+// read stale accumulators that way), so the operation is a builtin the hazard recogniser knows.  Same bits for every
+// finite x and for -0 (both give +0).
 __device__ __forceinline__ f32x16 relu16(f32x16 t) {
 #pragma unroll
-    for (int g = 0; g < 16; ++g) {
-        float x = t[g], y;
-        asm("v_max_f32 %0, 0, %1" : "=v"(y) : "v"(x));
-        t[g] = y;
-    }
+    for (int g = 0; g < 16; ++g) t[g] = __builtin_amdgcn_fmed3f(t[g], 0.f, __builtin_inff());
     return t;
 }
 
