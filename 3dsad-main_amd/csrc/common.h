@@ -99,6 +99,20 @@ struct BfRegMulti {
     long long max_tiles;
     int static_f4;                 // family 0: float4 of all chains' stream images held in LDS (filled by launch_bfreg)
 };
+// One plain-row bf16 layer (csrc/mlp_bf16_rows.hip)
+struct BfRowsJob {
+    const void *x;                 // rows [rows, ldx], bf16 (x_bf16) or f32
+    int x_bf16, ldx, kin;          // kin = input channels (a multiple of 8)
+    long long rows;
+    const void *w;                 // fragment image of the layer: [channel tile][k-step][lane] x 8 bf16
+    const float *bias;             // padded to a multiple of 32
+    int ks, ct, cout;              // k-steps of 16, channel tiles of 32, true output channels
+    int relu;
+    void *out;                     // rows [rows, ld_out], f32 or bf16 (out_bf16)
+    int out_bf16, ld_out, col_off, vec_out;
+    int nrb, ncb;                  // (filled by launch_bf16_rows) row blocks of 128, channel blocks of 128
+};
+int launch_bf16_rows(const BfRowsJob &job, hipStream_t st);
 int bfreg_shape_id(int L, const int *dims);        // dims = {C + 3, C1, C2, C3}; -1: no compiled shape
 int bfreg_family(int shape);
 long long bfreg_stream_frags(int shape);           // 1-KB fragments of the stream image (whole stages)

@@ -516,6 +516,8 @@ struct BfPrepared {
     BfParams p;
     size_t lds;
     int grid;
+    bool rows;              // plain single layer on the row-streaming kernel (mlp_bf16_rows.hip); `rj` is filled, p is not
+    sad::BfRowsJob rj;
     bool reg;               // geometry 2: register-resident chain (mlp_bf16_reg.hip); `rc` is filled, p is not
     sad::BfRegChain rc;
     int reg_shape;
@@ -555,7 +557,30 @@ static int prepare_bf16(const sad_mlp_bf16_args *a, sad_stream_t stream, BfPrepa
     p.L = a->L; p.relu_mask = a->relu_mask;
     p.out = a->out; p.out_bf16 = a->out_bf16; p.ld_out = a->ld_out; p.col_off = a->col_off;
     prep.reg = false;
+    prep.rows = false;
     prep.prescanned = a->prescanned != 0;
+    if (!grouped && a->L == 1 && (a->geometry == 0 || a->geometry == 3)) {
+        // ---- one plain layer: the row-streaming kernel (every input row read once per 128 output channels) ----
+        const size_t esz = a->feat_bf16 ? 2 : 4;
+        const bool ok = (a->C & 7) == 0 && ((size_t)a->ld_feat * esz) % 16 == 0 && (uintptr_t)a->feat % 16 == 0;
+        if (ok) {
+            sad::BfRowsJob &j = prep.rj;
+            j = sad::BfRowsJob{};
+            j.x = a->feat; j.x_bf16 = a->feat_bf16; j.ldx = a->ld_feat; j.kin = a->C; j.rows = p.rows;
+            const int kp = kpad(0, a->dims[0]), CT = (a->dims[1] + 31) / 32;
+            j.w = a->packed;
+            j.bias = (const float *)((const unsigned char *)a->packed + align16((size_t)CT * 32 * kp * 2));
+            j.ks = kp / 16; j.ct = CT; j.cout = a->dims[1];
+            j.relu = a->relu_mask & 1;
+            j.out = a->out; j.out_bf16 = a->out_bf16; j.ld_out = a->ld_out; j.col_off = a->col_off;
+            const size_t osz = a->out_bf16 ? 2 : 4;
+            j.vec_out = ((size_t)a->ld_out * osz) % (4 * osz) == 0 && ((size_t)a->col_off * osz) % (4 * osz) == 0 &&
+                        (uintptr_t)a->out % (4 * osz) == 0;
+            prep.rows = true;
+            return SAD_OK;
+        }
+        if (a->geometry == 3) return sad::fail(SAD_EUNSUPPORTED, "sad_mlp_chain_bf16: geometry 3 (row-streaming layer) needs C %% 8 == 0 and 16-byte aligned rows");
+    }
     if (a->geometry == 2) {
         // ---- register-resident chain: one wave per 32-row tile, activations in registers, weights through an LDS ring ----
         const int shape = grouped ? sad::bfreg_shape_id(a->L, a->dims) : -1;
@@ -612,7 +637,7 @@ static int prepare_bf16(const sad_mlp_bf16_args *a, sad_stream_t stream, BfPrepa
     const size_t budget = 150 * 1024;
     int R = 128;
     auto lds_of = [&](int r) { return (((size_t)r * 2 * (ldA + ldB) + 15) & ~(size_t)15) + (size_t)(2 * r + 4) * sizeof(int); };
-    if (a->geometry) {     // forced rows per tile (autotuners): 32 / 64 / 128 / 256 (2 = the register-resident chain, above)
+    if (a->geometry) {     // forced rows per tile (autotuners): 32 / 64 / 128 / 256 (2 = the register-resident chain, 3 = the row-streaming layer, above)
         SAD_REQUIRE(a->geometry == 32 || a->geometry == 64 || a->geometry == 128 || a->geometry == 256,
                     "sad_mlp_chain_bf16: geometry (rows per tile) must be 32, 64, 128 or 256");
         R = a->geometry;
@@ -671,6 +696,7 @@ static int launch_bfreg_chains(const BfPrepared *const *qs, int n, hipStream_t s
 SAD_API int sad_mlp_chain_bf16(const sad_mlp_bf16_args *a, sad_stream_t stream) {
     BfPrepared q;
     if (int e = prepare_bf16(a, stream, q)) return e;
+    if (q.rows) return sad::launch_bf16_rows(q.rj, (hipStream_t)stream);
     if (q.reg) {
         const BfPrepared *one = &q;
         return launch_bfreg_chains(&one, 1, (hipStream_t)stream);
@@ -692,11 +718,16 @@ SAD_API int sad_mlp_chain_multi_bf16(const sad_mlp_bf16_args *const *args, int n
         if (int e = prepare_bf16(args[i], stream, q[i])) return e;
     {   // register-resident chains: one dispatch per shape family, heaviest chain first
         bool any_reg = false;
-        for (int i = 0; i < n; ++i) any_reg = any_reg || q[i].reg;
+        for (int i = 0; i < n; ++i) any_reg = any_reg || q[i].reg || q[i].rows;
         if (any_reg) {
             bool done[BF_MULTI_MAX] = {};
             for (int i = 0; i < n; ++i) {
                 if (done[i]) continue;
+                if (q[i].rows) {
+                    if (int e = sad::launch_bf16_rows(q[i].rj, (hipStream_t)stream)) return e;
+                    done[i] = true;
+                    continue;
+                }
                 if (!q[i].reg) {
                     bf16_attrs();
                     hipLaunchKernelGGL(mlp_bf16_kernel, dim3(q[i].grid), dim3(BF_T), q[i].lds, (hipStream_t)stream, q[i].p);

@@ -1,0 +1,201 @@
+// One plain-row layer  out[row, :] = act(W . x[row, :] + b)  in bfloat16 on the gfx950 matrix cores: the stage
+// aggregations of the bf16 mode (SPEC.md §14; sa1.agg 128 -> 64 on 131 072 rows ... cluster.agg 1536 -> 512 on 8 192 rows
+// per 32-scene step).  No reference source exists (/root/reference/README.md:1-2 is the whole upstream repository).
+//
+// These layers are memory-bound (their input is the f32 pooled output of the stage: 50 - 67 MB per step, 2 - 13 GFLOP), so the
+// kernel is built around reading every input row exactly once per channel block and keeping many bytes in flight:
+//   * work item = 128 rows x up to 128 output channels, four waves, wave w owns row tile w (32 rows) and ALL channel tiles
+//     of the item: its x operand never goes through LDS — lane (r, h) loads the 8 consecutive k of its row straight from
+//     memory (two 16-byte loads of f32, or one of bf16), rounds once and has the MFMA B fragment;
+//   * the weight fragments of a k-chunk (64 k x 128 channels = 16 KB) are shared by the four waves through two LDS stages
+//     (each wave fetches a quarter, one barrier per chunk);
+//   * the next chunk's rows are in flight while the current one is multiplied;
+//   * items that share a row block run on the same XCD back to back (channel block fastest within an XCD's slots), so the
+//     2nd .. 4th read of a row block is an L2 hit;
+//   * D[cout, row] = W . X^T: a lane holds 4 consecutive channels of its row per accumulator quad: 8-byte (bf16) or 16-byte
+//     (f32) stores.
+// Same arithmetic as mlp_bf16.hip (bf16 products, binary32 accumulation in the matrix core, order unspecified): SPEC §14 tolerance.
+#include "common.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+using sad::BfRowsJob;
+
+constexpr int KC = 4;                 // k-steps (of 16) per chunk
+
+__device__ __forceinline__ bf16x8 cvt8(const float4 a, const float4 b) {
+    bf16x8 v;
+    v[0] = (__bf16)a.x; v[1] = (__bf16)a.y; v[2] = (__bf16)a.z; v[3] = (__bf16)a.w;
+    v[4] = (__bf16)b.x; v[5] = (__bf16)b.y; v[6] = (__bf16)b.z; v[7] = (__bf16)b.w;
+    return v;
+}
+
+// NT = channel tiles (of 32) per item: 4, or 2 for layers with at most 64 output channels
+template <bool XBF16, int NT>
+__global__ __launch_bounds__(256) void bf16_rows_kernel(const BfRowsJob jb) {
+    constexpr int STAGE_F4 = KC * NT * 64;
+    __shared__ __attribute__((aligned(16))) float4 lds[2 * STAGE_F4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int KS = jb.ks;                         // k-steps of the layer (K padded to 16)
+    const int NC = (KS + KC - 1) / KC;
+    const int ncb = jb.ncb, nrb = jb.nrb;
+    // XCD-aware item order: workgroup g runs on XCD g % 8; its slot g / 8 walks (row block, channel block) with the channel
+    // block fastest, row blocks dealt round-robin to the XCDs
+    const int g = blockIdx.x;
+    const int xcd = g & 7, slot = g >> 3;
+    const int rb = xcd + 8 * (slot / ncb), cb = slot % ncb;
+    if (rb >= nrb) return;
+    const int nt = jb.ct - cb * NT < NT ? jb.ct - cb * NT : NT;        // channel tiles of this item (1..4)
+    const long long row = (long long)rb * 128 + wave * 32 + r;
+    const bool live = row < jb.rows;
+    const long long rowc = live ? row : jb.rows - 1;
+    const float4 *wimg = reinterpret_cast<const float4 *>(jb.w) + (size_t)(cb * NT) * KS * 64;      // [tile][k-step][lane]
+    const unsigned ulane = (unsigned)lane;
+
+    // this lane's x: 8 consecutive k at k = 16 s + 8 h of its row
+    const char *xrow = reinterpret_cast<const char *>(jb.x) + (size_t)rowc * jb.ldx * (XBF16 ? 2 : 4);
+    struct XRaw { float4 a[KC], b[KC]; };
+    auto load_x = [&](int c) -> XRaw {
+        XRaw v;
+#pragma unroll
+        for (int s = 0; s < KC; ++s) {
+            int ks = c * KC + s;
+            ks = ks < KS ? ks : KS - 1;
+            const int k = 16 * ks + 8 * h;
+            const bool ok = k < jb.kin;            // (K is a multiple of 8: a chunk of 8 is all inside or all padding)
+            const int kk = ok ? k : 0;
+            if constexpr (XBF16) {
+                v.a[s] = *reinterpret_cast<const float4 *>(xrow + (size_t)kk * 2);
+                v.b[s] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (!ok) v.a[s] = make_float4(0.f, 0.f, 0.f, 0.f);
+            } else {
+                v.a[s] = *reinterpret_cast<const float4 *>(xrow + (size_t)kk * 4);
+                v.b[s] = *reinterpret_cast<const float4 *>(xrow + (size_t)kk * 4 + 16);
+                if (!ok) { v.a[s] = make_float4(0.f, 0.f, 0.f, 0.f); v.b[s] = v.a[s]; }
+            }
+        }
+        return v;
+    };
+    // this wave's quarter of the weight fragments of chunk c: fragment f = wave * NT + i -> (k-step f / NT of the chunk, tile f % NT)
+    struct WRaw { float4 f[NT]; };
+    auto load_w = [&](int c) -> WRaw {
+        WRaw v;
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+            const int f = wave * NT + i;
+            int ks = c * KC + (f / NT);
+            ks = ks < KS ? ks : KS - 1;
+            const int t = (f % NT) < nt ? (f % NT) : 0;
+            v.f[i] = (wimg + ((size_t)t * KS + ks) * 64)[ulane];
+        }
+        return v;
+    };
+    auto store_w = [&](const WRaw &v, float4 *st) {
+#pragma unroll
+        for (int i = 0; i < NT; ++i) st[(wave * NT + i) * 64 + lane] = v.f[i];
+    };
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const float *bias = jb.bias + (cb * NT + (t < nt ? t : 0)) * 32;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 bv = *reinterpret_cast<const float4 *>(bias + 8 * q + 4 * h);
+            acc[t][4 * q] = bv.x; acc[t][4 * q + 1] = bv.y; acc[t][4 * q + 2] = bv.z; acc[t][4 * q + 3] = bv.w;
+        }
+    }
+    XRaw xn = load_x(0);
+    {
+        const WRaw w0 = load_w(0);
+        store_w(w0, lds);
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int c = 0; c < NC; ++c) {
+        const float4 *cur = lds + (c & 1) * STAGE_F4;
+        bf16x8 x[KC];
+#pragma unroll
+        for (int s = 0; s < KC; ++s) x[s] = XBF16 ? __builtin_bit_cast(bf16x8, xn.a[s]) : cvt8(xn.a[s], xn.b[s]);
+        const int cn = c + 1 < NC ? c + 1 : c;
+        xn = load_x(cn);                            // the next chunk's rows and weights are in flight during the MFMAs
+        const WRaw wn = load_w(cn);
+#pragma unroll
+        for (int s = 0; s < KC; ++s) {
+            if (c * KC + s < KS) {                  // (wave-uniform: the padded k-steps of the last chunk are skipped)
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+                    if (t < nt)
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, cur[(s * NT + t) * 64 + lane]), x[s], acc[t], 0, 0, 0);
+            }
+        }
+        if (c + 1 < NC) store_w(wn, lds + ((c + 1) & 1) * STAGE_F4);
+        __syncthreads();
+    }
+    // ---- epilogue: lane = row, registers 4q .. 4q+3 = channels 32 t + 8 q + 4 h .. + 3 ----
+    if (!live) return;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        if (t >= nt) continue;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int co = (cb * NT + t) * 32 + 8 * q + 4 * h;
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float a = acc[t][4 * q + e];
+                v[e] = jb.relu ? __builtin_amdgcn_fmed3f(a, 0.f, __builtin_inff()) : a;
+            }
+            if (jb.out_bf16) {
+                __bf16 *o = reinterpret_cast<__bf16 *>(jb.out) + (size_t)row * jb.ld_out + jb.col_off + co;
+                if (co + 3 < jb.cout && jb.vec_out) {
+                    bf16x4 pk;
+                    pk[0] = (__bf16)v[0]; pk[1] = (__bf16)v[1]; pk[2] = (__bf16)v[2]; pk[3] = (__bf16)v[3];
+                    *reinterpret_cast<bf16x4 *>(o) = pk;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (co + e < jb.cout) o[e] = (__bf16)v[e];
+                }
+            } else {
+                float *o = reinterpret_cast<float *>(jb.out) + (size_t)row * jb.ld_out + jb.col_off + co;
+                if (co + 3 < jb.cout && jb.vec_out) {
+                    *reinterpret_cast<float4 *>(o) = make_float4(v[0], v[1], v[2], v[3]);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (co + e < jb.cout) o[e] = v[e];
+                }
+            }
+        }
+    }
+}
+
+}  // namespace
+
+namespace sad {
+
+int launch_bf16_rows(const BfRowsJob &job, hipStream_t st) {
+    BfRowsJob jb = job;
+    jb.nrb = (int)((jb.rows + 127) / 128);
+    // (two tiles per item for layers with few rows — twice the workgroups — measured slower: cluster.agg 70 vs 50 us, the
+    // weights and the rows are then read twice as often)
+    const int nt = jb.ct > 2 ? 4 : 2;
+    jb.ncb = (jb.ct + nt - 1) / nt;
+    const long long grid = 8LL * ((jb.nrb + 7) / 8) * jb.ncb;
+    if (grid >= (1LL << 31)) return fail(SAD_EINVAL, "sad_mlp_chain_bf16: too many rows");
+    if (nt == 4) {
+        if (jb.x_bf16) hipLaunchKernelGGL((bf16_rows_kernel<true, 4>), dim3((unsigned)grid), dim3(256), 0, st, jb);
+        else hipLaunchKernelGGL((bf16_rows_kernel<false, 4>), dim3((unsigned)grid), dim3(256), 0, st, jb);
+    } else {
+        if (jb.x_bf16) hipLaunchKernelGGL((bf16_rows_kernel<true, 2>), dim3((unsigned)grid), dim3(256), 0, st, jb);
+        else hipLaunchKernelGGL((bf16_rows_kernel<false, 2>), dim3((unsigned)grid), dim3(256), 0, st, jb);
+    }
+    return check_launch("sad_mlp_chain_bf16 (plain-row layer)");
+}
+
+}  // namespace sad

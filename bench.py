@@ -33,10 +33,11 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-# HIP multiplexes streams onto 4 hardware queues by default; this pipeline uses two main streams and
-# four sampling streams, and a 3 ms FPS kernel sharing a queue with MLP launches would serialise
-# them.  Must be set before the runtime initialises.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# HIP multiplexes streams onto 4 hardware queues by default; this pipeline uses two main streams, up to eight
+# sampling streams and the gather stream, and a 3 - 16 ms FPS kernel sharing a queue with MLP launches (or with
+# another FPS chain) would serialise them (measured: six FPS chains side by side keep their single-stream time,
+# eight on 8 queues take twice as long - tools/fps_concurrency.py).  Must be set before the runtime initialises.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 PEAK_MFMA_F32_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: dense f32 MFMA
 PEAK_MFMA_BF16_TFLOPS = 2500.0 # same guide: dense bf16 MFMA (not the 2:1-sparsity headline)
@@ -204,10 +205,11 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="scenes per GPU per step")
     ap.add_argument("--no-overlap", action="store_true", help="run FPS on the main stream")
     ap.add_argument("--fps-streams", type=int, default=None,
-                    help="sampling streams used round-robin (default: 2 for f32, 4 for bf16 - the bf16 MLP dispatches are short "
-                         "enough that the serial FPS chain of a batch, 2.9 ms, bounds the step unless four chains overlap)")
+                    help="sampling streams used round-robin (default: 2 for f32; bf16: 6 for kitti, 8 for nuscenes - the bf16 MLP "
+                         "dispatches are short enough that the serial FPS chain of a batch bounds the step otherwise)")
     ap.add_argument("--main-streams", type=int, default=2, help="main streams used round-robin by consecutive steps")
-    ap.add_argument("--queue-depth", type=int, default=6, help="steps in flight before the host waits for the oldest")
+    ap.add_argument("--queue-depth", type=int, default=None,
+                    help="steps in flight before the host waits for the oldest (default: max(6, sampling streams + 2))")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg (parity_check then uses 4 scenes)")
     ap.add_argument("--cpu-scenes", type=int, default=32)
     ap.add_argument("--no-launch-timing", action="store_true", help="skip the per-launch event passes (roofline / kernels)")
@@ -227,8 +229,10 @@ def main():
                          "the headline metric is the f32 default")
     ap.add_argument("--opt", action="append", default=[], help="tuning knob key=value (sad_set_option)")
     args = ap.parse_args()
-    if args.fps_streams is None:
-        args.fps_streams = 2 if args.dtype == "f32" else 4
+    if args.fps_streams is None:      # the serial FPS chain of a batch (2.9 ms KITTI, 15.6 ms nuScenes) must not bound the step
+        args.fps_streams = 2 if args.dtype == "f32" else (6 if args.config == "kitti" else 8)
+    if args.queue_depth is None:
+        args.queue_depth = max(6, args.fps_streams + 2)
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` as the driver runs it: start the N ranks ourselves (as a child process, before

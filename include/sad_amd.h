@@ -279,7 +279,9 @@ typedef struct sad_mlp_bf16_args {
      * 2 = register-resident chain (grouped 3-layer chains with cnt + workspace whose shape is compiled: the SA stages
      *     and the cluster layer of the KITTI / nuScenes / TINY topologies and configs[0]; 16-byte bf16 feature rows,
      *     or at most 13 feature channels of either type): one wave carries a 32-row tile through the chain in
-     *     registers, weights through an LDS ring, pooled rows leave as 128-byte stores */
+     *     registers, weights through an LDS ring, pooled rows staged in LDS and stored once per group;
+     * 3 = row-streaming layer (plain single layers: C % 8 == 0, 16-byte aligned rows; also what 0 picks for them):
+     *     every input row is read once per 128 output channels, weights shared through LDS */
     int geometry;
     /* != 0: `workspace` already holds the row-packing table of (cnt, idx) from sad_mlp_rowscan (geometry 2 only) */
     int prescanned;
