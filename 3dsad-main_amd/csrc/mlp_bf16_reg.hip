@@ -92,11 +92,30 @@ struct PoolInfo {
     bool whole_first, whole_last;   // the first / last group of the tile has no rows in another tile
 };
 
+// Row-map entries of a wave's NEXT tile, fetched while the current one runs: the gather is a chain of dependent round
+// trips (row map -> feature row / coordinates), and with two waves per SIMD nothing hides the first of them
+struct NextRows {
+    int src, gvq, gvn;  // row_src / row_gid of this lane's row pi(r), row_gid of tile row r (natural order)
+};
+__device__ __forceinline__ NextRows fetch_rows(const BfRegChain &c, int tile, int total, int lane) {
+    const int r = lane & 31;
+    const int rho = 16 * ((r >> 2) & 1) + 4 * (r >> 3) + (r & 3);
+    int q = tile * 32 + rho, qt = tile * 32 + r;
+    q = q < total ? q : total - 1;                  // rows past the end (and whole tiles past it) repeat the last row and store nothing
+    qt = qt < total ? qt : total - 1;
+    NextRows n;
+    n.src = c.row_src[q];
+    n.gvq = c.row_gid[q];
+    n.gvn = c.row_gid[qt];
+    return n;
+}
+
 // STATICW: the chain's whole fragment stream sits in LDS for the lifetime of the workgroup (the narrow first-stage chains:
 // 3 - 22 fragments) — no ring, no barriers, the waves of a workgroup are independent; `rs.ring` then points at that image.
 template <int KS0, int NO0, int NO1, int NO2, bool VEC0, int NW, bool STATICW>
 __device__ __forceinline__ void br_tile(const BfRegChain &c, const int tile, const float *__restrict__ sbias, const int lane, const int wave,
-                                        Ring &rs, const float4 *__restrict__ sbase, const float4 *__restrict__ nbase, float *stage) {
+                                        Ring &rs, const float4 *__restrict__ sbase, const float4 *__restrict__ nbase, float *stage,
+                                        const int total, NextRows &rows, const BfRegChain &nc, const int ntile, const int ntotal) {
     constexpr int KS1 = 2 * NO0, KS2 = 2 * NO1;
     constexpr int CB = stage_cb(NO2);                     // widest staged block of this chain (channels)
     constexpr int P0 = NO0 * KS0, P1 = NO1 * KS1, P2 = NO2 * KS2, P = P0 + P1 + P2;
@@ -105,13 +124,10 @@ __device__ __forceinline__ void br_tile(const BfRegChain &c, const int tile, con
     constexpr bool ROLL2 = (KS2 % RS == 0) && NO2 > 4;      // layer-2 tiles span whole stages: loop over them stays rolled
     const int r = lane & 31, h = lane >> 5;
     SAD_BSTAMP(ts0);
-    const int total = c.rowtab[0];
-    // ---- rows: lane r carries packed row pi(r) of the tile --------------------------------------------------
-    const int rho = 16 * ((r >> 2) & 1) + 4 * (r >> 3) + (r & 3);
-    int q = tile * 32 + rho;
-    if (q >= total) q = total - 1;                  // rows past the end (and whole tiles past it) repeat the last row and store nothing
-    const int src = c.row_src[q];
-    const int grp = c.row_gid[q] & (WHOLE_BIT - 1);
+    // ---- rows: lane r carries packed row pi(r) of the tile (its row-map entries were fetched during the previous tile) ----
+    const int src = rows.src;
+    const int grp = rows.gvq & (WHOLE_BIT - 1);
+    const int gv_nat = rows.gvn;
     float rel[3];
     {
         const float *pq = c.xyz + (long long)src * 3;
@@ -147,13 +163,12 @@ __device__ __forceinline__ void br_tile(const BfRegChain &c, const int tile, con
             x0[ks] = v;
         }
     }
+    rows = fetch_rows(nc, ntile, ntotal, lane);     // (consumed by this wave's next tile)
     // ---- pooling bookkeeping (lane t < 32 looks at tile row t in natural order; both halves compute the same) ----
     PoolInfo pi;
     {
-        int qt = tile * 32 + r;
-        const bool live = qt < total;
-        if (!live) qt = total - 1;
-        const int gv = c.row_gid[qt];
+        const bool live = tile * 32 + r < total;
+        const int gv = gv_nat;
         const int g = gv & (WHOLE_BIT - 1);
         const int gprev = __shfl_up(g, 1, 64);
         const bool same_prev = r > 0 && gprev == g;                 // (rows past the end repeat the last row: same group)
@@ -379,21 +394,22 @@ __device__ __forceinline__ void br_tile(const BfRegChain &c, const int tile, con
 //  8: 259 -> 256 -> 256 -> 512 (cluster)     9: 259 -> 256 -> 512 -> 1024
 template <int FAMILY, int NW>
 __device__ __forceinline__ void run_br(const BfRegChain &c, int shape, int tile, const float *sb, int lane, int wave, Ring &rs,
-                                       const float4 *sbase, const float4 *nbase, float *stage) {
+                                       const float4 *sbase, const float4 *nbase, float *stage, int total, NextRows &rows,
+                                       const BfRegChain &nc, int ntile, int ntotal) {
     if constexpr (FAMILY == 0) {
-        if (shape == 0) br_tile<1, 1, 1, 1, false, NW, true>(c, tile, sb, lane, wave, rs, sbase, nbase, stage);
-        else if (shape == 1) br_tile<1, 1, 1, 2, false, NW, true>(c, tile, sb, lane, wave, rs, sbase, nbase, stage);
-        else br_tile<1, 2, 2, 4, false, NW, true>(c, tile, sb, lane, wave, rs, sbase, nbase, stage);
+        if (shape == 0) br_tile<1, 1, 1, 1, false, NW, true>(c, tile, sb, lane, wave, rs, sbase, nbase, stage, total, rows, nc, ntile, ntotal);
+        else if (shape == 1) br_tile<1, 1, 1, 2, false, NW, true>(c, tile, sb, lane, wave, rs, sbase, nbase, stage, total, rows, nc, ntile, ntotal);
+        else br_tile<1, 2, 2, 4, false, NW, true>(c, tile, sb, lane, wave, rs, sbase, nbase, stage, total, rows, nc, ntile, ntotal);
     } else if constexpr (FAMILY == 1) {
-        if (shape == 2) br_tile<5, 2, 2, 4, true, NW, false>(c, tile, sb, lane, wave, rs, sbase, nbase, stage);
-        else br_tile<5, 2, 3, 4, true, NW, false>(c, tile, sb, lane, wave, rs, sbase, nbase, stage);
+        if (shape == 2) br_tile<5, 2, 2, 4, true, NW, false>(c, tile, sb, lane, wave, rs, sbase, nbase, stage, total, rows, nc, ntile, ntotal);
+        else br_tile<5, 2, 3, 4, true, NW, false>(c, tile, sb, lane, wave, rs, sbase, nbase, stage, total, rows, nc, ntile, ntotal);
     } else if constexpr (FAMILY == 2) {
-        if (shape == 4) br_tile<9, 4, 4, 8, true, NW, false>(c, tile, sb, lane, wave, rs, sbase, nbase, stage);
-        else if (shape == 5) br_tile<9, 4, 6, 8, true, NW, false>(c, tile, sb, lane, wave, rs, sbase, nbase, stage);
-        else br_tile<9, 4, 8, 8, true, NW, false>(c, tile, sb, lane, wave, rs, sbase, nbase, stage);
+        if (shape == 4) br_tile<9, 4, 4, 8, true, NW, false>(c, tile, sb, lane, wave, rs, sbase, nbase, stage, total, rows, nc, ntile, ntotal);
+        else if (shape == 5) br_tile<9, 4, 6, 8, true, NW, false>(c, tile, sb, lane, wave, rs, sbase, nbase, stage, total, rows, nc, ntile, ntotal);
+        else br_tile<9, 4, 8, 8, true, NW, false>(c, tile, sb, lane, wave, rs, sbase, nbase, stage, total, rows, nc, ntile, ntotal);
     } else {
-        if (shape == 8) br_tile<17, 8, 8, 16, true, NW, false>(c, tile, sb, lane, wave, rs, sbase, nbase, stage);
-        else br_tile<17, 8, 16, 32, true, NW, false>(c, tile, sb, lane, wave, rs, sbase, nbase, stage);
+        if (shape == 8) br_tile<17, 8, 8, 16, true, NW, false>(c, tile, sb, lane, wave, rs, sbase, nbase, stage, total, rows, nc, ntile, ntotal);
+        else br_tile<17, 8, 16, 32, true, NW, false>(c, tile, sb, lane, wave, rs, sbase, nbase, stage, total, rows, nc, ntile, ntotal);
     }
 }
 
@@ -423,9 +439,10 @@ __global__ __launch_bounds__(BR_NW * 64, FAMILY == 3 ? 1 : 2) void mlp_bf16_reg_
         }
     }
     // items = NW consecutive tiles of one chain, chain 0 first (heaviest); static round-robin deal
-    const int t0 = ((mp.c[0].rowtab[0] + 31) / 32 + NW - 1) / NW;
-    const int t1 = mp.n > 1 ? t0 + ((mp.c[1].rowtab[0] + 31) / 32 + NW - 1) / NW : t0;
-    const int nitems = mp.n > 2 ? t1 + ((mp.c[2].rowtab[0] + 31) / 32 + NW - 1) / NW : t1;
+    const int tot0 = mp.c[0].rowtab[0], tot1 = mp.n > 1 ? mp.c[1].rowtab[0] : 1, tot2 = mp.n > 2 ? mp.c[2].rowtab[0] : 1;
+    const int t0 = ((tot0 + 31) / 32 + NW - 1) / NW;
+    const int t1 = mp.n > 1 ? t0 + ((tot1 + 31) / 32 + NW - 1) / NW : t0;
+    const int nitems = mp.n > 2 ? t1 + ((tot2 + 31) / 32 + NW - 1) / NW : t1;
     const unsigned ulane = (unsigned)lane;
     auto stream_of = [&](int it) -> const float4 * {
         const int ci = it < t0 ? 0 : (it < t1 ? 1 : 2);
@@ -457,14 +474,23 @@ __global__ __launch_bounds__(BR_NW * 64, FAMILY == 3 ? 1 : 2) void mlp_bf16_reg_
     if (blockIdx.x < 256 && lane == 0)
         for (int i = 0; i < 16; ++i) g_brst[(blockIdx.x * 4 + wave) * 16 + i] = 0;
 #endif
+    auto chain_of = [&](int it) { return __builtin_amdgcn_readfirstlane(it < t0 ? 0 : (it < t1 ? 1 : 2)); };
+    auto tile_of = [&](int it, int ci) { return (it - (ci == 0 ? 0 : (ci == 1 ? t0 : t1))) * NW + wave; };
+    auto total_of = [&](int ci) { return ci == 0 ? tot0 : (ci == 1 ? tot1 : tot2); };
+    NextRows rows{0, 0, 0};
+    if (item < nitems) {
+        const int ci = chain_of(item);
+        rows = fetch_rows(mp.c[ci], tile_of(item, ci), total_of(ci), lane);
+    }
     for (; item < nitems; item += (int)gridDim.x) { // (workgroup-uniform)
-        const int ci = __builtin_amdgcn_readfirstlane(item < t0 ? 0 : (item < t1 ? 1 : 2));
-        const int tg = item - (ci == 0 ? 0 : (ci == 1 ? t0 : t1));
+        const int ci = chain_of(item);
         const int nxt = item + (int)gridDim.x;
-        // the tile's last two stages fetch the first two of the next item (any valid stream when there is none)
+        const int nit = nxt < nitems ? nxt : item;   // (no next item: any valid one, its rows are fetched and dropped)
+        const int nci = chain_of(nit);
+        // the tile's last two stages fetch the first two of the next item's stream, and the tile the row map of the next tile
         if constexpr (STATICW) rs.ring = ring + (ci == 0 ? 0 : (ci == 1 ? w1 : w2));
-        run_br<FAMILY, NW>(mp.c[ci], mp.shape[ci], tg * NW + wave, sbias + (ci == 0 ? 0 : (ci == 1 ? b1 : b2)), lane, wave, rs,
-                           stream_of(item), stream_of(nxt < nitems ? nxt : item), stage);
+        run_br<FAMILY, NW>(mp.c[ci], mp.shape[ci], tile_of(item, ci), sbias + (ci == 0 ? 0 : (ci == 1 ? b1 : b2)), lane, wave, rs,
+                           stream_of(item), stream_of(nit), stage, total_of(ci), rows, mp.c[nci], tile_of(nit, nci), total_of(nci));
     }
 #ifdef SAD_BR_STAMPS
     if (blockIdx.x < 256 && lane == 0) {

@@ -15,12 +15,12 @@ Per step the MLP kernels are grouped into dispatches in launch order: a row-pack
 it (the cluster layer); a scan followed by other kernels first (the SA stages: it runs behind the ball query, on
 the sampling stream in the timed configuration) is not part of any MLP dispatch; consecutive mlp_layer_kernel
 launches (one per layer) belong together, every other mlp_* kernel is its own dispatch.  Prints per-dispatch duration and
-TFLOP/s and the total fraction of the dense f32 MFMA peak (157.3 TFLOP/s)."""
+TFLOP/s and the total fraction of the dense MFMA peak of the bench line's dtype (f32 157.3, bf16 2 500 TFLOP/s)."""
 import csv
 import json
 import sys
 
-PEAK = 157.3
+PEAK_F32, PEAK_BF16 = 157.3, 2500.0      # dense MFMA peaks, TFLOP/s (/opt/skills/guides/MI355X_MICROARCH.md)
 
 
 def short(name):
@@ -34,6 +34,8 @@ def main():
     allk = [(short(r["Kernel_Name"]), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3) for r in rows]
     ks = []
     for i, (n, d) in enumerate(allk):
+        if n.startswith("bf16_rows_kernel"):       # (the plain-row layer of the bf16 mode: an MLP kernel like the mlp_* ones)
+            n = "mlp_" + n
         if n == "mlp_pack_kernel" or not n.startswith(("mlp_", "rowscan_")):
             continue
         if n == "rowscan_sums_kernel":      # part of an MLP dispatch only if sums, write, MLP kernel follow each other directly
@@ -66,6 +68,7 @@ def main():
     for line in open(bench):
         if line.startswith("{"):
             j = json.loads(line)
+    PEAK = PEAK_BF16 if j.get("dtype") == "bf16" else PEAK_F32
     order = j["mlp_launch_order"]
     flops = {n: v["executed_gflop"] * 1e9 for n, v in j["mlp_launches"].items()}
     per = len(order)
