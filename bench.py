@@ -43,7 +43,7 @@ PEAK_MFMA_F32_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: dense f
 PEAK_MFMA_BF16_TFLOPS = 2500.0 # same guide: dense bf16 MFMA (not the 2:1-sparsity headline)
 PEAK_HBM_GBPS = 8000.0         # HBM3E spec
 PARITY_TOL = 1e-4              # BASELINE.json north_star: fp32 boxes within 1e-4
-TRAFFIC_FILE = "r02_pmc_traffic.json"   # profiles/: HBM bytes of the MLP dispatches (rocprofv3 --pmc passes)
+TRAFFIC_FILE = "r03_pmc_traffic.json"   # profiles/: HBM bytes of the MLP dispatches (rocprofv3 --pmc passes)
 
 
 def usable_cores() -> int:

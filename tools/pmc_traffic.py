@@ -20,14 +20,14 @@ fetch, s1 = total("fetch", "FETCH_SIZE")
 write, s2 = total("write", "WRITE_SIZE")
 # FETCH_SIZE / WRITE_SIZE are reported in kilobytes; on gfx950 FETCH_SIZE counts 32-byte requests as 64-byte units
 # halved, i.e. the raw value is doubled (MI355X_MICROARCH.md, HBM section) — same correction as in round 1
-res = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes, tools/pmc.sh: bench.py --geometry-file "
-                 "profiles/r02_geometry.json --main-streams 1 --steps 3 --warmup 1), summed over the MLP dispatches (mlp_reg / mlp_coop / mlp_layer / "
+res = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes, tools/profile_r03.sh pmc / tools/pmc.sh: bench.py --geometry-file "
+                 "<geometry of the run> --main-streams 1 --steps 3 --warmup 1), summed over the MLP dispatches (mlp_reg / mlp_coop / mlp_layer / "
                  "mlp_chain / mlp_multi kernels + their row-packing scans) and divided by the forward passes of the run; FETCH_SIZE doubled "
                  "per the gfx950 correction of MI355X_MICROARCH.md (HBM section); gather-width reads uncalibrated",
        "forward_passes": s1,
        "fetch_size_raw_kb_per_step": fetch / max(1, s1),
        "fetch_bytes_per_step": int(2 * fetch * 1024 / max(1, s1)),
        "write_bytes_per_step": int(write * 1024 / max(1, s2)),
-       "build": "r02"}
+       "build": sys.argv[3] if len(sys.argv) > 3 else "r02"}
 json.dump(res, open(out, "w"), indent=1)
 print(json.dumps(res, indent=1))
