@@ -16,7 +16,7 @@
 //     the rows of a group is a running max across registers with wave-half-uniform group boundaries, and a group's result
 //     leaves as one 128-byte store per lane half (an atomic max only for a group that continues in another half-tile);
 //   * the weight fragments of a tile form one fixed stream; the waves of a workgroup walk their tiles in lockstep and
-//     share the stream through a three-slot LDS ring (one global load per wave and NW fragments, prefetched two stages
+//     share the stream through a three-slot LDS ring of 8-fragment stages (one global load per wave and NW fragments, prefetched two stages
 //     ahead, never drained: the last stages of an item fetch the first of the next);
 //   * the layer-0 operand is gathered straight from the bf16 feature rows in fragment form (16-byte loads), the relative
 //     coordinates are formed in binary32 and rounded once (SPEC.md §14).
@@ -31,10 +31,16 @@ using sad::BfRegChain;
 using sad::BfRegMulti;
 
 constexpr int WHOLE_BIT = 1 << 30;
-constexpr int RS = 16;               // fragments (1 KB each) per ring stage
+#ifndef SAD_BR_RS
+#define SAD_BR_RS 8      // (16: sa1 82 vs 72 us, sa2 47 vs 41, cluster 112 vs 108, sa3 112 vs 115 — the smaller ring / image lets more workgroups share a CU)
+#endif
+#ifndef SAD_BR_PFD
+#define SAD_BR_PFD 4
+#endif
+constexpr int RS = SAD_BR_RS;        // fragments (1 KB each) per ring stage
 constexpr int RNS = 3;               // ring slots: being read / complete / being written
 constexpr int RING_F4 = RNS * RS * 64;
-constexpr int PFD = 4;               // ring reads run this many fragments ahead of the MFMA that consumes them
+constexpr int PFD = SAD_BR_PFD;      // ring reads run this many fragments ahead of the MFMA that consumes them
 // Staged pooled output.  A wave owns 4 KB of LDS: STAGE_F floats = slots x CB channels, slot = ordinal of a group inside
 // the tile, CB = 128 / 64 / 32 channels per block for tiles with <= 8 / 16 / 32 groups.  EVERY row of an output tile
 // max-combines into its group's slot with one LDS atomic per register (ds_max_u32 on the bit patterns: values are >= +0
@@ -164,31 +170,6 @@ __device__ __forceinline__ void br_tile(const BfRegChain &c, const int tile, con
         }
     }
     rows = fetch_rows(nc, ntile, ntotal, lane);     // (consumed by this wave's next tile)
-    // ---- pooling bookkeeping (lane t < 32 looks at tile row t in natural order; both halves compute the same) ----
-    PoolInfo pi;
-    {
-        const bool live = tile * 32 + r < total;
-        const int gv = gv_nat;
-        const int g = gv & (WHOLE_BIT - 1);
-        const int gprev = __shfl_up(g, 1, 64);
-        const bool same_prev = r > 0 && gprev == g;                 // (rows past the end repeat the last row: same group)
-        const unsigned startm = ~(unsigned)__ballot(same_prev && lane < 32);      // bit t: row t starts a group (bit 0 set)
-        const unsigned livem = (unsigned)__ballot(live && lane < 32);
-        pi.kind = (~startm & 0xFFFEFFFEu) == 0xFFFEFFFEu ? 1 : 2;   // (rows past the end count as continuing the last group)
-        pi.ngroups = __builtin_amdgcn_readfirstlane(__builtin_popcount(startm & livem));
-        pi.g_first = __builtin_amdgcn_readlane(g, 0);
-        const int nlive = __builtin_popcount(livem);
-        pi.whole_first = (__builtin_amdgcn_readlane(gv, 0) & WHOLE_BIT) != 0;
-        pi.whole_last = (__builtin_amdgcn_readlane(gv, nlive > 0 ? nlive - 1 : 0) & WHOLE_BIT) != 0;
-        constexpr int CBS_MAX = CB == 128 ? 7 : (CB == 64 ? 6 : 5);
-        const int want = pi.ngroups <= 8 ? 7 : (pi.ngroups <= 16 ? 6 : 5);
-        pi.cbs = want < CBS_MAX ? want : CBS_MAX;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int slot = __builtin_popcount(startm & (0xFFFFFFFFu >> (31 - (16 * h + i)))) - 1;
-            pi.soff[i] = (slot << (pi.cbs + 2)) + 4 * r;
-        }
-    }
     const float *sb0 = sbias, *sb1 = sbias + NO0 * 32, *sb2 = sb1 + NO1 * 32;
     // (kernel-argument fields used inside the loops: held in vector registers — left to the compiler they are re-read from
     // the argument segment at every use, and every scalar load drains the queue of LDS reads with an lgkmcnt(0))
@@ -201,7 +182,7 @@ __device__ __forceinline__ void br_tile(const BfRegChain &c, const int tile, con
     float4 *const ring = rs.ring;
     int slot = rs.slot;
     int srel = 0;
-    static_assert(FPW == 2 || FPW == 4, "two or four fragments per wave and stage");
+    static_assert(FPW == 2 || FPW == 4, "two or four fragments per wave and stage");   // (FPW == 2: T2, T3 stay unused)
     float4 T0, T1, T2, T3;                          // this wave's fragments of stage srel + 2, in flight (named: an array
     T2 = T3 = make_float4(0.f, 0.f, 0.f, 0.f);      // captured by the lambdas below may end up in scratch)
     const unsigned ulane = (unsigned)lane;
@@ -286,6 +267,32 @@ __device__ __forceinline__ void br_tile(const BfRegChain &c, const int tile, con
         }
         x2[2 * o] = pack8(acc, 0);
         x2[2 * o + 1] = pack8(acc, 1);
+    }
+    // ---- pooling bookkeeping, computed only now: its 16 slot offsets would otherwise be live through layers 0 and 1
+    // (lane t < 32 looks at tile row t in natural order; both halves compute the same) ----
+    PoolInfo pi;
+    {
+        const bool live = tile * 32 + r < total;
+        const int gv = gv_nat;
+        const int g = gv & (WHOLE_BIT - 1);
+        const int gprev = __shfl_up(g, 1, 64);
+        const bool same_prev = r > 0 && gprev == g;                 // (rows past the end repeat the last row: same group)
+        const unsigned startm = ~(unsigned)__ballot(same_prev && lane < 32);      // bit t: row t starts a group (bit 0 set)
+        const unsigned livem = (unsigned)__ballot(live && lane < 32);
+        pi.kind = (~startm & 0xFFFEFFFEu) == 0xFFFEFFFEu ? 1 : 2;   // (rows past the end count as continuing the last group)
+        pi.ngroups = __builtin_amdgcn_readfirstlane(__builtin_popcount(startm & livem));
+        pi.g_first = __builtin_amdgcn_readlane(g, 0);
+        const int nlive = __builtin_popcount(livem);
+        pi.whole_first = (__builtin_amdgcn_readlane(gv, 0) & WHOLE_BIT) != 0;
+        pi.whole_last = (__builtin_amdgcn_readlane(gv, nlive > 0 ? nlive - 1 : 0) & WHOLE_BIT) != 0;
+        constexpr int CBS_MAX = CB == 128 ? 7 : (CB == 64 ? 6 : 5);
+        const int want = pi.ngroups <= 8 ? 7 : (pi.ngroups <= 16 ? 6 : 5);
+        pi.cbs = want < CBS_MAX ? want : CBS_MAX;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int slot = __builtin_popcount(startm & (0xFFFFFFFFu >> (31 - (16 * h + i)))) - 1;
+            pi.soff[i] = (slot << (pi.cbs + 2)) + 4 * r;
+        }
     }
     SAD_BSTAMP(ts2);
     // ---- layer 2: D[row, cout] = X . W^T, pooled over the rows of each group -------------------------------------
@@ -416,7 +423,7 @@ __device__ __forceinline__ void run_br(const BfRegChain &c, int shape, int tile,
 constexpr int BR_NW = 4;
 
 template <int FAMILY>
-__global__ __launch_bounds__(BR_NW * 64, FAMILY == 3 ? 1 : 2) void mlp_bf16_reg_kernel(const BfRegMulti mp) {
+__global__ __launch_bounds__(BR_NW * 64, FAMILY == 0 ? 4 : (FAMILY == 1 ? 3 : 2)) void mlp_bf16_reg_kernel(const BfRegMulti mp) {
     constexpr int NW = BR_NW;
     constexpr int FPW = RS / NW;
     constexpr bool STATICW = FAMILY == 0;
@@ -584,7 +591,7 @@ static int launch_bfreg_family(const BfRegMulti &mp, size_t lds, hipStream_t st)
             (void)hipGetLastError();
             nb = 1;
         }
-        pc = nb > 3 ? 3 : nb;
+        pc = nb > 4 ? 4 : nb;
         per_cu.store(pc, std::memory_order_relaxed);
     }
     if (get_option(OPT_MLP_DYN_SLOTS) > 0 && get_option(OPT_MLP_DYN_SLOTS) < pc) pc = get_option(OPT_MLP_DYN_SLOTS);   // A/B knob
