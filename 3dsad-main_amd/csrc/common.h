@@ -72,6 +72,20 @@ struct LayerMulti {
     int n;
 };
 int launch_layers(const LayerMulti &lm, long long max_items, hipStream_t st);
+// Row-streaming plain f32 layer (csrc/mlp_rows.hip, geometry 5)
+struct RowsJob {
+    const float *x;                // rows [rows, ldx]
+    int ldx;
+    long long rows;
+    const float *packed;
+    long long off;                 // float offset of the layer inside `packed` (bias block, then A fragments)
+    int np, kg, ct, cout;          // padded output channels, k-groups of 8 (C / 8), channel tiles of 32, true output channels
+    int relu;
+    float *out;
+    int ld_out, col_off, vec_out;
+    int nrb, ncb;                  // (filled by launch_rows) row blocks of 128, channel blocks
+};
+int launch_rows(const RowsJob &job, hipStream_t st);
 int reg_shape_id(int L, const int *kp, const int *np);   // -1: no compiled shape
 int reg_family(int shape);
 int launch_reg(const RegMulti &mp, hipStream_t st);

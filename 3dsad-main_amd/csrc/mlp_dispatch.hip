@@ -18,6 +18,8 @@ struct Prepared {
     sad::RegChain rc;
     sad::ScanJob scan;  // row-packing scan this chain needs before its kernel
     bool prescanned;    // ... unless the caller already ran sad_mlp_rowscan on the workspace
+    bool rows;          // geometry 5: row-streaming plain layer (csrc/mlp_rows.hip); `rj` is filled
+    sad::RowsJob rj;
     bool layered;       // geometry 3: layer-streamed chain (csrc/mlp_layer.hip); lj[0..nl) are its launches
     sad::LayerJob lj[MAXL];
     int nl;
@@ -44,6 +46,7 @@ static int prepare_chain(const sad_mlp_args *a, sad_stream_t stream, Prepared &q
     q.reg = false;
     q.coop = false;
     q.layered = false;
+    q.rows = false;
     q.prescanned = a && a->prescanned != 0;
     SAD_REQUIRE(a, "sad_mlp_chain_f32: NULL args");
     SAD_REQUIRE(a->struct_size == sizeof(sad_mlp_args), "sad_mlp_chain_f32: struct_size=%zu, this library's sad_mlp_args has %zu bytes "
@@ -137,6 +140,22 @@ static int prepare_chain(const sad_mlp_args *a, sad_stream_t stream, Prepared &q
         q.reg_shape = shape;
         q.reg_tiles = (p.total_groups * a->S + 31) / 32;
         q.W = -1;
+        return SAD_OK;
+    }
+    // ---- geometry 5: row-streaming plain layer (one layer, every input row read once per 128 output channels) ----
+    if (geom_wg == 5) {
+        const bool ok = !grouped && a->L == 1 && p.cpr > 0 && a->C % 8 == 0 && g.kp[0] == a->C;
+        if (!ok)
+            return sad::fail(SAD_EUNSUPPORTED, "sad_mlp_chain_f32: geometry 5 (row-streaming layer) takes one plain layer with C %% 8 == 0 "
+                                               "and 16-byte aligned rows");
+        sad::RowsJob &j = q.rj;
+        j = sad::RowsJob{};
+        j.x = a->feat; j.ldx = a->ld_feat; j.rows = p.total_rows;
+        j.packed = a->packed; j.off = g.off[0]; j.np = g.np[0]; j.kg = g.kp[0] / 8; j.ct = g.np[0] / 32; j.cout = cout;
+        j.relu = a->relu_mask & 1;
+        j.out = a->out; j.ld_out = a->ld_out; j.col_off = a->col_off; j.vec_out = p.vec_out;
+        q.rows = true;
+        q.W = -3;
         return SAD_OK;
     }
     // ---- geometry 3: layer-streamed chain (one launch per layer, activations between layers in scratch) ----
@@ -412,6 +431,7 @@ int launch_layered_chains(const Prepared *const *qs, int n, hipStream_t st) {
 }
 
 int launch_prepared(const Prepared &q, hipStream_t st) {
+    if (q.rows) return sad::launch_rows(q.rj, st);
     if (q.layered) {
         const Prepared *one = &q;
         return launch_layered_chains(&one, 1, st);
@@ -468,7 +488,7 @@ SAD_API int sad_mlp_chain_multi_f32(const sad_mlp_args *const *args, int n, sad_
     }
     // one dispatch needs a common wave count and nothing already launched; otherwise one by one
     bool merge = n > 1;
-    for (int i = 0; i < n; ++i) merge = merge && !q[i].launched && !q[i].reg && !q[i].layered && q[i].W == q[0].W && q[i].W != 16;
+    for (int i = 0; i < n; ++i) merge = merge && !q[i].launched && !q[i].reg && !q[i].layered && !q[i].rows && q[i].W == q[0].W && q[i].W != 16;
     if (!merge) {
         for (int i = 0; i < n; ++i)
             if (!q[i].launched)

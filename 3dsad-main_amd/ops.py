@@ -430,7 +430,9 @@ class PackedMLP:
         best, best_ms = 0, None
         # 1 = VALU row-per-lane kernel (narrow chains), 2 = register-resident chain kernel (csrc/mlp_reg.hip),
         # 3 = layer-streamed chain (csrc/mlp_layer.hip), 4 = cooperative register-resident chain (csrc/mlp_coop.hip)
-        for code in self._CANDIDATES + ([1, 2, 3, 4] if a.idx else ([3] if self._layered_ok else [])):
+        # ... 5 = row-streaming plain layer (csrc/mlp_rows.hip)
+        plain_extra = ([3] if self._layered_ok else []) + ([5] if self.L == 1 and self.dims[0] % 8 == 0 else [])
+        for code in self._CANDIDATES + ([1, 2, 3, 4] if a.idx else plain_extra):
             a.geometry = code
             ms = self._time(a, stream)
             if ms is not None and (best_ms is None or ms < best_ms * 0.98):   # prefer earlier entries on ties

@@ -215,7 +215,9 @@ typedef struct sad_mlp_args {
      *   4 = cooperative register-resident chain: as 2, but the four waves of a workgroup walk four tiles
      *       through the chain in lockstep and share the weight stream through an LDS ring (one global load per
      *       16 MFMAs instead of one per 4; compiled for the SA2 / SA3 shapes 67 -> 64 -> {64,96} -> 128 and
-     *       131 -> 128 -> {128,192,256} -> 256). */
+     *       131 -> 128 -> {128,192,256} -> 256);
+     *   5 = row-streaming layer: ONE plain layer (idx == NULL, L == 1, C % 8 == 0, 16-byte aligned rows): a wave owns 32 rows
+     *       and all output channels of its item, its input rows never pass through LDS (the stage aggregations). */
     int geometry;
     /* geometry 3 only: sad_mlp_scratch_bytes(B, M, S, L, dims) bytes of 16-byte aligned device scratch */
     void *scratch;

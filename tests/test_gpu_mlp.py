@@ -833,6 +833,53 @@ def test_layer_streamed_plain_rows_parity(orc, sad, dev, rows, dims, mask, ld_ou
     assert (rest == -7.0).all(), "columns outside the slice were written"
 
 
+ROWS_LAYER_CASES = [
+    # (rows, C, C_out, relu, ld_out, col_off) — geometry 5: the row-streaming plain layer (csrc/mlp_rows.hip)
+    (4096, 128, 64, True, 64, 0),            # sa1.agg
+    (777, 384, 128, True, 128, 0),           # sa2.agg, ragged last block
+    (1000, 768, 256, True, 384, 128),        # sa3.agg into a slice of a wider buffer
+    (130, 1536, 512, True, 512, 0),          # cluster.agg: four channel blocks per row block
+    (333, 256, 10, False, 10, 0),            # a linear head layer: C_out not a multiple of 4, unaligned rows of the output
+    (1, 8, 33, True, 40, 3),                 # a single row, one k-group, odd column offset
+    (257, 40, 96, True, 96, 0),              # five k-groups (a partial last chunk), three channel tiles
+]
+
+
+@pytest.mark.parametrize("rows,C,cout,relu,ld_out,col_off", ROWS_LAYER_CASES)
+def test_row_streaming_layer_parity(orc, sad, dev, rows, C, cout, relu, ld_out, col_off):
+    """geometry 5: one plain layer, a wave owns 32 rows and every output channel of its item; bit-identical to the oracle's
+    fmaf chains (SPEC.md §6) and to the tiled kernel; columns outside the output slice are left alone."""
+    import torch
+    from sad_amd import ops, synth
+    rng = np.random.default_rng(rows + C + cout)
+    layers = synth.make_mlp_weights([C, cout], rng)
+    x = rng.normal(size=(rows, C)).astype(np.float32)
+    mask = 1 if relu else 0
+    want = orc.mlp_rows(x, layers, relu_mask=mask)
+    net = ops.PackedMLP(layers, False, dev, relu_mask=mask)
+    tiled = net.rows(_t(x, dev)).cpu().numpy()
+    assert np.array_equal(tiled, want)
+    net.default_geometry = 5
+    out = torch.full((rows, ld_out), -7.0, dtype=torch.float32, device=dev)
+    net.rows(_t(x, dev), out=out, col_off=col_off)
+    got = out.cpu().numpy()
+    assert np.array_equal(got[:, col_off:col_off + cout], want), f"max diff {np.abs(got[:, col_off:col_off + cout] - want).max():.3e}"
+    rest = np.delete(got, np.s_[col_off:col_off + cout], axis=1)
+    assert (rest == -7.0).all(), "columns outside the slice were written"
+
+
+def test_row_streaming_layer_refusal(sad, dev):
+    """Chains geometry 5 cannot take (two layers, C not a multiple of 8) are refused with SAD_EUNSUPPORTED."""
+    import torch
+    from sad_amd import ops, synth
+    rng = np.random.default_rng(6)
+    for dims in ([128, 64, 32], [132, 64]):
+        net = ops.PackedMLP(synth.make_mlp_weights(dims, rng), False, dev)
+        net.default_geometry = 5
+        with pytest.raises(RuntimeError, match=r"\(-2\)"):
+            net.rows(torch.zeros((64, dims[0]), device=dev))
+
+
 def test_layer_streamed_plain_rows_refusal(sad, dev):
     """Shapes the plain layer-streamed path cannot take are refused with SAD_EUNSUPPORTED, never computed wrong."""
     import torch
