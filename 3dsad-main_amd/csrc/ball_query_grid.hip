@@ -204,10 +204,41 @@ struct GQParams {
     int nsample[SAD_MAX_RADII];
     int32_t *idx[SAD_MAX_RADII];
     int32_t *cnt[SAD_MAX_RADII];   // optional: accepted points per centroid, capped at nsample
+    int no_sort;                   // A/B knob (bq_variant = 1): always the bitmap path
 };
 
 constexpr int GQ_WAVES = 4;
 constexpr int GQ_CPW = 4;     // centroids per wave, processed one after the other
+
+// ---- sort path: a centroid with at most 64 candidates (the common case on lidar-density scenes) needs no bitmap --------
+// One candidate per lane: key = (index << 4) | (bit r set iff d2 < radius_r^2), empty lanes = all ones.  A 64-lane bitonic
+// sort by key (indices are unique) puts the candidates in ascending index order; for every radius the accepted ones are
+// then compacted with a ballot + prefix popcount: slot = number of accepted lanes below.  No LDS memory, no atomics, no
+// data-dependent loops: ~21 exchange stages of 5 instructions against the bitmap path's ~100 instructions per radius.
+__device__ __forceinline__ unsigned xor_partner(unsigned v, int d) {          // value of lane ^ d
+    if (d == 32) return (unsigned)__shfl_xor((int)v, 32, 64);
+    // ds_swizzle bit-mask mode inside groups of 32 lanes: and_mask 0x1F, or_mask 0, xor_mask d
+    switch (d) {
+        case 1: return (unsigned)__builtin_amdgcn_ds_swizzle((int)v, (1 << 10) | 0x1F);
+        case 2: return (unsigned)__builtin_amdgcn_ds_swizzle((int)v, (2 << 10) | 0x1F);
+        case 4: return (unsigned)__builtin_amdgcn_ds_swizzle((int)v, (4 << 10) | 0x1F);
+        case 8: return (unsigned)__builtin_amdgcn_ds_swizzle((int)v, (8 << 10) | 0x1F);
+        default: return (unsigned)__builtin_amdgcn_ds_swizzle((int)v, (16 << 10) | 0x1F);
+    }
+}
+__device__ __forceinline__ unsigned bitonic_sort64(unsigned v, int lane) {
+#pragma unroll
+    for (int k = 2; k <= 64; k <<= 1) {
+#pragma unroll
+        for (int d = k >> 1; d >= 1; d >>= 1) {
+            const unsigned p = xor_partner(v, d);
+            const bool keep_min = ((lane & d) == 0) == ((lane & k) == 0 || k == 64);
+            const unsigned lo = v < p ? v : p, hi = v < p ? p : v;
+            v = keep_min ? lo : hi;
+        }
+    }
+    return v;
+}
 
 template <int NR>
 __global__ __launch_bounds__(GQ_WAVES * 64) void grid_query_kernel(const float *__restrict__ new_xyz,
@@ -238,7 +269,7 @@ __global__ __launch_bounds__(GQ_WAVES * 64) void grid_query_kernel(const float *
     const float x0 = hdr->x0, y0 = hdr->y0, z0 = hdr->z0, inv = hdr->inv;
     const int gx = hdr->gx, gy = hdr->gy, gz = hdr->gz;
 
-    for (int w = lane; w < NR * (NWP + 64); w += 64) bm[w] = 0u;
+    bool bm_clean = false;                      // the bitmaps are zeroed on first use: most waves never need them (sort path)
 
     // The wave's GQ_CPW centroids are independent: their dependent memory round trips (centroid -> cell starts ->
     // first records) are issued for all of them before any is processed — one latency chain per wave instead
@@ -265,6 +296,7 @@ __global__ __launch_bounds__(GQ_WAVES * 64) void grid_query_kernel(const float *
         crs[cc] = rs; crl[cc] = rl;
     }
     float4 pr0[GQ_CPW];                         // first 64 candidate records of each centroid
+    int ctot[GQ_CPW];                           // candidates of each centroid (wave-uniform)
 #pragma unroll
     for (int cc = 0; cc < GQ_CPW; ++cc) {
         int src = __builtin_amdgcn_readlane(crs[cc], 0) + lane, off = 0;
@@ -274,6 +306,7 @@ __global__ __launch_bounds__(GQ_WAVES * 64) void grid_query_kernel(const float *
             src = lane >= off ? st + (lane - off) : src;
             off += __builtin_amdgcn_readlane(crl[cc], r);
         }
+        ctot[cc] = off;
         pr0[cc] = rec[lane < off ? src : 0];
     }
 #pragma unroll
@@ -284,6 +317,50 @@ __global__ __launch_bounds__(GQ_WAVES * 64) void grid_query_kernel(const float *
         float r2[NR];
 #pragma unroll
         for (int r = 0; r < NR; ++r) r2[r] = prm.radii[r] * prm.radii[r];
+        const int T = ctot[cc];
+        if (T <= 64 && !prm.no_sort) {
+            // ---- sort path ----
+            const float4 pr = pr0[cc];
+            const bool valid = lane < T;
+            const float d = sad::d2f(pr.x, pr.y, pr.z, cx, cy, cz);
+            unsigned key = 0xFFFFFFFFu;
+            if (valid) {
+                unsigned acc = 0u;
+#pragma unroll
+                for (int r = 0; r < NR; ++r) acc |= d < r2[r] ? 1u << r : 0u;
+                key = ((unsigned)__float_as_int(pr.w) << 4) | acc;
+            }
+#ifdef SAD_BQ_PROBE          // measurement builds only (wrong results): 1 = no sort, 2 = nothing after the candidate loads
+#if SAD_BQ_PROBE == 2
+            if (key == 0x12345u) prm.idx[0][0] = 1;
+            continue;
+#endif
+#else
+            key = bitonic_sort64(key, lane);
+#endif
+            const int jidx = (int)(key >> 4);
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                const int S = prm.nsample[r];
+                int32_t *out = prm.idx[r] + ((size_t)b * M + m) * S;
+                const bool ok = key != 0xFFFFFFFFu && ((key >> r) & 1u);
+                const unsigned long long bal = __ballot(ok);
+                const int slot = __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
+                const int total = __builtin_popcountll(bal);
+                if (ok && slot < S) out[slot] = jidx;
+                // SPEC.md §3 padding: the remaining slots repeat the first (lowest) accepted index; none accepted: zeros
+                int first = 0;
+                if (bal) first = __builtin_amdgcn_readlane(jidx, __builtin_ctzll(bal));
+                for (int sidx = (total < S ? total : S) + lane; sidx < S; sidx += 64) out[sidx] = first;
+                if (prm.cnt[r] && lane == 0) prm.cnt[r][(size_t)b * M + m] = total < S ? total : S;
+            }
+            continue;
+        }
+        // ---- bitmap path (more than 64 candidates) ----
+        if (!bm_clean) {
+            for (int w = lane; w < NR * (NWP + 64); w += 64) bm[w] = 0u;
+            bm_clean = true;
+        }
         int rstart[9], roff[10];
         roff[0] = 0;
 #pragma unroll
@@ -291,7 +368,6 @@ __global__ __launch_bounds__(GQ_WAVES * 64) void grid_query_kernel(const float *
             rstart[r] = __builtin_amdgcn_readlane(crs[cc], r);
             roff[r + 1] = roff[r] + __builtin_amdgcn_readlane(crl[cc], r);
         }
-        const int T = roff[9];
         for (int i0 = 0; i0 < T; i0 += 64) {
             const int i = i0 + lane;
             const bool valid = i < T;
@@ -388,6 +464,7 @@ SAD_API int sad_ball_query_grid_f32(const float *xyz, const float *new_xyz, int 
         prm.cnt[r] = cnt ? cnt[r] : nullptr;
         rmax = radii[r] > rmax ? radii[r] : rmax;
     }
+    prm.no_sort = sad::get_option(sad::OPT_BQ_VARIANT) == 1;
     hipStream_t st = (hipStream_t)stream;
     static std::atomic<uint64_t> attr_done0{0}, attr_done4{0}, attr_done16{0};
     const size_t blds = sizeof(int) * (GRID_MAXC + 64);

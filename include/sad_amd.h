@@ -49,7 +49,8 @@ const char *sad_last_error(void);
  *   fps_variant  1 pair kernel, 2 key kernel, 3 wave buckets, 4 cell buckets, 5 cell buckets over sorted records
  *   fps_threads  cell-bucket geometry waves*100 + slots (e.g. 1616, 832); old kernels: 1024/512/256 threads
  *   fps_dpp      1 = DPP reductions in the pair kernel
- *   bq_variant   reserved (grid vs scan is the caller's choice: sad_ball_query_grid_f32 / sad_ball_query_multi_f32)
+ *   bq_variant   1 = grid query: always the LDS-bitmap path (no 64-lane sort for centroids with <= 64 candidates);
+ *                grid vs scan is the caller's choice: sad_ball_query_grid_f32 / sad_ball_query_multi_f32
  *   group_variant 1 = L2-gather group_points kernel only (no LDS staging)
  *   mlp_rw, mlp_budget_kb, mlp_force, mlp_dedup_f, mlp_nodedup, mlp_static, mlp_dyn_slots, mlp_noxcd: f32 chain geometry overrides
  *                (see sad_mlp_args.geometry; mlp_nodedup = 1 computes the padding rows too)
