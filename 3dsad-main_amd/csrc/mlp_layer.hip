@@ -75,8 +75,59 @@ __device__ __forceinline__ RowInfo row_info(const LayerJob &jb, int rt, int lane
     return r;
 }
 
+struct Chunk { float4 a0, a1, a2, a3, b0, b1, b2, b3; };   // (named members: an array captured by lambdas ended up in scratch)
+static_assert(KC == 4 || KC == 2, "Chunk holds up to four activation fragments");
+
+// What one wave contributes to chunk c of an item's fill: its quarter of the weight fragments (k-group f / 4 of the chunk,
+// output tile f % 4 for f = wave * KC + i) and the activations of its row tile (`fr`) for the chunk's KC k-groups
+template <bool GATHER>
+__device__ __forceinline__ Chunk load_chunk_of(const LayerJob &jb, const unsigned xoff, const int ob, const int c, const int wave, const int lane) {
+    const int h = lane >> 5;
+    const int KG = jb.kg;
+    const char *xb = reinterpret_cast<const char *>(jb.x);
+    const float4 *wf = reinterpret_cast<const float4 *>(jb.packed + jb.off + jb.np) + (size_t)(ob * 4) * KG * 64;   // wave-uniform
+    const unsigned ulane = (unsigned)lane;
+    float4 ga[4], gb[KC];
+#pragma unroll
+    for (int i = 0; i < KC; ++i) {
+        const int f = wave * KC + i;
+        const int gk = c * KC + (f >> 2);
+        ga[i] = (wf + ((size_t)(f & 3) * KG + (gk < KG ? gk : KG - 1)) * 64)[ulane];
+    }
+#pragma unroll
+    for (int u = 0; u < KC; ++u) {
+        int g = c * KC + u;
+        g = g < KG ? g : KG - 1;
+        if constexpr (GATHER) {                     // [dx dy dz 0 | f0 f1 ...]: half h holds chunk 2g - 1 + h of the feature row
+            const int ch = 2 * g - 1 + h;
+            const int cc = ch < 0 ? 0 : (ch < jb.cpr ? ch : jb.cpr - 1);
+            gb[u] = *reinterpret_cast<const float4 *>(xb + (size_t)(xoff + 16u * (unsigned)cc));
+        } else {
+            gb[u] = *reinterpret_cast<const float4 *>((xb + (size_t)g * 32) + (size_t)(xoff + 16u * (unsigned)h));
+        }
+    }
+    return Chunk{ga[0], ga[1], ga[KC > 2 ? 2 : 0], ga[KC > 2 ? 3 : 0], gb[0], gb[1], gb[KC > 2 ? 2 : 0], gb[KC > 2 ? 3 : 0]};
+}
+
+// Chunk 0 of a workgroup's NEXT item, fetched while the current item's last chunk is multiplied: without it every item
+// starts with the exposed latency of its row bookkeeping and first loads (two dependent round trips for a gather layer) —
+// 6 % of an item of the 512-deep last cluster layer, a third of an item of the gather layer
+struct Prefetched {        // (plain words only: with a RowInfo and its bools inside, the object was kept in scratch)
+    Chunk ck;
+    float4 rel;             // relative coordinates of this lane's row (gather layers)
+    unsigned xoff;          // byte offset of its input row
+    int valid;
+};
+struct NextItem {
+    int ji;                 // job of the workgroup's next item, -1: none
+    int rb, ob;
+};
+
 template <bool GATHER, bool LAST>
-__device__ __forceinline__ void gemm_item(const LayerJob &jb, const int rb, const int ob, float4 *lds) {
+__device__ __forceinline__ Prefetched gemm_item(const LayerMulti &lm, const LayerJob &jb, const int rb, const int ob, float4 *lds,
+                                                const Prefetched pin, const NextItem nx) {
+    Prefetched pre;                                 // (by value in, by value out: a reference parameter kept the object in scratch)
+    pre.valid = 0;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = lane >> 5;
     const int wy = wave >> 1, wx = wave & 1;
@@ -84,35 +135,17 @@ __device__ __forceinline__ void gemm_item(const LayerJob &jb, const int rb, cons
     const int NC = (KG + KC - 1) / KC;              // chunks (a partial last chunk is padded with zero activations)
     // this wave FILLS: weight fragments of k-group (chunk*KC + wave) for the 4 output tiles, and the activation
     // operands of row tile rb*4 + wave for the KC k-groups of the chunk
-    const RowInfo fr = row_info<GATHER>(jb, rb * 4 + wave, lane, false);
-    const char *xb = reinterpret_cast<const char *>(jb.x);
-    const float4 *wf = reinterpret_cast<const float4 *>(jb.packed + jb.off + jb.np) + (size_t)(ob * 4) * KG * 64;   // wave-uniform
-    const unsigned ulane = (unsigned)lane;
-    struct Chunk { float4 a0, a1, a2, a3, b0, b1, b2, b3; };   // (named members: an array captured by the lambdas below ended up in scratch)
-    static_assert(KC == 4 || KC == 2, "Chunk holds up to four activation fragments");
-    auto load_chunk = [&](int c) -> Chunk {
-        float4 ga[4], gb[KC];
-        // this wave's weight fragments of the chunk: KC * 4 fragments over 4 waves
-#pragma unroll
-        for (int i = 0; i < KC; ++i) {
-            const int f = wave * KC + i;            // fragment f = (k-group f / 4 of the chunk, output tile f % 4)
-            const int gk = c * KC + (f >> 2);
-            ga[i] = (wf + ((size_t)(f & 3) * KG + (gk < KG ? gk : KG - 1)) * 64)[ulane];
-        }
-#pragma unroll
-        for (int u = 0; u < KC; ++u) {
-            int g = c * KC + u;
-            g = g < KG ? g : KG - 1;
-            if constexpr (GATHER) {                 // [dx dy dz 0 | f0 f1 ...]: half h holds chunk 2g - 1 + h of the feature row
-                const int ch = 2 * g - 1 + h;
-                const int cc = ch < 0 ? 0 : (ch < jb.cpr ? ch : jb.cpr - 1);
-                gb[u] = *reinterpret_cast<const float4 *>(xb + (size_t)(fr.xoff + 16u * (unsigned)cc));
-            } else {
-                gb[u] = *reinterpret_cast<const float4 *>((xb + (size_t)g * 32) + (size_t)(fr.xoff + 16u * (unsigned)h));
-            }
-        }
-        return Chunk{ga[0], ga[1], ga[KC > 2 ? 2 : 0], ga[KC > 2 ? 3 : 0], gb[0], gb[1], gb[KC > 2 ? 2 : 0], gb[KC > 2 ? 3 : 0]};
-    };
+    unsigned fr_xoff;
+    float4 fr_rel;
+    if (pin.valid) {
+        fr_xoff = pin.xoff;
+        fr_rel = pin.rel;
+    } else {
+        const RowInfo fr = row_info<GATHER>(jb, rb * 4 + wave, lane, false);
+        fr_xoff = fr.xoff;
+        fr_rel = fr.rel;
+    }
+    auto load_chunk = [&](int c) -> Chunk { return load_chunk_of<GATHER>(jb, fr_xoff, ob, c, wave, lane); };
     auto store_chunk = [&](const Chunk ck, int c, float4 *st) {     // st: [kg_l][8 fragments: 4 weights, 4 activations][64 lanes]
         const float4 ga[4] = {ck.a0, ck.a1, ck.a2, ck.a3}, gb[4] = {ck.b0, ck.b1, ck.b2, ck.b3};
 #pragma unroll
@@ -129,7 +162,7 @@ __device__ __forceinline__ void gemm_item(const LayerJob &jb, const int rb, cons
                 const bool ok = ch >= 0 && ch < jb.cpr;
                 v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
                 const bool first = g == 0 && h == 0;
-                v.x = first ? fr.rel.x : v.x; v.y = first ? fr.rel.y : v.y; v.z = first ? fr.rel.z : v.z; v.w = first ? fr.rel.w : v.w;
+                v.x = first ? fr_rel.x : v.x; v.y = first ? fr_rel.y : v.y; v.z = first ? fr_rel.z : v.z; v.w = first ? fr_rel.w : v.w;
             }
             if (g >= KG) v = make_float4(0.f, 0.f, 0.f, 0.f);      // padding k-group of the last chunk: x = 0 leaves every chain unchanged
             float ops[4];
@@ -152,13 +185,37 @@ __device__ __forceinline__ void gemm_item(const LayerJob &jb, const int rb, cons
             }
     }
     __syncthreads();                                // the previous item's readers (and its pooled-output staging) are done
-    Chunk nxt = load_chunk(0);
+    Chunk nxt;
+    if (pin.valid) nxt = pin.ck;
+    else nxt = load_chunk(0);
     store_chunk(nxt, 0, lds);
     __syncthreads();
 #pragma unroll 1
     for (int c = 0; c < NC; ++c) {
         float4 *cur = lds + (c & 1) * STAGE_F4;
-        nxt = load_chunk(c + 1 < NC ? c + 1 : c);   // global loads in flight while this chunk computes (last: harmless re-read)
+        if (c + 1 < NC) {
+            nxt = load_chunk(c + 1);                // global loads in flight while this chunk computes
+        } else if (nx.ji >= 0) {                    // last chunk: the first chunk of the workgroup's next item instead
+            // (one expansion per job, no run-time index into the kernel argument and no closure over `pre`: either keeps it in scratch)
+#define SAD_FETCH_NEXT(NJ)                                                                         \
+    do {                                                                                           \
+        if ((NJ).gather) {                                                                         \
+            const RowInfo nf = row_info<true>((NJ), nx.rb * 4 + wave, lane, false);                \
+            pre.xoff = nf.xoff;                                                                    \
+            pre.rel = nf.rel;                                                                      \
+            pre.ck = load_chunk_of<true>((NJ), nf.xoff, nx.ob, 0, wave, lane);                     \
+        } else {                                                                                   \
+            const RowInfo nf = row_info<false>((NJ), nx.rb * 4 + wave, lane, false);               \
+            pre.xoff = nf.xoff;                                                                    \
+            pre.rel = nf.rel;                                                                      \
+            pre.ck = load_chunk_of<false>((NJ), nf.xoff, nx.ob, 0, wave, lane);                    \
+        }                                                                                          \
+    } while (0)
+            if (nx.ji == 0) SAD_FETCH_NEXT(lm.j[0]);
+            else SAD_FETCH_NEXT(lm.j[1]);
+#undef SAD_FETCH_NEXT
+            pre.valid = 1;
+        }
         // one k-group = 2 weight + 2 activation fragments from LDS -> 16 MFMAs; reads run one k-group ahead
         float4 wa[2][2], xa[2][2];
 #pragma unroll
@@ -263,6 +320,7 @@ __device__ __forceinline__ void gemm_item(const LayerJob &jb, const int rb, cons
             }
         }
     }
+    return pre;
 }
 
 // (two workgroups per CU by LDS; amdgpu_waves_per_eu tells the register allocator so — left alone it squeezes the
@@ -275,17 +333,28 @@ __global__ __launch_bounds__(LWAVES * 64) __attribute__((amdgpu_waves_per_eu(2, 
     // ~30 ns each chip-wide; measured) and items of a layer cost the same.
     const int i0 = ((job_rows(lm.j[0]) + 127) / 128) * lm.j[0].nog;
     const int nitems = lm.n > 1 ? i0 + ((job_rows(lm.j[1]) + 127) / 128) * lm.j[1].nog : i0;
+    Prefetched pre;
+    pre.valid = 0;
     for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
         const int ji = item < i0 ? 0 : 1;
         const int it = item - (ji ? i0 : 0);
         const LayerJob &jb = lm.j[ji];
         const int nog = jb.nog;
+        NextItem nx{-1, 0, 0};
+        const int nitem = item + (int)gridDim.x;
+        if (nitem < nitems) {
+            const int nji = nitem < i0 ? 0 : 1;
+            const int nit = nitem - (nji ? i0 : 0);
+            nx.ji = nji;
+            nx.rb = nit / lm.j[nji].nog;
+            nx.ob = nit % lm.j[nji].nog;
+        }
         if (jb.gather) {
-            if (jb.last) gemm_item<true, true>(jb, it / nog, it % nog, lds4);
-            else gemm_item<true, false>(jb, it / nog, it % nog, lds4);
+            if (jb.last) pre = gemm_item<true, true>(lm, jb, it / nog, it % nog, lds4, pre, nx);
+            else pre = gemm_item<true, false>(lm, jb, it / nog, it % nog, lds4, pre, nx);
         } else {
-            if (jb.last) gemm_item<false, true>(jb, it / nog, it % nog, lds4);
-            else gemm_item<false, false>(jb, it / nog, it % nog, lds4);
+            if (jb.last) pre = gemm_item<false, true>(lm, jb, it / nog, it % nog, lds4, pre, nx);
+            else pre = gemm_item<false, false>(lm, jb, it / nog, it % nog, lds4, pre, nx);
         }
     }
 }
