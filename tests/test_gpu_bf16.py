@@ -156,6 +156,41 @@ def test_register_chain_bf16(orc, sad, dev, B, N, M, S, C, mlp, r, fdt):
     assert np.array_equal(again, got), "prescanned table: different bits"
 
 
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
+def test_register_chain_bf16_random_group_sizes(orc, sad, dev, seed):
+    """Arbitrary group sizes (not from a ball query): every mix of 1 .. S rows per group, so tiles with 1, 8, 9, 16, 17 and 32
+    groups, groups that span two or three tiles, a last tile with a single live row — the staged pooling's slot / block-width
+    choices (CB = 128 / 64 / 32) and its atomic merge of tile-crossing groups all occur.  SPEC.md §14 tolerance vs the oracle."""
+    import torch
+    from sad_amd import ops, synth
+    rng = np.random.default_rng(1000 + seed)
+    B, N, C = 2, 900, 64
+    S = int(rng.choice([8, 16, 32, 64]))
+    M = int(rng.integers(40, 400))
+    mlp = [[64, 64, 128], [64, 96, 128]][seed % 2]
+    xyz = rng.uniform(0, 1, (B, N, 3)).astype(np.float32)
+    feat = orc.bf16_round(rng.normal(size=(B, N, C)).astype(np.float32))
+    new_xyz = rng.uniform(0, 1, (B, M, 3)).astype(np.float32)
+    idx = rng.integers(0, N, (B, M, S)).astype(np.int32)
+    mode = seed % 3
+    if mode == 0:
+        cnt = rng.integers(1, S + 1, (B, M))
+    elif mode == 1:
+        cnt = rng.choice([1, 1, 1, 2, S], size=(B, M))                   # many single-row groups (32 groups per tile) and full ones
+    else:
+        cnt = np.where(rng.random((B, M)) < 0.5, S, rng.integers(1, 4, (B, M)))
+    cnt = cnt.astype(np.int32)
+    for b in range(B):
+        for m in range(M):
+            idx[b, m, cnt[b, m]:] = idx[b, m, 0]                          # ball-query style padding
+    layers = synth.make_mlp_weights([C + 3] + mlp, rng)
+    want = orc.sa_group_mlp_max_bf16(xyz, feat, new_xyz, idx, layers)
+    net = ops.PackedMLPBf16(layers, True, dev)
+    net.default_geometry = 2
+    got = net.grouped(_t(xyz, dev), _t(feat, dev).bfloat16(), _t(new_xyz, dev), _t(idx, dev), cnt=_t(cnt, dev)).cpu().numpy()
+    _close(got, want, f"random groups seed {seed}: S={S} M={M} mode={mode} rows={int(cnt.sum())}")
+
+
 def test_register_chain_bf16_three_chain_dispatch(orc, sad, dev):
     """The three SA3 branches as ONE register-resident dispatch (sad_mlp_chain_multi_bf16) with prescanned tables:
     chains of different shapes follow each other in a workgroup's item list and the weight ring carries over."""
