@@ -6,10 +6,12 @@
 // 0.77 MB of compulsory bytes per radius — ~87 tests per byte, VALU-bound at <1 % of the HBM
 // roofline.  A uniform grid with cell edge > r_max cuts the tests by ~100x.
 //
-// How index order survives pruning: candidates arrive in cell order, not index order, so accepted
-// indices are not appended — they set one bit each in a per-wave LDS bitmap (N bits per radius).
-// Scanning the bitmap in ascending bit order with a wave-wide popcount prefix yields the first
-// `nsample` accepted indices in ascending index order, exactly what SPEC.md §3's scan produces.
+// How index order survives pruning: candidates arrive in cell order, not index order.  A centroid with
+// at most 128 candidates (99.95 % of a KITTI-shaped scene) sorts them by index in registers (one or two
+// keys per lane, bitonic network) and compacts the accepted ones per radius with a ballot; a denser one
+// sets one bit per accepted index in an LDS bitmap (N bits per radius, one set per workgroup under a
+// lock) and scans it in ascending bit order with a wave-wide popcount prefix.  Either way the first
+// `nsample` accepted indices come out in ascending index order, exactly what SPEC.md §3's scan produces.
 //
 // Exactness: the accept test is the same sad::d2f(point, centroid) < r*r.  Pruning is conservative:
 // cell = floor((x - x0) * inv) is a monotone function of x in binary32, the cell edge is r_max *
@@ -211,40 +213,74 @@ constexpr int GQ_WAVES = 4;
 constexpr int GQ_CPW = 4;     // centroids per wave, processed one after the other
 
 // ---- sort path: a centroid with at most 64 candidates (the common case on lidar-density scenes) needs no bitmap --------
-// One candidate per lane: key = (index << 4) | (bit r set iff d2 < radius_r^2), empty lanes = all ones.  A 64-lane bitonic
+// One candidate per lane: key = (index << 4) | (bit r set iff d2 < radius_r^2), empty lanes = 0xFFFFFFF0.  A 64-lane bitonic
 // sort by key (indices are unique) puts the candidates in ascending index order; for every radius the accepted ones are
 // then compacted with a ballot + prefix popcount: slot = number of accepted lanes below.  No LDS memory, no atomics, no
-// data-dependent loops: ~21 exchange stages of 5 instructions against the bitmap path's ~100 instructions per radius.
-__device__ __forceinline__ unsigned xor_partner(unsigned v, int d) {          // value of lane ^ d
-    if (d == 32) return (unsigned)__shfl_xor((int)v, 32, 64);
-    // ds_swizzle bit-mask mode inside groups of 32 lanes: and_mask 0x1F, or_mask 0, xor_mask d
-    switch (d) {
-        case 1: return (unsigned)__builtin_amdgcn_ds_swizzle((int)v, (1 << 10) | 0x1F);
-        case 2: return (unsigned)__builtin_amdgcn_ds_swizzle((int)v, (2 << 10) | 0x1F);
-        case 4: return (unsigned)__builtin_amdgcn_ds_swizzle((int)v, (4 << 10) | 0x1F);
-        case 8: return (unsigned)__builtin_amdgcn_ds_swizzle((int)v, (8 << 10) | 0x1F);
-        default: return (unsigned)__builtin_amdgcn_ds_swizzle((int)v, (16 << 10) | 0x1F);
-    }
+// data-dependent loops: 21 exchange stages against the bitmap path's ~100 instructions per radius.
+// The kernel is bound by VALU issue (rocprofv3: 1 650 vector instructions per wave, the SIMD's vector unit ~90 % busy at five
+// waves), so the network is the one that needs the fewest of them: every merge starts with a MIRROR exchange (lane i against
+// lane k-1-i of its block) and continues with half-cleaners (i against i^d) — all blocks ascend, the lane that keeps the
+// minimum is always the one with bit d clear, and the six lane masks are compile-time constants handed to v_cndmask as scalar
+// operands (a direction-dependent network needs 21 masks: the compiler kept them in spilled SGPRs, two v_readlane per stage).
+// The partner comes through the LDS crossbar (ds_swizzle / ds_bpermute: no vector instruction): three VALU per stage.
+template <int X>
+__device__ __forceinline__ unsigned swz_xor(unsigned v) {                     // value of lane ^ X, X < 32 (bit-mask mode: and 0x1F, or 0, xor X)
+    return (unsigned)__builtin_amdgcn_ds_swizzle((int)v, (X << 10) | 0x1F);
 }
-__device__ __forceinline__ unsigned bitonic_sort64(unsigned v, int lane) {
-#pragma unroll
-    for (int k = 2; k <= 64; k <<= 1) {
-#pragma unroll
-        for (int d = k >> 1; d >= 1; d >>= 1) {
-            const unsigned p = xor_partner(v, d);
-            const bool keep_min = ((lane & d) == 0) == ((lane & k) == 0 || k == 64);
-            const unsigned lo = v < p ? v : p, hi = v < p ? p : v;
-            v = keep_min ? lo : hi;
-        }
+template <int D>
+__device__ __forceinline__ unsigned long long low_mask() {                    // lanes with bit D clear
+    return D == 1 ? 0x5555555555555555ull : D == 2 ? 0x3333333333333333ull : D == 4 ? 0x0F0F0F0F0F0F0F0Full
+         : D == 8 ? 0x00FF00FF00FF00FFull : D == 16 ? 0x0000FFFF0000FFFFull : 0x00000000FFFFFFFFull;
+}
+template <int D>
+__device__ __forceinline__ unsigned exchange(unsigned v, unsigned p) {        // lanes with bit D clear keep the minimum
+    const unsigned lo = v < p ? v : p, hi = v < p ? p : v;
+    unsigned r;
+    const unsigned long long m = low_mask<D>();
+    asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(r) : "v"(hi), "v"(lo), "s"(m));
+    return r;
+}
+template <int D>
+__device__ __forceinline__ unsigned clean_from(unsigned v) {                  // half-cleaners D, D/2 .. 1
+    if constexpr (D >= 1) {
+        v = exchange<D>(v, swz_xor<D>(v));
+        v = clean_from<D / 2>(v);
     }
     return v;
+}
+template <int K>
+__device__ __forceinline__ unsigned merge_upto32(unsigned v) {                // merges of blocks 2 .. K (K <= 32)
+    if constexpr (K >= 2) {
+        v = merge_upto32<K / 2>(v);
+        v = exchange<K / 2>(v, swz_xor<K - 1>(v));                           // mirror inside the block of K
+        v = clean_from<K / 4>(v);
+    }
+    return v;
+}
+// mir63 = 4 * (63 - lane), x32 = 4 * (lane ^ 32): ds_bpermute addresses
+__device__ __forceinline__ unsigned bitonic_sort64(unsigned v, int mir63) {
+    v = merge_upto32<32>(v);
+    v = exchange<32>(v, (unsigned)__builtin_amdgcn_ds_bpermute(mir63, (int)v));
+    return clean_from<16>(v);
+}
+// 128 keys, two per lane: element e = lane + 64 * register
+__device__ __forceinline__ void bitonic_sort128(unsigned &v0, unsigned &v1, int mir63, int x32) {
+    v0 = bitonic_sort64(v0, mir63);
+    v1 = bitonic_sort64(v1, mir63);
+    const unsigned p0 = (unsigned)__builtin_amdgcn_ds_bpermute(mir63, (int)v1), p1 = (unsigned)__builtin_amdgcn_ds_bpermute(mir63, (int)v0);
+    v0 = v0 < p0 ? v0 : p0;                                                   // element e against 127 - e
+    v1 = v1 < p1 ? p1 : v1;
+    v0 = exchange<32>(v0, (unsigned)__builtin_amdgcn_ds_bpermute(x32, (int)v0));
+    v1 = exchange<32>(v1, (unsigned)__builtin_amdgcn_ds_bpermute(x32, (int)v1));
+    v0 = clean_from<16>(v0);
+    v1 = clean_from<16>(v1);
 }
 
 template <int NR>
 __global__ __launch_bounds__(GQ_WAVES * 64) void grid_query_kernel(const float *__restrict__ new_xyz,
                                                                    const char *__restrict__ ws,
                                                                    GQParams prm, int N, int M, int B, int nbx) {
-    extern __shared__ unsigned bm_all[];        // GQ_WAVES * NR * (NWP + 64) words, zero between centroids
+    extern __shared__ unsigned bm_all[];        // NR * (NWP + 64) words (zero between centroids) + the lock word
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // XCD-aware order: workgroups go to the 8 XCDs round-robin; all centroid blocks of scene
@@ -252,13 +288,15 @@ __global__ __launch_bounds__(GQ_WAVES * 64) void grid_query_kernel(const float *
     const int slot = blockIdx.x >> 3;
     const int b = (blockIdx.x & 7) + 8 * (slot / nbx);
     const int bx = slot - (slot / nbx) * nbx;
-    if (b >= B) return;
     const int NW = (N + 31) >> 5;               // bitmap words
     int wshift = 0;                             // words per lane in the scan: 2^wshift (<= 32 for N <= 65536)
     while ((64 << wshift) < NW) ++wshift;
     const int WPL = 1 << wshift;
     const int NWP = WPL * 64;                   // padded words per bitmap
-    unsigned *bm = bm_all + (size_t)wave * NR * (NWP + 64);
+    // ONE bitmap set per workgroup, taken under a lock: only centroids with more than 128 candidates use it (0.05 % of a
+    // KITTI-shaped scene), and a set per wave (27 KB per workgroup at N = 16 384) capped the kernel at five waves per SIMD
+    unsigned *bm = bm_all;
+    unsigned *lock = bm_all + NR * (NWP + 64);
     // second level: dm[r*64 + l] has bit k set iff word l*WPL + k of bitmap r is non-zero, so the
     // scan touches only the words that received a bit (cost ~ accepted points, not N)
     unsigned *dm = bm + NR * NWP;
@@ -269,12 +307,14 @@ __global__ __launch_bounds__(GQ_WAVES * 64) void grid_query_kernel(const float *
     const float x0 = hdr->x0, y0 = hdr->y0, z0 = hdr->z0, inv = hdr->inv;
     const int gx = hdr->gx, gy = hdr->gy, gz = hdr->gz;
 
-    bool bm_clean = false;                      // the bitmaps are zeroed on first use: most waves never need them (sort path)
+    if (b >= B) return;                         // (workgroup-uniform)
+    for (int w = threadIdx.x; w < NR * (NWP + 64) + 1; w += GQ_WAVES * 64) bm_all[w] = 0u;
+    __syncthreads();
 
     // The wave's GQ_CPW centroids are independent: their dependent memory round trips (centroid -> cell starts ->
-    // first records) are issued for all of them before any is processed — one latency chain per wave instead
-    // of one per centroid (the kernel is latency-bound: ~10 000 cycles of wave time per centroid for ~2 000 of work).
+    // first records) are issued for all of them before any is processed.
     const int m0 = (bx * GQ_WAVES + wave) * GQ_CPW;
+    const int mir63 = 4 * (63 - lane), x32 = 4 * (lane ^ 32);
     float ccx[GQ_CPW], ccy[GQ_CPW], ccz[GQ_CPW];
     int crs[GQ_CPW], crl[GQ_CPW];               // lanes 0..8: start / length of the nine record runs
 #pragma unroll
@@ -309,69 +349,100 @@ __global__ __launch_bounds__(GQ_WAVES * 64) void grid_query_kernel(const float *
         ctot[cc] = off;
         pr0[cc] = rec[lane < off ? src : 0];
     }
-#pragma unroll
-    for (int cc = 0; cc < GQ_CPW; ++cc) {
-        const int m = m0 + cc;
+    // ONE copy of the per-centroid code (the slots rotate through registers): unrolled four times the kernel was 160 KB of
+    // instructions, more than the instruction cache two CUs share
+#pragma unroll 1
+    for (int it = 0; it < GQ_CPW; ++it) {
+        const int m = m0 + it;
         if (m >= M) break;                      // wave-uniform
-        const float cx = ccx[cc], cy = ccy[cc], cz = ccz[cc];
+        const float cx = ccx[0], cy = ccy[0], cz = ccz[0];
+        const float4 prc = pr0[0];
+        const int crsc = crs[0], crlc = crl[0];
+        const int T = ctot[0];
+#pragma unroll
+        for (int cc = 0; cc + 1 < GQ_CPW; ++cc) {
+            ccx[cc] = ccx[cc + 1]; ccy[cc] = ccy[cc + 1]; ccz[cc] = ccz[cc + 1];
+            pr0[cc] = pr0[cc + 1]; crs[cc] = crs[cc + 1]; crl[cc] = crl[cc + 1]; ctot[cc] = ctot[cc + 1];
+        }
         float r2[NR];
 #pragma unroll
         for (int r = 0; r < NR; ++r) r2[r] = prm.radii[r] * prm.radii[r];
-        const int T = ctot[cc];
+        auto make_key = [&](const float4 pr, bool valid) -> unsigned {
+            const float d = sad::d2f(pr.x, pr.y, pr.z, cx, cy, cz);
+            unsigned acc = 0u;
+#pragma unroll
+            for (int r = 0; r < NR; ++r) acc |= d < r2[r] ? 1u << r : 0u;
+            return valid ? ((unsigned)__float_as_int(pr.w) << 4) | acc : 0xFFFFFFF0u;     // (empty lane: sorts last, accepted by no radius)
+        };
+        if (T > 64 && T <= 128 && !prm.no_sort) {
+            // ---- sort path, two candidates per lane (5 % of the centroids of a KITTI-shaped scene; more than 128: 0.05 %) ----
+            int src = __builtin_amdgcn_readlane(crsc, 0) + 64 + lane, off = 0;
+#pragma unroll
+            for (int r = 0; r < 9; ++r) {
+                const int st = __builtin_amdgcn_readlane(crsc, r);
+                src = 64 + lane >= off ? st + (64 + lane - off) : src;
+                off += __builtin_amdgcn_readlane(crlc, r);
+            }
+            const bool valid1 = 64 + lane < T;
+            const float4 pr1 = rec[valid1 ? src : 0];
+            unsigned k0 = make_key(prc, true), k1 = make_key(pr1, valid1);
+            bitonic_sort128(k0, k1, mir63, x32);
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                const int S = prm.nsample[r];                       // (<= 64: one padding store covers the row)
+                int32_t *out = prm.idx[r] + ((size_t)b * M + m) * S;
+                const bool ok0 = (k0 >> r) & 1u, ok1 = (k1 >> r) & 1u;
+                const unsigned long long b0 = __ballot(ok0), b1 = __ballot(ok1);
+                const int n0 = __builtin_popcountll(b0), total = n0 + __builtin_popcountll(b1);
+                const unsigned s0 = __builtin_amdgcn_mbcnt_hi((unsigned)(b0 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b0, 0u));
+                const unsigned s1 = n0 + __builtin_amdgcn_mbcnt_hi((unsigned)(b1 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b1, 0u));
+                if (ok0 && s0 < (unsigned)S) out[s0] = (int)(k0 >> 4);
+                if (ok1 && s1 < (unsigned)S) out[s1] = (int)(k1 >> 4);
+                // SPEC.md §3 padding: the remaining slots repeat the first (lowest) accepted index; none accepted: zeros
+                int first = 0;
+                if (b0) first = __builtin_amdgcn_readlane((int)(k0 >> 4), __builtin_ctzll(b0));
+                else if (b1) first = __builtin_amdgcn_readlane((int)(k1 >> 4), __builtin_ctzll(b1));
+                if (lane >= total && lane < S) out[(unsigned)lane] = first;
+                if (prm.cnt[r] && lane == 0) prm.cnt[r][(size_t)b * M + m] = total < S ? total : S;
+            }
+            continue;
+        }
         if (T <= 64 && !prm.no_sort) {
             // ---- sort path ----
-            const float4 pr = pr0[cc];
-            const bool valid = lane < T;
-            const float d = sad::d2f(pr.x, pr.y, pr.z, cx, cy, cz);
-            unsigned key = 0xFFFFFFFFu;
-            if (valid) {
-                unsigned acc = 0u;
-#pragma unroll
-                for (int r = 0; r < NR; ++r) acc |= d < r2[r] ? 1u << r : 0u;
-                key = ((unsigned)__float_as_int(pr.w) << 4) | acc;
-            }
-#ifdef SAD_BQ_PROBE          // measurement builds only (wrong results): 1 = no sort, 2 = nothing after the candidate loads
-#if SAD_BQ_PROBE == 2
-            if (key == 0x12345u) prm.idx[0][0] = 1;
-            continue;
-#endif
-#else
-            key = bitonic_sort64(key, lane);
-#endif
+            unsigned key = make_key(prc, lane < T);
+            key = bitonic_sort64(key, mir63);
             const int jidx = (int)(key >> 4);
 #pragma unroll
             for (int r = 0; r < NR; ++r) {
                 const int S = prm.nsample[r];
                 int32_t *out = prm.idx[r] + ((size_t)b * M + m) * S;
-                const bool ok = key != 0xFFFFFFFFu && ((key >> r) & 1u);
+                const bool ok = (key >> r) & 1u;
                 const unsigned long long bal = __ballot(ok);
-                const int slot = __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
+                const unsigned slot = __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
                 const int total = __builtin_popcountll(bal);
-                if (ok && slot < S) out[slot] = jidx;
-                // SPEC.md §3 padding: the remaining slots repeat the first (lowest) accepted index; none accepted: zeros
+                if (ok && slot < (unsigned)S) out[slot] = jidx;
                 int first = 0;
                 if (bal) first = __builtin_amdgcn_readlane(jidx, __builtin_ctzll(bal));
-                for (int sidx = (total < S ? total : S) + lane; sidx < S; sidx += 64) out[sidx] = first;
+                if (lane >= total && lane < S) out[(unsigned)lane] = first;
                 if (prm.cnt[r] && lane == 0) prm.cnt[r][(size_t)b * M + m] = total < S ? total : S;
             }
             continue;
         }
         // ---- bitmap path (more than 64 candidates) ----
-        if (!bm_clean) {
-            for (int w = lane; w < NR * (NWP + 64); w += 64) bm[w] = 0u;
-            bm_clean = true;
-        }
+        if (lane == 0)
+            while (atomicCAS(lock, 0u, 1u) != 0u) __builtin_amdgcn_s_sleep(4);
+        __threadfence_block();
         int rstart[9], roff[10];
         roff[0] = 0;
 #pragma unroll
         for (int r = 0; r < 9; ++r) {
-            rstart[r] = __builtin_amdgcn_readlane(crs[cc], r);
-            roff[r + 1] = roff[r] + __builtin_amdgcn_readlane(crl[cc], r);
+            rstart[r] = __builtin_amdgcn_readlane(crsc, r);
+            roff[r + 1] = roff[r] + __builtin_amdgcn_readlane(crlc, r);
         }
         for (int i0 = 0; i0 < T; i0 += 64) {
             const int i = i0 + lane;
             const bool valid = i < T;
-            float4 pr = pr0[cc];
+            float4 pr = prc;
             if (i0 > 0) {                       // (rare: more than 64 candidates)
                 int src = rstart[0] + i;
 #pragma unroll
@@ -419,9 +490,11 @@ __global__ __launch_bounds__(GQ_WAVES * 64) void grid_query_kernel(const float *
             const unsigned long long has = __ballot(cnt != 0);
             int first = 0;
             if (has) first = __builtin_amdgcn_readlane(myfirst, __builtin_ctzll(has));
-            for (int s = (total < S ? total : S) + lane; s < S; s += 64) out[s] = first;
+            if (lane >= total && lane < S) out[(unsigned)lane] = first;
             if (prm.cnt[r] && lane == 0) prm.cnt[r][(size_t)b * M + m] = total < S ? total : S;
         }
+        __threadfence_block();                  // the bitmaps are clean again before the next wave takes them
+        if (lane == 0) atomicExch(lock, 0u);
     }
 }
 
@@ -431,7 +504,7 @@ void launch_query(const float *new_xyz, const char *ws, const GQParams &prm, int
     const int NW = (N + 31) >> 5;
     int WPL = 1;
     while (64 * WPL < NW) WPL <<= 1;
-    const size_t lds = sizeof(unsigned) * (size_t)GQ_WAVES * NR * (WPL * 64 + 64);
+    const size_t lds = sizeof(unsigned) * ((size_t)NR * (WPL * 64 + 64) + 1);
     const int nbx = (M + GQ_WAVES * GQ_CPW - 1) / (GQ_WAVES * GQ_CPW);
     const long long nwg = 8LL * ((B + 7) / 8) * nbx;
     hipLaunchKernelGGL((grid_query_kernel<NR>), dim3((unsigned)nwg), dim3(GQ_WAVES * 64), lds, st, new_xyz, ws, prm, N, M, B, nbx);
