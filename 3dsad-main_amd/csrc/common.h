@@ -70,8 +70,13 @@ struct LayerJob {
 struct LayerMulti {
     LayerJob j[2];
     int n;
+    int *queue;                    // zeroed item queues of the launching stream (ItemQueue, eight counters), NULL: static deal
 };
 int launch_layers(const LayerMulti &lm, long long max_items, hipStream_t st);
+// ITEMQ_INTS zeroed ints owned by (device, stream): launches of one stream run one after the other, and the last workgroup
+// of a launch re-arms the queues, so one set per stream is enough.  NULL while the stream is being captured into a graph
+// (no allocation then) or when the allocation fails: the caller falls back to a static deal.
+int *stream_item_queue(hipStream_t st);
 // Row-streaming plain f32 layer (csrc/mlp_rows.hip, geometry 5)
 struct RowsJob {
     const float *x;                // rows [rows, ldx]
@@ -132,7 +137,7 @@ int bfreg_family(int shape);
 long long bfreg_stream_frags(int shape);           // 1-KB fragments of the stream image (whole stages)
 int bfreg_pack(int shape, const int *dims, int first_has_xyz, const float *const *W, void *dst, hipStream_t st);
 int launch_bfreg(const BfRegMulti &mp, hipStream_t st);
-enum { OPT_FPS_DPP = 0, OPT_MLP_RW = 1, OPT_MLP_BUDGET_KB = 2, OPT_BQ_VARIANT = 3, OPT_FPS_VARIANT = 4, OPT_MLP_FORCE = 5, OPT_MLP_DEDUP_F = 6, OPT_MLP_NODEDUP = 7, OPT_FPS_THREADS = 8, OPT_MLP_STATIC = 9, OPT_GROUP_VARIANT = 10, OPT_MLP_DYN_SLOTS = 11, OPT_MLP_NOXCD = 12, OPT_MLP_STEAL_AFTER = 13, OPT_MLP_CHECK_INUSE = 14, OPT_COUNT };
+enum { OPT_FPS_DPP = 0, OPT_MLP_RW = 1, OPT_MLP_BUDGET_KB = 2, OPT_BQ_VARIANT = 3, OPT_FPS_VARIANT = 4, OPT_MLP_FORCE = 5, OPT_MLP_DEDUP_F = 6, OPT_MLP_NODEDUP = 7, OPT_FPS_THREADS = 8, OPT_MLP_STATIC = 9, OPT_GROUP_VARIANT = 10, OPT_MLP_DYN_SLOTS = 11, OPT_MLP_NOXCD = 12, OPT_MLP_STEAL_AFTER = 13, OPT_MLP_CHECK_INUSE = 14, OPT_MLP_LAYER_QUEUE = 15, OPT_COUNT };
 
 inline int fail(int code, const char *fmt, ...) {
     char buf[480];

@@ -14,6 +14,9 @@
 // persistent workgroups.  k ascends from the bias inside every output's chain, so results are SPEC.md §6's
 // fmaf chains bit for bit (tests/test_gpu_mlp.py::test_layer_streamed_chain_parity).
 #include "common.h"
+#include <map>
+#include <mutex>
+#include <utility>
 
 namespace {
 
@@ -117,17 +120,36 @@ struct Prefetched {        // (plain words only: with a RowInfo and its bools in
     float4 rel;             // relative coordinates of this lane's row (gather layers)
     unsigned xoff;          // byte offset of its input row
     int valid;
+    int next;               // the workgroup's next item (>= the item count: none)
 };
+// Where the next item comes from.  Static deal: item + gridDim.x.  Queues (common.h, ItemQueue): thread 0 pulled a
+// position of its XCD's queue when the current item started and hands the item to the workgroup through `slot` (LDS) one
+// barrier before the last chunk; an empty own queue ends the prefetched sequence (the kernel's loop then looks at the
+// other queues, latency exposed: only at the tail of a launch).
 struct NextItem {
-    int ji;                 // job of the workgroup's next item, -1: none
+    int ji;                 // job of the workgroup's next item
     int rb, ob;
 };
+struct NextSource {
+    int dyn;
+    int pulled;             // thread 0: the position pulled at the start of the item
+    int stat;               // static deal: the next item
+    int own;                // this workgroup's queue
+};
+// three ints behind the two fill stages: the published next item, the items of job 0, the items of both jobs (kept in LDS:
+// as scalar registers they were spilled inside the chunk loop)
+constexpr int META_ITEM = 0, META_I0 = 1, META_N = 2;
 
 template <bool GATHER, bool LAST>
 __device__ __forceinline__ Prefetched gemm_item(const LayerMulti &lm, const LayerJob &jb, const int rb, const int ob, float4 *lds,
-                                                const Prefetched pin, const NextItem nx) {
+                                                const Prefetched pin, const NextSource ns) {
     Prefetched pre;                                 // (by value in, by value out: a reference parameter kept the object in scratch)
     pre.valid = 0;
+    pre.next = 0x7FFFFFFF;
+    int *meta = reinterpret_cast<int *>(lds + 2 * STAGE_F4);
+    auto publish_next = [&]() {                     // (thread 0, before the barrier in front of the last chunk)
+        if (ns.dyn && threadIdx.x == 0) meta[META_ITEM] = ns.pulled * 8 + ns.own;
+    };
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = lane >> 5;
     const int wy = wave >> 1, wx = wave & 1;
@@ -189,13 +211,25 @@ __device__ __forceinline__ Prefetched gemm_item(const LayerMulti &lm, const Laye
     if (pin.valid) nxt = pin.ck;
     else nxt = load_chunk(0);
     store_chunk(nxt, 0, lds);
+    if (NC == 1) publish_next();
     __syncthreads();
 #pragma unroll 1
     for (int c = 0; c < NC; ++c) {
         float4 *cur = lds + (c & 1) * STAGE_F4;
         if (c + 1 < NC) {
             nxt = load_chunk(c + 1);                // global loads in flight while this chunk computes
-        } else if (nx.ji >= 0) {                    // last chunk: the first chunk of the workgroup's next item instead
+        } else {                                    // last chunk: the first chunk of the workgroup's next item instead
+          const int nitem = __builtin_amdgcn_readfirstlane(ns.dyn ? meta[META_ITEM] : ns.stat);     // (wave-uniform: scalar decode and branches)
+          const int mi0 = __builtin_amdgcn_readfirstlane(meta[META_I0]);
+          pre.next = nitem;
+          if (nitem < __builtin_amdgcn_readfirstlane(meta[META_N])) {
+            const int nji = nitem < mi0 ? 0 : 1;
+            const int nit = nitem - (nji ? mi0 : 0);
+            const int nnog = nji ? lm.j[1].nog : lm.j[0].nog;
+            NextItem nx;
+            nx.ji = nji;
+            nx.rb = nit / nnog;
+            nx.ob = nit % nnog;
             // (one expansion per job, no run-time index into the kernel argument and no closure over `pre`: either keeps it in scratch)
 #define SAD_FETCH_NEXT(NJ)                                                                         \
     do {                                                                                           \
@@ -215,6 +249,7 @@ __device__ __forceinline__ Prefetched gemm_item(const LayerMulti &lm, const Laye
             else SAD_FETCH_NEXT(lm.j[1]);
 #undef SAD_FETCH_NEXT
             pre.valid = 1;
+          }
         }
         // one k-group = 2 weight + 2 activation fragments from LDS -> 16 MFMAs; reads run one k-group ahead
         float4 wa[2][2], xa[2][2];
@@ -242,6 +277,7 @@ __device__ __forceinline__ Prefetched gemm_item(const LayerMulti &lm, const Laye
             __builtin_amdgcn_sched_barrier(0);
         }
         if (c + 1 < NC) store_chunk(nxt, c + 1, lds + ((c + 1) & 1) * STAGE_F4);
+        if (c + 2 == NC) publish_next();
         __syncthreads();
     }
     if (jb.relu) {
@@ -329,44 +365,91 @@ __global__ __launch_bounds__(LWAVES * 64) __attribute__((amdgpu_waves_per_eu(2, 
     extern __shared__ __attribute__((aligned(16))) float4 lds4[];     // two fill stages (the first doubles as pooled-output staging)
     // items = (block of 128 rows) x (block of 128 output channels), job 0 first (heaviest); the channel block runs
     // fastest, so the workgroups that share a row block (and its activations in L2) run at about the same time.
-    // Static round-robin: a shared work counter does not scale (returning atomics on one address are served at
-    // ~30 ns each chip-wide; measured) and items of a layer cost the same.
+    // Items are pulled from the launching stream's per-XCD queues (common.h, ItemQueue): under an FPS kernel of another
+    // stream some of these workgroups only start when others finish, and with a static round-robin they still owned a full
+    // share of the items (cluster dispatch 757 us alone, 1 069 us beside one FPS kernel).  lm.queue == NULL: static deal.
+    int *meta = reinterpret_cast<int *>(lds4 + 2 * STAGE_F4);
     const int i0 = ((job_rows(lm.j[0]) + 127) / 128) * lm.j[0].nog;
     const int nitems = lm.n > 1 ? i0 + ((job_rows(lm.j[1]) + 127) / 128) * lm.j[1].nog : i0;
+    const int dyn = lm.queue != nullptr;
+    const sad::ItemQueue Q = sad::itemq_init(lm.queue, dyn ? 8 : 0);
+    int item = blockIdx.x;
+    if (threadIdx.x == 0) {
+        meta[META_I0] = i0;
+        meta[META_N] = nitems;
+        if (dyn) meta[META_ITEM] = sad::itemq_item(Q, Q.own, sad::itemq_pull(Q));
+    }
+    __syncthreads();
+    if (dyn) item = meta[META_ITEM];
     Prefetched pre;
     pre.valid = 0;
-    for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+    while (true) {
+        if (item >= nitems) {
+            if (!dyn) break;
+            __syncthreads();                        // (every thread has read the published item)
+            if (threadIdx.x == 0) meta[META_ITEM] = sad::itemq_steal(Q, nitems);
+            __syncthreads();
+            item = meta[META_ITEM];
+            if (item >= nitems) break;
+            pre.valid = 0;
+        }
         const int ji = item < i0 ? 0 : 1;
         const int it = item - (ji ? i0 : 0);
         const LayerJob &jb = lm.j[ji];
         const int nog = jb.nog;
-        NextItem nx{-1, 0, 0};
-        const int nitem = item + (int)gridDim.x;
-        if (nitem < nitems) {
-            const int nji = nitem < i0 ? 0 : 1;
-            const int nit = nitem - (nji ? i0 : 0);
-            nx.ji = nji;
-            nx.rb = nit / lm.j[nji].nog;
-            nx.ob = nit % lm.j[nji].nog;
-        }
+        NextSource ns;
+        ns.dyn = dyn;
+        ns.pulled = 0;
+        if (dyn && threadIdx.x == 0) ns.pulled = sad::itemq_pull(Q);      // (returning atomic: in flight while the item is computed)
+        ns.stat = item + (int)gridDim.x;
+        ns.own = Q.own;
         if (jb.gather) {
-            if (jb.last) pre = gemm_item<true, true>(lm, jb, it / nog, it % nog, lds4, pre, nx);
-            else pre = gemm_item<true, false>(lm, jb, it / nog, it % nog, lds4, pre, nx);
+            if (jb.last) pre = gemm_item<true, true>(lm, jb, it / nog, it % nog, lds4, pre, ns);
+            else pre = gemm_item<true, false>(lm, jb, it / nog, it % nog, lds4, pre, ns);
         } else {
-            if (jb.last) pre = gemm_item<false, true>(lm, jb, it / nog, it % nog, lds4, pre, nx);
-            else pre = gemm_item<false, false>(lm, jb, it / nog, it % nog, lds4, pre, nx);
+            if (jb.last) pre = gemm_item<false, true>(lm, jb, it / nog, it % nog, lds4, pre, ns);
+            else pre = gemm_item<false, false>(lm, jb, it / nog, it % nog, lds4, pre, ns);
         }
+        item = pre.next;
     }
+    if (dyn && threadIdx.x == 0) sad::itemq_done(Q, (int)gridDim.x);      // the last workgroup out re-arms the queues for the next launch
 }
 
 }  // namespace
 
 namespace sad {
 
-int launch_layers(const LayerMulti &lm, long long max_items, hipStream_t st) {
+int *stream_item_queue(hipStream_t st) {
+    static std::mutex mu;
+    static std::map<std::pair<int, hipStream_t>, int *> queues;     // (never freed: 1 KB per stream that ever launched a layer)
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = queues.find({dev, st});
+    if (it != queues.end()) return it->second;
+    int *q = nullptr;
+    if (hipMalloc(&q, sizeof(int) * ITEMQ_INTS) != hipSuccess || hipMemset(q, 0, sizeof(int) * ITEMQ_INTS) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    queues[{dev, st}] = q;
+    return q;
+}
+
+int launch_layers(const LayerMulti &lm_in, long long max_items, hipStream_t st) {
+    LayerMulti lm = lm_in;
+    lm.queue = get_option(OPT_MLP_LAYER_QUEUE) == 1 ? stream_item_queue(st) : nullptr;
     static std::atomic<uint64_t> attr_done{0};
     lds_attr_once(attr_done, reinterpret_cast<const void *>(&mlp_layer_kernel), 160 * 1024);
-    const size_t lds = sizeof(float4) * (size_t)2 * STAGE_F4;
+    const size_t lds = sizeof(float4) * ((size_t)2 * STAGE_F4 + 1);     // + the three meta ints
     static std::atomic<int> per_cu{0};
     int pc = per_cu.load(std::memory_order_relaxed);
     if (pc == 0) {

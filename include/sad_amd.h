@@ -54,6 +54,10 @@ const char *sad_last_error(void);
  *   group_variant 1 = L2-gather group_points kernel only (no LDS staging)
  *   mlp_rw, mlp_budget_kb, mlp_force, mlp_dedup_f, mlp_nodedup, mlp_static, mlp_dyn_slots, mlp_noxcd: f32 chain geometry overrides
  *                (see sad_mlp_args.geometry; mlp_nodedup = 1 computes the padding rows too)
+ *   mlp_layer_queue 1 = the layer-streamed chain kernel (geometry 3) pulls its items from per-XCD queues owned by the
+ *                launching stream instead of a static round-robin.  Beside an FPS kernel of another stream the cluster
+ *                dispatch of the benchmark is 15 % shorter (905 vs 1 080 us), alone 2 % longer, and the pipelined step
+ *                (two main streams always busy) 1.5 % slower: off by default.  Same results either way.
  * Test knobs of the item queues of the cooperative chain kernel (geometry 4; tables of >= 257 groups):
  *   mlp_steal_after v > 0: a workgroup treats the queue of its own XCD as empty after v - 1 items and takes its items from
  *                the other queues, one at a time and with nothing prefetched, so the cross-queue / weight-ring refill

@@ -799,6 +799,15 @@ def test_layer_streamed_chain_parity(orc, sad, dev, B, N, M, S, C, mlp, r):
     finally:
         _lib.set_option("mlp_nodedup", 0)
     assert np.array_equal(dense, want), "padding skip off: different result"
+    # knob mlp_layer_queue: the same items pulled from the launching stream's per-XCD queues (twice: the last workgroup of a
+    # launch re-arms the queues for the next one)
+    _lib.set_option("mlp_layer_queue", 1)
+    try:
+        for _ in range(2):
+            queued = net.grouped(X, F, Cn, idxs[0], cnt=cnts[0]).cpu().numpy()
+            assert np.array_equal(queued, want), "queue-fed items: different result"
+    finally:
+        _lib.set_option("mlp_layer_queue", 0)
 
 
 PLAIN_LAYERED_CASES = [
@@ -831,6 +840,14 @@ def test_layer_streamed_plain_rows_parity(orc, sad, dev, rows, dims, mask, ld_ou
     assert np.array_equal(got[:, col_off:col_off + dims[-1]], want), f"max diff {np.abs(got[:, col_off:col_off + dims[-1]] - want).max():.3e}"
     rest = np.delete(got, np.s_[col_off:col_off + dims[-1]], axis=1)
     assert (rest == -7.0).all(), "columns outside the slice were written"
+    from sad_amd import _lib
+    _lib.set_option("mlp_layer_queue", 1)               # (plain rows have no row-packing table: the queues are the stream's)
+    try:
+        out2 = torch.full((rows, ld_out), -7.0, dtype=torch.float32, device=dev)
+        net.rows(_t(x, dev), out=out2, col_off=col_off)
+        assert np.array_equal(out2.cpu().numpy(), got), "queue-fed items: different result"
+    finally:
+        _lib.set_option("mlp_layer_queue", 0)
 
 
 ROWS_LAYER_CASES = [

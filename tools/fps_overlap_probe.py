@@ -14,7 +14,7 @@ cfg = config.KITTI
 w = synth.make_weights(cfg, 0)
 pts = torch.from_numpy(synth.make_batch(0, 32)).to(dev)
 det = SADDetector(cfg, w, dev, overlap_fps=False)
-det.set_geometry(json.load(open("profiles/r02_geometry.json")))
+det.set_geometry(json.load(open("profiles/r03_geometry.json")))
 tr = {}
 det(pts, tr); torch.cuda.synchronize()
 xyz0 = pts[:, :, :3].contiguous()
