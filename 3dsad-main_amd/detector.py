@@ -22,7 +22,7 @@ from .sa_module import SAModuleMSG
 
 class SADDetector(nn.Module):
     def __init__(self, cfg: DetectorConfig, weights: dict, device, overlap_fps: bool = True,
-                 n_fps_streams: int = 2, n_main_streams: int = 2, nested_fps_shortcut: bool = True,
+                 n_fps_streams: int = 3, n_main_streams: int = 2, nested_fps_shortcut: bool = True,
                  dtype: str = "f32", query_on_sampling_stream: bool = True):
         """``dtype="bf16"``: every MLP runs on the bf16 matrix-core path (SPEC.md §14, BASELINE.json
         configs[4]); sampling, ball query and box decode are unchanged."""
