@@ -205,7 +205,7 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="scenes per GPU per step")
     ap.add_argument("--no-overlap", action="store_true", help="run FPS on the main stream")
     ap.add_argument("--fps-streams", type=int, default=None,
-                    help="sampling streams used round-robin (default: 3 for f32; bf16: 6 for kitti, 8 for nuscenes - the bf16 MLP "
+                    help="sampling streams used round-robin (default: 3 for f32, 6 for bf16 - the bf16 MLP "
                          "dispatches are short enough that the serial FPS chain of a batch bounds the step otherwise)")
     ap.add_argument("--main-streams", type=int, default=2, help="main streams used round-robin by consecutive steps")
     ap.add_argument("--queue-depth", type=int, default=None,
@@ -231,7 +231,9 @@ def main():
     args = ap.parse_args()
     if args.fps_streams is None:      # the serial FPS chain of a batch (2.9 ms KITTI, 15.6 ms nuScenes) must not bound the step
         # (f32, 16 hardware queues: 13.55 / 13.89 / 12.90 k scenes/s with 2 / 3 / 4 sampling streams, tools/probe/ab_fps_streams.sh)
-        args.fps_streams = 3 if args.dtype == "f32" else (6 if args.config == "kitti" else 8)
+        # bf16 nuScenes (tools/probe/nus_sweep.sh): 32 scenes per batch 3.7 / 4.6 / 5.1 / 5.2 k scenes/s with 3 / 4 / 5 / 6 streams; the
+        # record-streaming FPS slows down as more scenes are in flight (their 1 MB record arrays share the L2)
+        args.fps_streams = 3 if args.dtype == "f32" else 6
     if args.queue_depth is None:
         args.queue_depth = max(6, args.fps_streams + 2)
 

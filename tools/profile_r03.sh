@@ -56,10 +56,10 @@ bf16)
   timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -d $out/pmc_bf16sq -- python3 bench.py --dtype bf16 --no-cpu --geometry-file $out/bf16_geometry.json --no-launch-timing --main-streams 1 --no-overlap --steps 3 --warmup 1 > $out/pmc_bf16sq.log 2>&1 || tail -3 $out/pmc_bf16sq.log
   ;;
 nus)
-  python3 bench.py --config nuscenes --dtype bf16 --batch 8 --no-cpu --steps 80 --warmup 8 --save-geometry $out/nus_geometry.json > $out/nus_bench.log 2>&1 || { tail -3 $out/nus_bench.log; exit 1; }
+  python3 bench.py --config nuscenes --dtype bf16 --batch 32 --no-cpu --steps 40 --warmup 6 --save-geometry $out/nus_geometry.json > $out/nus_bench.log 2>&1 || { tail -3 $out/nus_bench.log; exit 1; }
   grep -E '^\{' $out/nus_bench.log > $out/nuscenes_bf16_bench.json
-  serial nus_serial --config nuscenes --dtype bf16 --batch 8 --steps 6 --geometry-file $out/nus_geometry.json || exit 1
-  python3 tools/roofline_from_profiles.py $out/nus_serial_kernel_trace.csv $out/nuscenes_bf16_bench.json 6 | tee $out/nuscenes_bf16_roofline_from_profiles.txt
+  serial nus_serial --config nuscenes --dtype bf16 --batch 32 --steps 4 --geometry-file $out/nus_geometry.json || exit 1
+  python3 tools/roofline_from_profiles.py $out/nus_serial_kernel_trace.csv $out/nuscenes_bf16_bench.json 4 | tee $out/nuscenes_bf16_roofline_from_profiles.txt
   ;;
 esac; done
 ls -la $out/*.csv $out/*.json $out/*.txt 2>/dev/null
