@@ -3,10 +3,10 @@
 Units and corrections as /opt/skills/guides/MI355X_MICROARCH.md prescribes: both counters are in KiB... (see `note`)."""
 import csv, glob, json, os, sys
 root, out = sys.argv[1], sys.argv[2]
-MLP = ("mlp_reg_kernel", "mlp_coop_kernel", "mlp_layer_kernel", "mlp_chain_kernel", "mlp_chain2_kernel", "mlp_multi_kernel", "rowscan_")
+MLP = ("mlp_reg_kernel", "mlp_coop_kernel", "mlp_layer_kernel", "mlp_chain_kernel", "mlp_chain2_kernel", "mlp_multi_kernel", "mlp_rows_kernel", "rowscan_")
 def total(passname, counter):
     tot, steps = 0.0, 0
-    for f in glob.glob(os.path.join(root, passname, "*", "*_counter_collection.csv")):
+    for f in glob.glob(os.path.join(root, passname, "*", "*_counter_collection.csv")) + glob.glob(os.path.join(root, "pmc_" + passname, "*", "*_counter_collection.csv")):
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"] != counter:
                 continue
@@ -22,7 +22,7 @@ write, s2 = total("write", "WRITE_SIZE")
 # halved, i.e. the raw value is doubled (MI355X_MICROARCH.md, HBM section) — same correction as in round 1
 res = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes, tools/profile_r03.sh pmc / tools/pmc.sh: bench.py --geometry-file "
                  "<geometry of the run> --main-streams 1 --steps 3 --warmup 1), summed over the MLP dispatches (mlp_reg / mlp_coop / mlp_layer / "
-                 "mlp_chain / mlp_multi kernels + their row-packing scans) and divided by the forward passes of the run; FETCH_SIZE doubled "
+                 "mlp_chain / mlp_multi / mlp_rows kernels + their row-packing scans) and divided by the forward passes of the run; FETCH_SIZE doubled "
                  "per the gfx950 correction of MI355X_MICROARCH.md (HBM section); gather-width reads uncalibrated",
        "forward_passes": s1,
        "fetch_size_raw_kb_per_step": fetch / max(1, s1),
