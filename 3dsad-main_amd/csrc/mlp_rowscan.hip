@@ -19,6 +19,7 @@ using sad::chain::WHOLE_BIT;
 // block's offsets in LDS) — a thread walking its own group's rows wrote 4 bytes per lane per step at
 // scattered addresses and took 22 us for 16 384 groups; this takes ~4.
 constexpr int SCAN_T = 1024;
+static_assert(SCAN_T == 1024, "the row search of rowscan_write_kernel is ten halvings");
 
 __device__ __forceinline__ int scan_job_of(const sad::ScanMulti &sm, int block, int &local) {
     int ji = 0;
@@ -100,18 +101,42 @@ __global__ __launch_bounds__(SCAN_T) void rowscan_write_kernel(const sad::ScanMu
     }
     if (!jb.row_src) return;
     // row map of rows [base, base + blk_rows), by destination row
-    for (int q = tid; q < blk_rows; q += SCAN_T) {
-        int lo = 0, hi = SCAN_T;                 // largest gi with s_start[gi] <= q
-        while (hi - lo > 1) {
-            const int mid = (lo + hi) >> 1;
-            if (s_start[mid] <= q) lo = mid; else hi = mid;
+    // Four rows per thread and step (eight: slower, the clamped surplus searches cost more than the overlap buys): a row is a chain of ten dependent LDS reads (the search) and a dependent gather of its
+    // index, and a block has 5 - 30 rows per thread — one at a time, a block of the SA3 stage took 17 us of pure latency.
+    constexpr int U = 4;
+    for (int q0 = tid; q0 < blk_rows; q0 += U * SCAN_T) {
+        int lo[U], src[U], gid[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int q = q0 + u * SCAN_T < blk_rows ? q0 + u * SCAN_T : blk_rows - 1;     // (clamped: searched, not stored)
+            int l = 0, h = SCAN_T;               // largest gi with s_start[gi] <= q
+#pragma unroll
+            for (int it = 0; it < 10; ++it) {    // SCAN_T = 2^10
+                const int mid = (l + h) >> 1;
+                const bool le = s_start[mid] <= q;
+                l = le ? mid : l;
+                h = le ? h : mid;
+            }
+            lo[u] = l;
         }
-        const int gg = lb * SCAN_T + lo;
-        const int r0 = base + s_start[lo], cc = s_start[lo + 1] - s_start[lo];
-        const int whole = ((r0 >> 5) == ((r0 + cc - 1) >> 5)) ? WHOLE_BIT : 0;
-        const long long b = gg / jb.M;
-        jb.row_src[base + q] = (int)(b * jb.N + jb.idx[(long long)gg * jb.S + (q - s_start[lo])]);
-        jb.row_gid[base + q] = gg | whole;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int q = q0 + u * SCAN_T < blk_rows ? q0 + u * SCAN_T : blk_rows - 1;
+            const int gg = lb * SCAN_T + lo[u];
+            const int r0 = base + s_start[lo[u]], cc = s_start[lo[u] + 1] - s_start[lo[u]];
+            const int whole = ((r0 >> 5) == ((r0 + cc - 1) >> 5)) ? WHOLE_BIT : 0;
+            const long long b = gg / jb.M;
+            src[u] = (int)(b * jb.N + jb.idx[(long long)gg * jb.S + (q - s_start[lo[u]])]);
+            gid[u] = gg | whole;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int q = q0 + u * SCAN_T;
+            if (q < blk_rows) {
+                jb.row_src[base + q] = src[u];
+                jb.row_gid[base + q] = gid[u];
+            }
+        }
     }
 }
 }  // namespace
