@@ -91,6 +91,9 @@ SIGNATURES = {
     "sad_mlp_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     "sad_mlp_rowscan": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_int),
                                        ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(vp), vp]),
+    "sad_mlp_rowscan_init": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_int),
+                                            ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(vp), ctypes.POINTER(vp),
+                                            ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), vp]),
     "sad_mlp_preferred_geometry": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(ctypes.c_int)]),
     "sad_mlp_scratch_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                                ctypes.POINTER(ctypes.c_int)]),

@@ -19,6 +19,11 @@ struct ScanJob {
     const int32_t *cnt, *idx;
     int *tab, *blk_sum, *row_src, *row_gid;
     int ngroups, S, N, M, nodedup, R, blk0;
+    // optional: the pooled-output slice of this chain, [ngroups][zld] floats, columns 0 .. zcols-1 of which the scan zero-fills
+    // for the groups the MLP kernels combine with an atomic max (packed rows straddling a 32-row tile: WHOLE_BIT clear) — the
+    // others are overwritten by plain stores, so the caller need not initialise the buffer at all
+    float *zout;
+    int zld, zcols;
 };
 constexpr int SCAN_MAX_CHAINS = SAD_MAX_RADII;     // the branches of one multi-radius stage
 struct ScanMulti { ScanJob j[SCAN_MAX_CHAINS]; int n; };

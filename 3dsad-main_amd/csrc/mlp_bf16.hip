@@ -595,6 +595,9 @@ static int prepare_bf16(const sad_mlp_bf16_args *a, sad_stream_t stream, BfPrepa
         const int ngroups = a->B * a->M;
         int *tab = (int *)a->workspace;
         prep.scan = sad::make_scan_job(a->cnt, ngroups, a->S, 32, tab, 0, a->idx, a->N, a->M);
+        prep.scan.zout = (float *)a->out + a->col_off;     // (a scan launched by the dispatch itself zero-fills the groups that need it)
+        prep.scan.zld = a->ld_out;
+        prep.scan.zcols = a->dims[a->L];
         sad::BfRegChain &rc = prep.rc;
         rc = sad::BfRegChain{};
         rc.xyz = a->xyz; rc.new_xyz = a->new_xyz; rc.feat = a->feat; rc.feat_bf16 = a->feat_bf16; rc.ld_feat = a->ld_feat; rc.C = a->C;

@@ -126,6 +126,9 @@ static int prepare_chain(const sad_mlp_args *a, sad_stream_t stream, Prepared &q
         int *tab = (int *)a->workspace;
         // (the scan is launched by the caller: the chains of a merged dispatch share its two launches)
         q.scan = sad::make_scan_job(a->cnt, (int)p.total_groups, a->S, 32, tab, sad::get_option(sad::OPT_MLP_NODEDUP), a->idx, a->N, a->M);
+        q.scan.zout = a->out + a->col_off;         // (a scan launched by the dispatch itself zero-fills the groups that need it)
+        q.scan.zld = a->ld_out;
+        q.scan.zcols = a->dims[a->L];
         sad::RegChain &rc = q.rc;
         rc.xyz = a->xyz; rc.new_xyz = a->new_xyz; rc.feat = a->feat; rc.packed = a->packed; rc.out = a->out;
         rc.rowtab = tab;
@@ -211,6 +214,9 @@ static int prepare_chain(const sad_mlp_args *a, sad_stream_t stream, Prepared &q
         SAD_REQUIRE(p.total_groups < (1LL << 30), "sad_mlp_chain_f32: too many groups");
         int *tab = (int *)a->workspace;
         q.scan = sad::make_scan_job(a->cnt, (int)p.total_groups, a->S, 32, tab, sad::get_option(sad::OPT_MLP_NODEDUP), a->idx, a->N, a->M);
+        q.scan.zout = a->out + a->col_off;         // (a scan launched by the dispatch itself zero-fills the groups that need it)
+        q.scan.zld = a->ld_out;
+        q.scan.zcols = a->dims[a->L];
         const long long rows_max = (p.total_groups * a->S + 31) / 32 * 32;
         int wa = 0, wb = 0;                         // widths of the two ping-pong activation buffers
         for (int l = 0; l + 1 < a->L; ++l) {

@@ -99,6 +99,26 @@ __global__ __launch_bounds__(SCAN_T) void rowscan_write_kernel(const sad::ScanMu
             jb.tab[2 + sad::ITEMQ_CONFLICT] = 0;
         }
     }
+    if (jb.zout) {
+        // zero the output rows of the groups that straddle a tile boundary (the only ones combined with an atomic max)
+        __shared__ int s_nw[SCAN_T];
+        __shared__ int s_nnw;
+        if (tid == 0) s_nnw = 0;
+        __syncthreads();
+        if (g < jb.ngroups) {
+            const int r0 = base + run;
+            if ((r0 >> 5) != ((r0 + c - 1) >> 5)) s_nw[atomicAdd(&s_nnw, 1)] = g;
+        }
+        __syncthreads();
+        const int nnw = s_nnw;
+        if (((jb.zld | jb.zcols) & 3) == 0 && (reinterpret_cast<uintptr_t>(jb.zout) & 15) == 0) {
+            const int per = jb.zcols >> 2;
+            for (int i = tid; i < nnw * per; i += SCAN_T)
+                reinterpret_cast<float4 *>(jb.zout + (long long)s_nw[i / per] * jb.zld)[i % per] = make_float4(0.f, 0.f, 0.f, 0.f);
+        } else {
+            for (int i = tid; i < nnw * jb.zcols; i += SCAN_T) jb.zout[(long long)s_nw[i / jb.zcols] * jb.zld + i % jb.zcols] = 0.f;
+        }
+    }
     if (!jb.row_src) return;
     // row map of rows [base, base + blk_rows), by destination row
     // Four rows per thread and step (eight: slower, the clamped surplus searches cost more than the overlap buys): a row is a chain of ten dependent LDS reads (the search) and a dependent gather of its
@@ -188,6 +208,27 @@ SAD_API int sad_mlp_rowscan(int n, const int32_t *const *cnt, const int32_t *con
         SAD_REQUIRE((uintptr_t)workspace[i] % 16 == 0, "sad_mlp_rowscan: workspace must be 16-byte aligned");
         SAD_REQUIRE((long long)B * M * S[i] < (1LL << 31), "sad_mlp_rowscan: B*M*S too large");
         jobs[i] = sad::make_scan_job(cnt[i], B * M, S[i], 32, (int *)workspace[i], sad::get_option(sad::OPT_MLP_NODEDUP), idx[i], N, M);
+    }
+    return sad::launch_rowscan_multi(jobs, n, (hipStream_t)stream);
+}
+
+SAD_API int sad_mlp_rowscan_init(int n, const int32_t *const *cnt, const int32_t *const *idx, const int *S, int B, int N,
+                                 int M, void *const *workspace, float *const *out, const int *ld_out, const int *col_off,
+                                 const int *cout, sad_stream_t stream) {
+    SAD_REQUIRE(n >= 1 && n <= sad::SCAN_MAX_CHAINS && cnt && idx && S && workspace && out && ld_out && col_off && cout,
+                "sad_mlp_rowscan_init: need 1..%d chains and non-NULL arrays", sad::SCAN_MAX_CHAINS);
+    SAD_REQUIRE(B >= 1 && N >= 1 && M >= 1 && (long long)B * M < (1LL << 30), "sad_mlp_rowscan_init: bad B/N/M");
+    sad::ScanJob jobs[sad::SCAN_MAX_CHAINS];
+    for (int i = 0; i < n; ++i) {
+        SAD_REQUIRE(cnt[i] && idx[i] && workspace[i] && S[i] >= 1 && S[i] <= 64, "sad_mlp_rowscan_init: chain %d: NULL pointer or bad nsample", i);
+        SAD_REQUIRE((uintptr_t)workspace[i] % 16 == 0, "sad_mlp_rowscan_init: workspace must be 16-byte aligned");
+        SAD_REQUIRE((long long)B * M * S[i] < (1LL << 31), "sad_mlp_rowscan_init: B*M*S too large");
+        SAD_REQUIRE(out[i] && cout[i] >= 1 && col_off[i] >= 0 && ld_out[i] >= col_off[i] + cout[i],
+                    "sad_mlp_rowscan_init: chain %d: need out != NULL and col_off + cout <= ld_out", i);
+        jobs[i] = sad::make_scan_job(cnt[i], B * M, S[i], 32, (int *)workspace[i], sad::get_option(sad::OPT_MLP_NODEDUP), idx[i], N, M);
+        jobs[i].zout = out[i] + col_off[i];
+        jobs[i].zld = ld_out[i];
+        jobs[i].zcols = cout[i];
     }
     return sad::launch_rowscan_multi(jobs, n, (hipStream_t)stream);
 }

@@ -65,6 +65,7 @@ class SADDetector(nn.Module):
         # The SA ball queries need coordinates only: run them right behind the sampling chain, off the
         # main stream (whose MLP kernels they then overlap); the adaptive cluster query stays on main.
         self.query_on_sampling_stream = query_on_sampling_stream
+        self.poison_buffers = False        # test knob: fill the (otherwise uninitialised) pooling buffers with NaN
         # FPS of an FPS-ordered point set is the identity prefix: stage s+1 samples the first M_{s+1}
         # centroids of stage s (proof in _sample_stage).  Only stage 1 runs the FPS kernel.
         self.nested_fps_shortcut = nested_fps_shortcut
@@ -187,16 +188,28 @@ class SADDetector(nn.Module):
             evs = []
             with torch.cuda.stream(side):
                 xyz = points[:, :, :3].contiguous()
-                # the zero-initialised pooling buffers of every stage: one fill, covered by ev_xyz
+                # the pooling buffers of every stage, one allocation.  With the row-packing scans made here (prescan), the scan
+                # zero-fills the few groups the chain kernels combine with an atomic max and the buffers stay uninitialised
+                # (217 MB per 32-scene KITTI step not filled); otherwise one zero fill, covered by ev_xyz
+                prep = self.query_on_sampling_stream and not ops.AUTOTUNE
                 shapes = [(B, m.stage.npoint, m.cat_channels) for m in self.stages]
                 shapes.append((B, cfg.n_cand, self.cluster_cat))
-                zeros = torch.zeros((sum(a * b_ * c_ for a, b_, c_ in shapes),), dtype=torch.float32,
-                                    device=points.device)
+                zeros = (torch.empty if prep else torch.zeros)((sum(a * b_ * c_ for a, b_, c_ in shapes),), dtype=torch.float32,
+                                                               device=points.device)
+                if prep and self.poison_buffers:      # (tests: whatever the kernels do not write must not matter)
+                    zeros.fill_(float("nan"))
                 cats, o = [], 0
                 for shp in shapes:
                     n_el = shp[0] * shp[1] * shp[2]
                     cats.append(zeros[o:o + n_el].view(shp))
                     o += n_el
+                if prep:
+                    # the cluster dispatch scans for itself (its query needs the candidates): fine when both branches run table
+                    # kernels (the dispatch's own scan prepares `out`), else zero the buffer here
+                    m3, cin = self.stages[-1].stage.npoint, self.stages[-1].out_channels
+                    if not all(mlp.wants_prescan(B, m3, cfg.n_cand, s_, self.cluster_cat, cin)
+                               for mlp, s_ in zip(self.cluster_branches, cfg.cluster_nsamples)):
+                        cats[-1].zero_()
                 ev_xyz = torch.cuda.Event()
                 ev_xyz.record(side)
                 cur = xyz
@@ -206,7 +219,7 @@ class SADDetector(nn.Module):
                     prev = cur
                     cur = self._sample_stage(si, cur)
                     centroids.append(cur)
-                    queries.append(self.stages[si].query(prev, cur, prescan=not ops.AUTOTUNE)
+                    queries.append(self.stages[si].query(prev, cur, prescan=not ops.AUTOTUNE, cat=cats[si] if prep else None)
                                    if self.query_on_sampling_stream else None)
                     ev = torch.cuda.Event()
                     ev.record(side)

@@ -253,11 +253,14 @@ def ball_query_multi(radii: Sequence[float], nsamples: Sequence[int], xyz: torch
     return (outs, cnts) if return_counts else outs
 
 
-def rowscan_multi(idxs: Sequence[torch.Tensor], cnts: Sequence[torch.Tensor], N: int) -> List[torch.Tensor]:
+def rowscan_multi(idxs: Sequence[torch.Tensor], cnts: Sequence[torch.Tensor], N: int,
+                  outs: Optional[Sequence[Tuple[torch.Tensor, int, int]]] = None) -> List[torch.Tensor]:
     """Row-packing tables (prefix sum of the per-group counts + row map) of up to four branches of one ball
     query, two launches for all of them.  Needs only what the ball query produced, so it can run on the stream
     that ran the query (the sampling stream), off the MLP stream's critical path; pass table i as the last
-    element of branch i's ``grouped_multi`` call (``PackedMLP.grouped(..., ws=table)``)."""
+    element of branch i's ``grouped_multi`` call (``PackedMLP.grouped(..., ws=table)``).
+    ``outs`` = [(out [B,M,ld_out] float32, col_off, C_out)] per branch: the scan also zero-fills the output slice of the
+    groups the chain kernels combine with an atomic max, so ``out`` may be UNINITIALISED (``sad_mlp_rowscan_init``)."""
     n = len(idxs)
     if n != len(cnts) or not 1 <= n <= _lib.MAX_RADII:
         raise ValueError(f"need 1..{_lib.MAX_RADII} (idx, cnt) pairs")
@@ -273,7 +276,21 @@ def rowscan_multi(idxs: Sequence[torch.Tensor], cnts: Sequence[torch.Tensor], N:
     i_arr = (vp * n)(*[i.data_ptr() for i in idxs])
     s_arr = (ctypes.c_int * n)(*[int(i.shape[2]) for i in idxs])
     w_arr = (vp * n)(*[w.data_ptr() for w in wss])
-    check(lib().sad_mlp_rowscan(n, c_arr, i_arr, s_arr, B, int(N), M, w_arr, _stream()), "sad_mlp_rowscan")
+    if outs is None:
+        check(lib().sad_mlp_rowscan(n, c_arr, i_arr, s_arr, B, int(N), M, w_arr, _stream()), "sad_mlp_rowscan")
+        return wss
+    if len(outs) != n:
+        raise ValueError("outs: one (out, col_off, C_out) per branch")
+    for o, off, co in outs:
+        o = _need(o, "out", torch.float32, 3)
+        if tuple(o.shape[:2]) != (B, M) or not o.is_contiguous() or off < 0 or off + co > o.shape[2]:
+            raise ValueError("outs: need contiguous [B,M,ld_out] float32 buffers with col_off + C_out <= ld_out")
+    o_arr = (vp * n)(*[o.data_ptr() for o, _, _ in outs])
+    ld_arr = (ctypes.c_int * n)(*[int(o.shape[2]) for o, _, _ in outs])
+    off_arr = (ctypes.c_int * n)(*[int(off) for _, off, _ in outs])
+    co_arr = (ctypes.c_int * n)(*[int(co) for _, _, co in outs])
+    check(lib().sad_mlp_rowscan_init(n, c_arr, i_arr, s_arr, B, int(N), M, w_arr, o_arr, ld_arr, off_arr, co_arr, _stream()),
+          "sad_mlp_rowscan_init")
     return wss
 
 

@@ -57,9 +57,12 @@ class SAModuleMSG(nn.Module):
         return fidx, ops.gather_xyz(xyz, fidx)
 
     def query(self, xyz: torch.Tensor, new_xyz: torch.Tensor, radius_pc: Optional[torch.Tensor] = None,
-              radii: Optional[Sequence[float]] = None, prescan: bool = False):
+              radii: Optional[Sequence[float]] = None, prescan: bool = False, cat: Optional[torch.Tensor] = None):
         """The stage's multi-radius ball query: ([idx_b [B,M,S_b]], [cnt_b [B,M]]) and, with ``prescan``,
-        the row-packing tables of the branches as a third element."""
+        the row-packing tables of the branches as a third element.  ``cat`` (with ``prescan``): the stage's
+        UNINITIALISED [B,M,sum C_b] pooling buffer — the scan prepares the slices of the branches that take a table
+        (ops.rowscan_multi ``outs``), the slices of the others are zero-filled here; pass the same buffer to
+        ``group_and_pool(cat=...)``."""
         st = self.stage
         idxs, cnts = ops.ball_query_multi(radii if radii is not None else st.radii, st.nsamples, xyz, new_xyz,
                                           radius_pc, return_counts=True)
@@ -71,8 +74,17 @@ class SAModuleMSG(nn.Module):
             pick = [i for i, (mlp, s) in enumerate(zip(self.branches, st.nsamples))
                     if mlp.wants_prescan(B, N, M, s, self.cat_channels, self.in_channels)]
             wss = [None] * len(idxs)
+            outs = None
+            if cat is not None:
+                offs = [0]
+                for mlp in self.branches:
+                    offs.append(offs[-1] + mlp.out_channels)
+                outs = [(cat, offs[i], self.branches[i].out_channels) for i in pick]
+                for i in range(len(self.branches)):
+                    if i not in pick:
+                        cat[:, :, offs[i]:offs[i + 1]].zero_()
             if pick:
-                for i, w in zip(pick, ops.rowscan_multi([idxs[i] for i in pick], [cnts[i] for i in pick], N)):
+                for i, w in zip(pick, ops.rowscan_multi([idxs[i] for i in pick], [cnts[i] for i in pick], N, outs)):
                     wss[i] = w
             return idxs, cnts, wss
         return idxs, cnts
@@ -93,7 +105,7 @@ class SAModuleMSG(nn.Module):
         wss = q[2] if len(q) > 2 else [None] * len(idxs)
         if keep is not None:
             keep["ball_idx"] = idxs
-        if cat is None:      # ``cat``: a caller-provided ZERO [B,M,sum C_b] float32 buffer
+        if cat is None:      # ``cat``: a caller-provided [B,M,sum C_b] float32 buffer, ZERO or prepared by ``query(prescan=True, cat=cat)``
             cat = torch.zeros((B, M, self.cat_channels), dtype=torch.float32, device=xyz.device)
         calls, off = [], 0               # all branches in one dispatch (ops.grouped_multi)
         for mlp, idx, cnt, ws in zip(self.branches, idxs, cnts, wss):

@@ -238,6 +238,16 @@ size_t sad_mlp_workspace_bytes(int B, int M, int S);
  * for all n.  Pass the workspaces to sad_mlp_chain_f32 with prescanned = 1. */
 int sad_mlp_rowscan(int n, const int32_t *const *cnt, const int32_t *const *idx, const int *S, int B, int N,
                     int M, void *const *workspace, sad_stream_t stream);
+/* The same, and it prepares the pooled-output buffers so that they need NO zero fill: for chain i, columns
+ * [col_off[i], col_off[i] + cout[i]) of the rows out[i][(b*M+m)*ld_out[i] + ...] are set to zero for exactly the groups
+ * whose packed rows straddle a 32-row tile — the only ones the chain kernels of geometries 2 / 3 / 4 (bf16: 2) combine
+ * with an atomic max; every other group is written with plain stores.  (A 32-scene KITTI-shaped step otherwise zero-fills
+ * 217 MB of pooling buffers.)  A scan that sad_mlp_chain[_multi]_f32 / _bf16 launches itself (prescanned == 0, geometries
+ * 2 / 3 / 4) does the same with the call's own `out`.  The tiled kernels (geometry 0 / tile heights) still need `out`
+ * zeroed by the caller. */
+int sad_mlp_rowscan_init(int n, const int32_t *const *cnt, const int32_t *const *idx, const int *S, int B, int N,
+                         int M, void *const *workspace, float *const *out, const int *ld_out, const int *col_off,
+                         const int *cout, sad_stream_t stream);
 size_t sad_mlp_scratch_bytes(int B, int M, int S, int L, const int *dims);
 /* The `geometry` a caller that does not autotune should pass for a GROUPED chain of this shape when it provides
  * cnt + workspace (+ scratch for 3): 4 (cooperative register-resident chain: the SA3 shapes), 2 (register-resident

@@ -363,3 +363,23 @@ def test_bf16_rows_per_tile_geometries_agree(orc, sad, dev):
     a, out, keep = net._grouped_args(_t(xyz, dev), _t(feat, dev).bfloat16(), _t(new_xyz, dev), idxs[0], None, 0, None)
     a.geometry = 100
     assert _lib.lib().sad_mlp_chain_bf16(ctypes.byref(a), torch.cuda.current_stream().cuda_stream) == -1
+
+
+def test_detector_bf16_overlapped_path_with_poisoned_pooling_buffers(sad, dev):
+    """The overlapped path (submit(): scans on the sampling streams) never zero-fills its pooling buffers — the row-packing
+    scans prepare the groups that are combined with an atomic max.  With NaN in those buffers it must give the boxes of the
+    serial path (same kernels, zero-filled buffers) bit for bit."""
+    import torch
+    from sad_amd import config, synth
+    from sad_amd.detector import SADDetector
+    cfg = config.KITTI
+    w = synth.make_weights(cfg, 0)
+    P = _t(synth.make_batch(0, 4), dev)
+    ref = SADDetector(cfg, w, dev, overlap_fps=False, dtype="bf16")(P).clone()
+    det = SADDetector(cfg, w, dev, overlap_fps=True, dtype="bf16")
+    det.poison_buffers = True
+    outs = [det.submit(P)[0] for _ in range(3)]
+    torch.cuda.synchronize()
+    for o in outs:
+        assert torch.equal(o, ref), "overlapped bf16 path with uninitialised pooling buffers differs from the serial path"
+

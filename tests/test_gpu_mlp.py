@@ -935,3 +935,37 @@ def test_layer_streamed_two_chain_dispatch(orc, sad, dev):
         off += net.out_channels
     ops.grouped_multi(calls)
     assert torch.equal(single, merged)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("geom", [2, 3, 4])
+def test_scan_prepares_uninitialised_pooling_buffers(orc, sad, dev, geom):
+    """sad_mlp_rowscan_init: the scan zero-fills exactly the output rows the chain kernels combine with an atomic max, so
+    the pooling buffer may hold anything on entry (here NaN, and a neighbouring column slice that must stay untouched) —
+    prescanned tables and the dispatch's own scan alike, every table-driven geometry; bit-exact vs the oracle."""
+    import torch
+    from sad_amd import ops, synth
+    B, N, M, S, C = 2, 1024, 512, 32, 128
+    mlp = [128, 128, 256] if geom != 3 else [128, 256, 256]
+    rng = np.random.default_rng(geom)
+    xyz = rng.uniform(0, 1, (B, N, 3)).astype(np.float32)
+    feat = rng.normal(size=(B, N, C)).astype(np.float32)
+    new_xyz = np.ascontiguousarray(xyz[:, :M])
+    X, F, Cn = _t(xyz, dev), _t(feat, dev), _t(new_xyz, dev)
+    idxs, cnts = ops.ball_query_multi((0.12,), (S,), X, Cn, return_counts=True)
+    layers = synth.make_mlp_weights([C + 3] + mlp, rng)
+    want = orc.sa_group_mlp_max(xyz, feat, new_xyz, idxs[0].cpu().numpy(), layers)
+    net = ops.PackedMLP(layers, True, dev)
+    net.default_geometry = geom
+    co, off, ld = mlp[-1], 64, mlp[-1] + 96
+    straddling = int(((cnts[0].clamp(min=1).flatten().cumsum(0) - 1) // 32 != (cnts[0].clamp(min=1).flatten().cumsum(0) - cnts[0].clamp(min=1).flatten()) // 32).sum())
+    assert straddling > 50, "the case must have groups that straddle tiles"
+    for prescan in (True, False):
+        out = torch.full((B, M, ld), float("nan"), dtype=torch.float32, device=dev)
+        out[:, :, :off] = -5.0
+        out[:, :, off + co:] = -6.0
+        ws = ops.rowscan_multi(idxs, cnts, N, outs=[(out, off, co)])[0] if prescan else None
+        net.grouped(X, F, Cn, idxs[0], out=out, col_off=off, cnt=cnts[0], ws=ws)
+        got = out.cpu().numpy()
+        assert np.array_equal(got[:, :, off:off + co], want), f"prescan={prescan}: max diff {np.nanmax(np.abs(got[:, :, off:off + co] - want))}"
+        assert (got[:, :, :off] == -5.0).all() and (got[:, :, off + co:] == -6.0).all(), "columns outside the slice were written"

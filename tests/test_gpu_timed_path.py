@@ -179,6 +179,9 @@ def test_bench_configuration_b32_submit_autotuned(orc, sad, dev):
     tuned = det.autotune(P)
     assert "cluster.agg+head" in tuned, f"the fused chain was not tuned: {sorted(tuned)}"
     print(f"[parity] tuned geometry: {tuned}")
+    # the pooling buffers of the overlapped path are never zero-filled (the row-packing scans prepare the few groups that are
+    # combined with an atomic max): NaN in everything the kernels do not write must not reach the boxes
+    det.poison_buffers = True
     import os
     stress = int(os.environ.get("SAD_STRESS", "1"))     # SAD_STRESS=10: soak (the kernels that pull work from queues,
     outs = []                                           # overlap of batches on two main + four sampling streams)
