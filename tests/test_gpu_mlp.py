@@ -969,3 +969,66 @@ def test_scan_prepares_uninitialised_pooling_buffers(orc, sad, dev, geom):
         got = out.cpu().numpy()
         assert np.array_equal(got[:, :, off:off + co], want), f"prescan={prescan}: max diff {np.nanmax(np.abs(got[:, :, off:off + co] - want))}"
         assert (got[:, :, :off] == -5.0).all() and (got[:, :, off + co:] == -6.0).all(), "columns outside the slice were written"
+
+
+def test_scan_prepares_unaligned_output_slice(orc, sad, dev):
+    """sad_mlp_rowscan_init on an output slice that is not 16-byte aligned (odd column offset, odd row stride): the scalar
+    zero-fill path; a chain whose last width is not a multiple of 4."""
+    import torch
+    from sad_amd import ops, synth
+    B, N, M, S, C = 1, 512, 256, 16, 1
+    mlp = [16, 16, 32]
+    rng = np.random.default_rng(7)
+    xyz = rng.uniform(0, 1, (B, N, 3)).astype(np.float32)
+    feat = rng.normal(size=(B, N, C)).astype(np.float32)
+    new_xyz = np.ascontiguousarray(xyz[:, :M])
+    X, F, Cn = _t(xyz, dev), _t(feat, dev), _t(new_xyz, dev)
+    idxs, cnts = ops.ball_query_multi((0.15,), (S,), X, Cn, return_counts=True)
+    layers = synth.make_mlp_weights([C + 3] + mlp, rng)
+    want = orc.sa_group_mlp_max(xyz, feat, new_xyz, idxs[0].cpu().numpy(), layers)
+    net = ops.PackedMLP(layers, True, dev)
+    net.default_geometry = 2
+    co, off, ld = mlp[-1], 3, mlp[-1] + 9
+    out = torch.full((B, M, ld), float("nan"), dtype=torch.float32, device=dev)
+    out[:, :, :off] = -5.0
+    out[:, :, off + co:] = -6.0
+    ws = ops.rowscan_multi(idxs, cnts, N, outs=[(out, off, co)])[0]
+    net.grouped(X, F, Cn, idxs[0], out=out, col_off=off, cnt=cnts[0], ws=ws)
+    got = out.cpu().numpy()
+    assert np.array_equal(got[:, :, off:off + co], want)
+    assert (got[:, :, :off] == -5.0).all() and (got[:, :, off + co:] == -6.0).all()
+
+
+def test_layer_queue_on_two_streams_at_once(orc, sad, dev):
+    """mlp_layer_queue=1: the item queues belong to the launching stream, so layer-streamed chains launched on two
+    streams at the same time do not share counters; both give the oracle's bits, several rounds."""
+    import torch
+    from sad_amd import _lib, ops, synth
+    B, N, M, S, C = 2, 1024, 512, 32, 128
+    mlp = [128, 256, 256]
+    rng = np.random.default_rng(11)
+    xyz = rng.uniform(0, 1, (B, N, 3)).astype(np.float32)
+    feat = rng.normal(size=(B, N, C)).astype(np.float32)
+    new_xyz = np.ascontiguousarray(xyz[:, :M])
+    X, F, Cn = _t(xyz, dev), _t(feat, dev), _t(new_xyz, dev)
+    idxs, cnts = ops.ball_query_multi((0.12,), (S,), X, Cn, return_counts=True)
+    layers = synth.make_mlp_weights([C + 3] + mlp, rng)
+    want = orc.sa_group_mlp_max(xyz, feat, new_xyz, idxs[0].cpu().numpy(), layers)
+    nets = [ops.PackedMLP(layers, True, dev) for _ in range(2)]
+    for n in nets:
+        n.default_geometry = 3
+    streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
+    torch.cuda.synchronize()
+    _lib.set_option("mlp_layer_queue", 1)
+    try:
+        for _ in range(4):
+            outs = []
+            for n, st in zip(nets, streams):
+                with torch.cuda.stream(st):
+                    outs.append(n.grouped(X, F, Cn, idxs[0], cnt=cnts[0]))
+            torch.cuda.synchronize()
+            for o in outs:
+                assert np.array_equal(o.cpu().numpy(), want)
+    finally:
+        _lib.set_option("mlp_layer_queue", 0)
+

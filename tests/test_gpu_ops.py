@@ -129,6 +129,9 @@ def test_ball_query_parity(orc, sad, dev, B, N, M, r, S):
     (2, 3000, 300, (0.3,), (16,)),                       # one radius, N not a multiple of 32
     (1, 2048, 2048, (0.02, 0.5), (8, 64)),               # tiny and huge ball (grid doubles its cells)
     (2, 16384, 512, (0.2, 0.4, 0.8, 1.2), (32, 32, 64, 48)),   # four radii
+    (1, 2048, 512, (0.11,), (64,)),                      # ~74 candidates per centroid: the two-keys-per-lane register sort
+    (2, 2048, 700, (0.05, 0.08), (16, 32)),              # ~27 candidates: the one-key register sort, M not a multiple of 16
+    (1, 2048, 512, (0.08, 0.11, 0.13), (8, 64, 32)),     # ~120 candidates: sort and bitmap paths mixed inside one wave
 ])
 def test_ball_query_grid_vs_oracle(orc, sad, dev, B, N, M, radii, ns):
     """The grid-pruned kernel (LDS bitmap restores index order) returns the oracle's indices."""
