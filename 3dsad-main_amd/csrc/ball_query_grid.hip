@@ -276,6 +276,10 @@ __device__ __forceinline__ void bitonic_sort128(unsigned &v0, unsigned &v1, int 
     v1 = clean_from<16>(v1);
 }
 
+__device__ __forceinline__ float readlane_f(float v, int l) {                  // (the builtin takes ints: a float argument would be CONVERTED)
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+}
+
 template <int NR>
 __global__ __launch_bounds__(GQ_WAVES * 64) void grid_query_kernel(const float *__restrict__ new_xyz,
                                                                    const char *__restrict__ ws,
@@ -311,190 +315,236 @@ __global__ __launch_bounds__(GQ_WAVES * 64) void grid_query_kernel(const float *
     for (int w = threadIdx.x; w < NR * (NWP + 64) + 1; w += GQ_WAVES * 64) bm_all[w] = 0u;
     __syncthreads();
 
-    // The wave's GQ_CPW centroids are independent: their dependent memory round trips (centroid -> cell starts ->
-    // first records) are issued for all of them before any is processed.
+    // The wave's GQ_CPW = 4 centroids are independent: their dependent memory round trips (centroid -> cell starts -> first
+    // records) are issued for all of them before any is processed, and the bookkeeping in front of the records is done for
+    // all four at once: lane 16 c + r holds run r (of nine: three x-adjacent cells each) of centroid c.
+    static_assert(GQ_CPW == 4, "the prologue lays four centroids out in the four rows of 16 lanes");
     const int m0 = (bx * GQ_WAVES + wave) * GQ_CPW;
     const int mir63 = 4 * (63 - lane), x32 = 4 * (lane ^ 32);
-    float ccx[GQ_CPW], ccy[GQ_CPW], ccz[GQ_CPW];
-    int crs[GQ_CPW], crl[GQ_CPW];               // lanes 0..8: start / length of the nine record runs
-#pragma unroll
-    for (int cc = 0; cc < GQ_CPW; ++cc) {
-        const int m = m0 + cc < M ? m0 + cc : M - 1;
-        const float *q = new_xyz + ((size_t)b * M + m) * 3;
-        ccx[cc] = q[0]; ccy[cc] = q[1]; ccz[cc] = q[2];
-        const int ix = cell_coord(ccx[cc], x0, inv, gx), iy = cell_coord(ccy[cc], y0, inv, gy), iz = cell_coord(ccz[cc], z0, inv, gz);
-        // nine runs of up to three x-adjacent cells (contiguous in the record array): lane l < 9
-        int rs = 0, rl = 0;
-        const int dy = lane % 3 - 1, dz = (lane / 3) % 3 - 1;
+    const int pcen = lane >> 4, prun = lane & 15;
+    const int mq = m0 + pcen < M ? m0 + pcen : M - 1;
+    const float *qp = new_xyz + ((size_t)b * M + mq) * 3;
+    const float qx = qp[0], qy = qp[1], qz = qp[2];
+    int rsv = 0, rlv = 0;                       // start / length of this lane's run
+    {
+        const int ix = cell_coord(qx, x0, inv, gx), iy = cell_coord(qy, y0, inv, gy), iz = cell_coord(qz, z0, inv, gz);
+        const int dy = prun % 3 - 1, dz = prun / 3 - 1;
         const int yy = iy + dy, zz = iz + dz;
         const int xlo = ix - 1 < 0 ? 0 : ix - 1, xhi = ix + 1 > gx - 1 ? gx - 1 : ix + 1;
-        if (lane < 9 && yy >= 0 && yy < gy && zz >= 0 && zz < gz && xlo <= xhi) {
+        if (prun < 9 && yy >= 0 && yy < gy && zz >= 0 && zz < gz && xlo <= xhi) {
             const int c0 = (zz * gy + yy) * gx;
-            rs = cell_start[c0 + xlo];
-            rl = cell_start[c0 + xhi + 1] - rs;
+            rsv = cell_start[c0 + xlo];
+            rlv = cell_start[c0 + xhi + 1] - rsv;
         }
-        crs[cc] = rs; crl[cc] = rl;
     }
-    float4 pr0[GQ_CPW];                         // first 64 candidate records of each centroid
-    int ctot[GQ_CPW];                           // candidates of each centroid (wave-uniform)
-#pragma unroll
-    for (int cc = 0; cc < GQ_CPW; ++cc) {
-        int src = __builtin_amdgcn_readlane(crs[cc], 0) + lane, off = 0;
+    // offsets of the runs inside their centroid's candidate list: inclusive scan over each row of 16 lanes (DPP row shifts)
+    int incl = rlv;
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xF, 0xF, true);
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xF, 0xF, true);
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xF, 0xF, true);
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xF, 0xF, true);
+    const int offv = incl - rlv;                // candidate i of the centroid lies in run r iff offv[r] <= i < offv[r] + rlv[r]
+    const int delv = rsv - offv;                // ... and is record i + delv[r]
+    const int T0 = __builtin_amdgcn_readlane(incl, 15), T1 = __builtin_amdgcn_readlane(incl, 31);
+    const int T2 = __builtin_amdgcn_readlane(incl, 47), T3 = __builtin_amdgcn_readlane(incl, 63);
+    // record of candidate i (per lane) of centroid c (wave-uniform): the last run whose offset is <= i
+    auto record_of = [&](int c, int i) -> int {
+        int src = 0;
 #pragma unroll
         for (int r = 0; r < 9; ++r) {
-            const int st = __builtin_amdgcn_readlane(crs[cc], r);
-            src = lane >= off ? st + (lane - off) : src;
-            off += __builtin_amdgcn_readlane(crl[cc], r);
+            const int o = __builtin_amdgcn_readlane(offv, 16 * c + r), d = __builtin_amdgcn_readlane(delv, 16 * c + r);
+            src = i >= o ? i + d : src;
         }
-        ctot[cc] = off;
-        pr0[cc] = rec[lane < off ? src : 0];
+        return src;
+    };
+    // Two neighbouring centroids with at most 32 candidates each (most pairs of a lidar-density scene: mean 20) share ONE pass:
+    // lanes 0..31 carry the first, lanes 32..63 the second — keys, a 32-lane sort per half and the compaction cost the same
+    // instructions for two centroids as for one.
+    const bool pair0 = T0 <= 32 && T1 <= 32 && m0 + 1 < M && !prm.no_sort;
+    const bool pair1 = T2 <= 32 && T3 <= 32 && m0 + 3 < M && !prm.no_sort;
+    const int half = lane >> 5, hi = lane & 31;
+    float4 pra[2], prb[2];                      // records of the pair's first / second centroid (paired: both in pra)
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const bool paired = p ? pair1 : pair0;
+        const int Ta = p ? T2 : T0, Tb = p ? T3 : T1;
+        if (paired) {
+            const int sa = record_of(2 * p, hi), sb = record_of(2 * p + 1, hi);
+            const bool valid = hi < (half ? Tb : Ta);
+            pra[p] = rec[valid ? (half ? sb : sa) : 0];
+            prb[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+        } else {
+            pra[p] = rec[lane < Ta ? record_of(2 * p, lane) : 0];
+            prb[p] = rec[lane < Tb ? record_of(2 * p + 1, lane) : 0];
+        }
     }
-    // ONE copy of the per-centroid code (the slots rotate through registers): unrolled four times the kernel was 160 KB of
-    // instructions, more than the instruction cache two CUs share
+    float r2[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) r2[r] = prm.radii[r] * prm.radii[r];
+    // ONE copy of the per-pair code (the records rotate through registers): unrolled, the kernel was 160 KB of instructions,
+    // more than the instruction cache two CUs share
 #pragma unroll 1
-    for (int it = 0; it < GQ_CPW; ++it) {
-        const int m = m0 + it;
-        if (m >= M) break;                      // wave-uniform
-        const float cx = ccx[0], cy = ccy[0], cz = ccz[0];
-        const float4 prc = pr0[0];
-        const int crsc = crs[0], crlc = crl[0];
-        const int T = ctot[0];
-#pragma unroll
-        for (int cc = 0; cc + 1 < GQ_CPW; ++cc) {
-            ccx[cc] = ccx[cc + 1]; ccy[cc] = ccy[cc + 1]; ccz[cc] = ccz[cc + 1];
-            pr0[cc] = pr0[cc + 1]; crs[cc] = crs[cc + 1]; crl[cc] = crl[cc + 1]; ctot[cc] = ctot[cc + 1];
-        }
-        float r2[NR];
-#pragma unroll
-        for (int r = 0; r < NR; ++r) r2[r] = prm.radii[r] * prm.radii[r];
-        auto make_key = [&](const float4 pr, bool valid) -> unsigned {
-            const float d = sad::d2f(pr.x, pr.y, pr.z, cx, cy, cz);
+    for (int p = 0; p < 2; ++p) {
+        if (m0 + 2 * p >= M) break;             // wave-uniform
+        const bool paired = p ? pair1 : pair0;
+        const float4 pa = pra[0], pb = prb[0];
+        pra[0] = pra[1]; prb[0] = prb[1];
+        if (paired) {
+            // ---- two centroids, one per half wave ----
+            const int ca = 2 * p;
+            const int Ta = p ? T2 : T0, Tb = p ? T3 : T1;
+            const float cxa = readlane_f(qx, 16 * ca), cya = readlane_f(qy, 16 * ca), cza = readlane_f(qz, 16 * ca);
+            const float cxb = readlane_f(qx, 16 * ca + 16), cyb = readlane_f(qy, 16 * ca + 16), czb = readlane_f(qz, 16 * ca + 16);
+            const float cx = half ? cxb : cxa, cy = half ? cyb : cya, cz = half ? czb : cza;
+            const float d = sad::d2f(pa.x, pa.y, pa.z, cx, cy, cz);
             unsigned acc = 0u;
 #pragma unroll
             for (int r = 0; r < NR; ++r) acc |= d < r2[r] ? 1u << r : 0u;
-            return valid ? ((unsigned)__float_as_int(pr.w) << 4) | acc : 0xFFFFFFF0u;     // (empty lane: sorts last, accepted by no radius)
-        };
-        if (T > 64 && T <= 128 && !prm.no_sort) {
-            // ---- sort path, two candidates per lane (5 % of the centroids of a KITTI-shaped scene; more than 128: 0.05 %) ----
-            int src = __builtin_amdgcn_readlane(crsc, 0) + 64 + lane, off = 0;
-#pragma unroll
-            for (int r = 0; r < 9; ++r) {
-                const int st = __builtin_amdgcn_readlane(crsc, r);
-                src = 64 + lane >= off ? st + (64 + lane - off) : src;
-                off += __builtin_amdgcn_readlane(crlc, r);
-            }
-            const bool valid1 = 64 + lane < T;
-            const float4 pr1 = rec[valid1 ? src : 0];
-            unsigned k0 = make_key(prc, true), k1 = make_key(pr1, valid1);
-            bitonic_sort128(k0, k1, mir63, x32);
+            unsigned key = hi < (half ? Tb : Ta) ? ((unsigned)__float_as_int(pa.w) << 4) | acc : 0xFFFFFFF0u;
+            key = merge_upto32<32>(key);        // every exchange stays inside a group of 32 lanes: two independent sorts
+            const int jidx = (int)(key >> 4);
+            const int m = m0 + ca;
 #pragma unroll
             for (int r = 0; r < NR; ++r) {
-                const int S = prm.nsample[r];                       // (<= 64: one padding store covers the row)
-                int32_t *out = prm.idx[r] + ((size_t)b * M + m) * S;
-                const bool ok0 = (k0 >> r) & 1u, ok1 = (k1 >> r) & 1u;
-                const unsigned long long b0 = __ballot(ok0), b1 = __ballot(ok1);
-                const int n0 = __builtin_popcountll(b0), total = n0 + __builtin_popcountll(b1);
-                const unsigned s0 = __builtin_amdgcn_mbcnt_hi((unsigned)(b0 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b0, 0u));
-                const unsigned s1 = n0 + __builtin_amdgcn_mbcnt_hi((unsigned)(b1 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b1, 0u));
-                if (ok0 && s0 < (unsigned)S) out[s0] = (int)(k0 >> 4);
-                if (ok1 && s1 < (unsigned)S) out[s1] = (int)(k1 >> 4);
+                const int S = prm.nsample[r];
+                int32_t *out = prm.idx[r] + ((size_t)b * M + m) * S;      // (the second centroid's row follows: + S)
+                const bool ok = (key >> r) & 1u;
+                const unsigned long long bal = __ballot(ok);
+                const unsigned blo = (unsigned)bal, bhi = (unsigned)(bal >> 32);
+                const int na = __builtin_popcount(blo), nb = __builtin_popcount(bhi);
+                const unsigned below = __builtin_amdgcn_mbcnt_hi(bhi, __builtin_amdgcn_mbcnt_lo(blo, 0u));
+                const unsigned slot = below - (half ? (unsigned)na : 0u);
+                const unsigned rowoff = half ? (unsigned)S : 0u;
+                if (ok && slot < (unsigned)S) out[rowoff + slot] = jidx;
                 // SPEC.md §3 padding: the remaining slots repeat the first (lowest) accepted index; none accepted: zeros
-                int first = 0;
-                if (b0) first = __builtin_amdgcn_readlane((int)(k0 >> 4), __builtin_ctzll(b0));
-                else if (b1) first = __builtin_amdgcn_readlane((int)(k1 >> 4), __builtin_ctzll(b1));
-                if (lane >= total && lane < S) out[(unsigned)lane] = first;
-                if (prm.cnt[r] && lane == 0) prm.cnt[r][(size_t)b * M + m] = total < S ? total : S;
+                int fa = 0, fb = 0;
+                if (blo) fa = __builtin_amdgcn_readlane(jidx, __builtin_ctz(blo));
+                if (bhi) fb = __builtin_amdgcn_readlane(jidx, 32 + __builtin_ctz(bhi));
+                const int total = half ? nb : na, first = half ? fb : fa;
+                const int p1 = total + hi, p2 = p1 + 32;        // (nsample <= 64: two stores per lane cover [total, S))
+                if (p1 < S) out[rowoff + (unsigned)p1] = first;
+                if (p2 < S) out[rowoff + (unsigned)p2] = first;
+                if (prm.cnt[r] && hi == 0) prm.cnt[r][(size_t)b * M + m + half] = total < S ? total : S;
             }
             continue;
         }
-        if (T <= 64 && !prm.no_sort) {
-            // ---- sort path ----
-            unsigned key = make_key(prc, lane < T);
-            key = bitonic_sort64(key, mir63);
-            const int jidx = (int)(key >> 4);
+#pragma unroll 1
+        for (int h2 = 0; h2 < 2; ++h2) {
+            const int c = 2 * p + h2;
+            const int m = m0 + c;
+            if (m >= M) break;                  // wave-uniform
+            const float4 prc = h2 ? pb : pa;
+            const int T = h2 ? (p ? T3 : T1) : (p ? T2 : T0);
+            const float cx = readlane_f(qx, 16 * c), cy = readlane_f(qy, 16 * c), cz = readlane_f(qz, 16 * c);
+            auto make_key = [&](const float4 pr, bool valid) -> unsigned {
+                const float d = sad::d2f(pr.x, pr.y, pr.z, cx, cy, cz);
+                unsigned acc = 0u;
+#pragma unroll
+                for (int r = 0; r < NR; ++r) acc |= d < r2[r] ? 1u << r : 0u;
+                return valid ? ((unsigned)__float_as_int(pr.w) << 4) | acc : 0xFFFFFFF0u;     // (empty lane: sorts last, accepted by no radius)
+            };
+            if (T > 64 && T <= 128 && !prm.no_sort) {
+                // ---- sort path, two candidates per lane (5 % of the centroids of a KITTI-shaped scene; more than 128: 0.05 %) ----
+                const bool valid1 = 64 + lane < T;
+                const float4 pr1 = rec[valid1 ? record_of(c, 64 + lane) : 0];
+                unsigned k0 = make_key(prc, true), k1 = make_key(pr1, valid1);
+                bitonic_sort128(k0, k1, mir63, x32);
+#pragma unroll
+                for (int r = 0; r < NR; ++r) {
+                    const int S = prm.nsample[r];                       // (<= 64: one padding store covers the row)
+                    int32_t *out = prm.idx[r] + ((size_t)b * M + m) * S;
+                    const bool ok0 = (k0 >> r) & 1u, ok1 = (k1 >> r) & 1u;
+                    const unsigned long long b0 = __ballot(ok0), b1 = __ballot(ok1);
+                    const int n0 = __builtin_popcountll(b0), total = n0 + __builtin_popcountll(b1);
+                    const unsigned s0 = __builtin_amdgcn_mbcnt_hi((unsigned)(b0 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b0, 0u));
+                    const unsigned s1 = n0 + __builtin_amdgcn_mbcnt_hi((unsigned)(b1 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b1, 0u));
+                    if (ok0 && s0 < (unsigned)S) out[s0] = (int)(k0 >> 4);
+                    if (ok1 && s1 < (unsigned)S) out[s1] = (int)(k1 >> 4);
+                    int first = 0;
+                    if (b0) first = __builtin_amdgcn_readlane((int)(k0 >> 4), __builtin_ctzll(b0));
+                    else if (b1) first = __builtin_amdgcn_readlane((int)(k1 >> 4), __builtin_ctzll(b1));
+                    if (lane >= total && lane < S) out[(unsigned)lane] = first;
+                    if (prm.cnt[r] && lane == 0) prm.cnt[r][(size_t)b * M + m] = total < S ? total : S;
+                }
+                continue;
+            }
+            if (T <= 64 && !prm.no_sort) {
+                // ---- sort path, one candidate per lane ----
+                unsigned key = make_key(prc, lane < T);
+                key = bitonic_sort64(key, mir63);
+                const int jidx = (int)(key >> 4);
+#pragma unroll
+                for (int r = 0; r < NR; ++r) {
+                    const int S = prm.nsample[r];
+                    int32_t *out = prm.idx[r] + ((size_t)b * M + m) * S;
+                    const bool ok = (key >> r) & 1u;
+                    const unsigned long long bal = __ballot(ok);
+                    const unsigned slot = __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
+                    const int total = __builtin_popcountll(bal);
+                    if (ok && slot < (unsigned)S) out[slot] = jidx;
+                    int first = 0;
+                    if (bal) first = __builtin_amdgcn_readlane(jidx, __builtin_ctzll(bal));
+                    if (lane >= total && lane < S) out[(unsigned)lane] = first;
+                    if (prm.cnt[r] && lane == 0) prm.cnt[r][(size_t)b * M + m] = total < S ? total : S;
+                }
+                continue;
+            }
+            // ---- bitmap path (more than 128 candidates, or bq_variant = 1) ----
+            if (lane == 0)
+                while (atomicCAS(lock, 0u, 1u) != 0u) __builtin_amdgcn_s_sleep(4);
+            __threadfence_block();
+            for (int i0 = 0; i0 < T; i0 += 64) {
+                const int i = i0 + lane;
+                const bool valid = i < T;
+                float4 pr = prc;
+                if (i0 > 0) pr = rec[valid ? record_of(c, i) : 0];
+                const float d = sad::d2f(pr.x, pr.y, pr.z, cx, cy, cz);
+                const unsigned j = (unsigned)__float_as_int(pr.w);
+#pragma unroll
+                for (int r = 0; r < NR; ++r)
+                    if (valid && d < r2[r]) {
+                        const unsigned w = j >> 5;
+                        atomicOr(&bm[r * NWP + w], 1u << (j & 31));
+                        atomicOr(&dm[r * 64 + (w >> wshift)], 1u << (w & (WPL - 1)));
+                    }
+            }
+            // scan each bitmap in ascending bit order; a lane owns WPL consecutive words
 #pragma unroll
             for (int r = 0; r < NR; ++r) {
                 const int S = prm.nsample[r];
                 int32_t *out = prm.idx[r] + ((size_t)b * M + m) * S;
-                const bool ok = (key >> r) & 1u;
-                const unsigned long long bal = __ballot(ok);
-                const unsigned slot = __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
-                const int total = __builtin_popcountll(bal);
-                if (ok && slot < (unsigned)S) out[slot] = jidx;
+                unsigned *bw = bm + r * NWP + lane * WPL;
+                const unsigned dirty = dm[r * 64 + lane];
+                dm[r * 64 + lane] = 0u;
+                int cnt = 0;
+                for (unsigned dd = dirty; dd; dd &= dd - 1) cnt += __builtin_popcount(bw[__builtin_ctz(dd)]);
+                const int inclb = wave_incl_scan(cnt);              // DPP: no LDS round trips on this dependent chain
+                int slot = inclb - cnt;                             // exclusive prefix
+                const int total = __builtin_amdgcn_readlane(inclb, 63);
+                int myfirst = 0;
+                for (unsigned dd = dirty; dd; dd &= dd - 1) {
+                    const int k = __builtin_ctz(dd);
+                    unsigned wd = bw[k];
+                    bw[k] = 0u;                                     // leave the bitmap clean
+                    const int wbase = (lane * WPL + k) << 5;
+                    if (slot == 0 && !myfirst) myfirst = wbase + __builtin_ctz(wd);
+                    while (wd && slot < S) {
+                        const int bit = __builtin_ctz(wd);
+                        wd &= wd - 1;
+                        out[slot++] = wbase + bit;
+                    }
+                    slot += __builtin_popcount(wd);                 // bits beyond nsample
+                }
+                // SPEC.md §3 padding: the remaining slots repeat the first (lowest) accepted index
+                const unsigned long long has = __ballot(cnt != 0);
                 int first = 0;
-                if (bal) first = __builtin_amdgcn_readlane(jidx, __builtin_ctzll(bal));
+                if (has) first = __builtin_amdgcn_readlane(myfirst, __builtin_ctzll(has));
                 if (lane >= total && lane < S) out[(unsigned)lane] = first;
                 if (prm.cnt[r] && lane == 0) prm.cnt[r][(size_t)b * M + m] = total < S ? total : S;
             }
-            continue;
+            __threadfence_block();                  // the bitmaps are clean again before the next wave takes them
+            if (lane == 0) atomicExch(lock, 0u);
         }
-        // ---- bitmap path (more than 64 candidates) ----
-        if (lane == 0)
-            while (atomicCAS(lock, 0u, 1u) != 0u) __builtin_amdgcn_s_sleep(4);
-        __threadfence_block();
-        int rstart[9], roff[10];
-        roff[0] = 0;
-#pragma unroll
-        for (int r = 0; r < 9; ++r) {
-            rstart[r] = __builtin_amdgcn_readlane(crsc, r);
-            roff[r + 1] = roff[r] + __builtin_amdgcn_readlane(crlc, r);
-        }
-        for (int i0 = 0; i0 < T; i0 += 64) {
-            const int i = i0 + lane;
-            const bool valid = i < T;
-            float4 pr = prc;
-            if (i0 > 0) {                       // (rare: more than 64 candidates)
-                int src = rstart[0] + i;
-#pragma unroll
-                for (int r = 1; r < 9; ++r) src = i >= roff[r] ? rstart[r] + (i - roff[r]) : src;
-                pr = rec[valid ? src : 0];
-            }
-            const float d = sad::d2f(pr.x, pr.y, pr.z, cx, cy, cz);
-            const unsigned j = (unsigned)__float_as_int(pr.w);
-#pragma unroll
-            for (int r = 0; r < NR; ++r)
-                if (valid && d < r2[r]) {
-                    const unsigned w = j >> 5;
-                    atomicOr(&bm[r * NWP + w], 1u << (j & 31));
-                    atomicOr(&dm[r * 64 + (w >> wshift)], 1u << (w & (WPL - 1)));
-                }
-        }
-        // scan each bitmap in ascending bit order; a lane owns WPL consecutive words
-#pragma unroll
-        for (int r = 0; r < NR; ++r) {
-            const int S = prm.nsample[r];
-            int32_t *out = prm.idx[r] + ((size_t)b * M + m) * S;
-            unsigned *bw = bm + r * NWP + lane * WPL;
-            const unsigned dirty = dm[r * 64 + lane];
-            dm[r * 64 + lane] = 0u;
-            int cnt = 0;
-            for (unsigned dd = dirty; dd; dd &= dd - 1) cnt += __builtin_popcount(bw[__builtin_ctz(dd)]);
-            const int incl = wave_incl_scan(cnt);               // DPP: no LDS round trips on this dependent chain
-            int slot = incl - cnt;                              // exclusive prefix
-            const int total = __builtin_amdgcn_readlane(incl, 63);
-            int myfirst = 0;
-            for (unsigned dd = dirty; dd; dd &= dd - 1) {
-                const int k = __builtin_ctz(dd);
-                unsigned wd = bw[k];
-                bw[k] = 0u;                                     // leave the bitmap clean
-                const int wbase = (lane * WPL + k) << 5;
-                if (slot == 0 && !myfirst) myfirst = wbase + __builtin_ctz(wd);
-                while (wd && slot < S) {
-                    const int bit = __builtin_ctz(wd);
-                    wd &= wd - 1;
-                    out[slot++] = wbase + bit;
-                }
-                slot += __builtin_popcount(wd);                 // bits beyond nsample
-            }
-            // SPEC.md §3 padding: the remaining slots repeat the first (lowest) accepted index
-            const unsigned long long has = __ballot(cnt != 0);
-            int first = 0;
-            if (has) first = __builtin_amdgcn_readlane(myfirst, __builtin_ctzll(has));
-            if (lane >= total && lane < S) out[(unsigned)lane] = first;
-            if (prm.cnt[r] && lane == 0) prm.cnt[r][(size_t)b * M + m] = total < S ? total : S;
-        }
-        __threadfence_block();                  // the bitmaps are clean again before the next wave takes them
-        if (lane == 0) atomicExch(lock, 0u);
     }
 }
 
