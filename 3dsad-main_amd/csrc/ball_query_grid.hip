@@ -280,8 +280,11 @@ __device__ __forceinline__ float readlane_f(float v, int l) {                  /
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
 }
 
+// (eight waves per SIMD = at most 64 registers: an FPS workgroup of another batch leaves exactly 64 per SIMD on its CU, so this
+// kernel still finds room on the 96 CUs three sampling chains hold; at 65 registers the pipelined step was 0.6 % (f32) / 1.5 % (bf16)
+// slower)
 template <int NR>
-__global__ __launch_bounds__(GQ_WAVES * 64) void grid_query_kernel(const float *__restrict__ new_xyz,
+__global__ __launch_bounds__(GQ_WAVES * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) void grid_query_kernel(const float *__restrict__ new_xyz,
                                                                    const char *__restrict__ ws,
                                                                    GQParams prm, int N, int M, int B, int nbx) {
     extern __shared__ unsigned bm_all[];        // NR * (NWP + 64) words (zero between centroids) + the lock word
