@@ -18,8 +18,12 @@ using sad::chain::WHOLE_BIT;
 // COOPERATIVELY by destination row (coalesced; each row finds its group by a binary search of the
 // block's offsets in LDS) — a thread walking its own group's rows wrote 4 bytes per lane per step at
 // scattered addresses and took 22 us for 16 384 groups; this takes ~4.
-constexpr int SCAN_T = 1024;
-static_assert(SCAN_T == 1024, "the row search of rowscan_write_kernel is ten halvings");
+// 256 groups per workgroup: four waves of ~40 registers find room on any CU — also beside an FPS workgroup of another batch
+// (which leaves 64 registers per SIMD), where the 1 024-thread workgroups of the first version did not fit
+constexpr int SCAN_T = 256;
+constexpr int SCAN_LOG = 8;
+constexpr int SCAN_WAVES = SCAN_T / 64;
+static_assert(SCAN_T == 1 << SCAN_LOG, "the row search of rowscan_write_kernel is SCAN_LOG halvings");
 
 __device__ __forceinline__ int scan_job_of(const sad::ScanMulti &sm, int block, int &local) {
     int ji = 0;
@@ -35,7 +39,7 @@ __device__ __forceinline__ int clamp_cnt(const sad::ScanJob &jb, int g) {
 }
 
 __global__ __launch_bounds__(SCAN_T) void rowscan_sums_kernel(const sad::ScanMulti sm) {
-    __shared__ int wsum[16];
+    __shared__ int wsum[SCAN_WAVES];
     int lb;
     const sad::ScanJob &jb = sm.j[scan_job_of(sm, blockIdx.x, lb)];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -46,13 +50,13 @@ __global__ __launch_bounds__(SCAN_T) void rowscan_sums_kernel(const sad::ScanMul
     __syncthreads();
     if (tid == 0) {
         int t = 0;
-        for (int w = 0; w < 16; ++w) t += wsum[w];
+        for (int w = 0; w < SCAN_WAVES; ++w) t += wsum[w];
         jb.blk_sum[lb] = t;
     }
 }
 
 __global__ __launch_bounds__(SCAN_T) void rowscan_write_kernel(const sad::ScanMulti sm) {
-    __shared__ int wsum[16];
+    __shared__ int wsum[SCAN_WAVES];
     __shared__ int s_base;
     __shared__ int s_start[SCAN_T + 1];          // row offsets of this block's groups, relative to s_base
     int lb;
@@ -65,7 +69,7 @@ __global__ __launch_bounds__(SCAN_T) void rowscan_write_kernel(const sad::ScanMu
     __syncthreads();
     if (tid == 0) {
         int t = 0;
-        for (int w = 0; w < 16; ++w) t += wsum[w];
+        for (int w = 0; w < SCAN_WAVES; ++w) t += wsum[w];
         s_base = t;
     }
     __syncthreads();
@@ -131,7 +135,7 @@ __global__ __launch_bounds__(SCAN_T) void rowscan_write_kernel(const sad::ScanMu
             const int q = q0 + u * SCAN_T < blk_rows ? q0 + u * SCAN_T : blk_rows - 1;     // (clamped: searched, not stored)
             int l = 0, h = SCAN_T;               // largest gi with s_start[gi] <= q
 #pragma unroll
-            for (int it = 0; it < 10; ++it) {    // SCAN_T = 2^10
+            for (int it = 0; it < SCAN_LOG; ++it) {
                 const int mid = (l + h) >> 1;
                 const bool le = s_start[mid] <= q;
                 l = le ? mid : l;
@@ -166,11 +170,12 @@ namespace sad {
 ScanJob make_scan_job(const int32_t *cnt, int ngroups, int S, int R, int *tab, int nodedup, const int32_t *idx, int N, int M) {
     ScanJob jb{};
     jb.cnt = cnt; jb.idx = idx; jb.tab = tab; jb.ngroups = ngroups; jb.S = S; jb.N = N; jb.M = M; jb.nodedup = nodedup; jb.R = R;
-    // layout (ints): hdr[4] | row_start[ngroups+1] (unused) | pass_first[ngroups*S/32+2] (unused) | blk_sum[ngroups/1024+2]
-    //                | row map: src[ngroups*S] | gid[ngroups*S]   (only written when idx != NULL)
-    jb.blk_sum = tab + 4 + (ngroups + 1) + ((long long)ngroups * S / 32 + 2);
+    // layout (ints): hdr[4] | row_start[ngroups+1] (item queues in its first 258 ints, else unused) | pass_first[ngroups*S/32+2]
+    //                (holds the block sums: ngroups/256 + 1 of them) | [ngroups/1024+2] (unused: the block sums of 1 024-group
+    //                blocks lived here) | row map: src[ngroups*S] | gid[ngroups*S]   (only written when idx != NULL)
+    jb.blk_sum = tab + 4 + (ngroups + 1);
     if (idx) {
-        jb.row_src = jb.blk_sum + (ngroups / 1024 + 2);
+        jb.row_src = tab + 4 + (ngroups + 1) + ((long long)ngroups * S / 32 + 2) + (ngroups / 1024 + 2);
         jb.row_gid = jb.row_src + (long long)ngroups * S;
     }
     return jb;
