@@ -328,6 +328,11 @@ def main():
     # queue for 15-30 ms once per run: measured); per-launch intervals under overlap are sampled in a few extra
     # steps AFTER the timed region, the roofline figures come from the serial pass further down.
     step_marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]   # one per step, created up front
+    # (no cyclic-GC passes of the interpreter inside the timed region: the 1 ms steps of the bf16 mode empty an eight-deep queue
+    # during one multi-millisecond pause of the enqueuing thread; one evidence run showed 14 of 200 steps stalled ~5 ms)
+    import gc
+    gc.collect()
+    gc.disable()
     t0 = time.perf_counter()
     for i in range(args.steps):
         out, _ = step()
@@ -337,6 +342,7 @@ def main():
         dist.barrier()
         torch.cuda.synchronize()
     elapsed_local = time.perf_counter() - t0
+    gc.enable()
     log = None if args.no_launch_timing else []
     timed_steps = 0
     if log is not None:
