@@ -317,6 +317,21 @@ __device__ __forceinline__ unsigned half_max_u32(unsigned v) {   // max over lan
     return o > v ? o : v;
 }
 
+#ifdef SAD_FPS_STAMPS
+// measurement build: per wave of workgroup 0, cycles (s_memtime) summed over the second half of the steps:
+// [0] skip test, [1] bucket updates + wave best, [2] publish up to the barrier, [3] barrier wait, [4] read + broadcast,
+// [5] steps in which the wave was active, [6] buckets updated, [7] steps
+__device__ unsigned long long g_fpst[16 * 8];
+extern "C" __attribute__((visibility("default"))) int sad_debug_read_fps_stamps(unsigned long long *dst) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_fpst), sizeof(unsigned long long) * 16 * 8);
+}
+#define FPS_T(v) const unsigned long long v = __builtin_amdgcn_s_memtime()
+#define FPS_ACC(slot, expr) do { if (sample) acc_##slot += (expr); } while (0)
+#else
+#define FPS_T(v)
+#define FPS_ACC(slot, expr)
+#endif
+
 template <int NW, int PPT>
 __device__ __forceinline__ void fps_cell_body(const float *__restrict__ xyz, const int *__restrict__ perm_in, int N,
                                               int M, int *__restrict__ idx_out) {
@@ -384,11 +399,23 @@ __device__ __forceinline__ void fps_cell_body(const float *__restrict__ xyz, con
         __syncthreads();
     }
     int b3 = 1;
+#ifdef SAD_FPS_STAMPS
+    unsigned long long acc_0 = 0, acc_1 = 0, acc_2 = 0, acc_3 = 0, acc_4 = 0, acc_5 = 0, acc_6 = 0, acc_7 = 0;
+#endif
     for (int i = 1; i < M; ++i) {
+#ifdef SAD_FPS_STAMPS
+        const bool sample = blockIdx.x == 0 && i >= M / 2;
+#endif
+        FPS_T(ta);
         // all PPT skip tests at once: lane k tests bucket k (a never-active lane has bmax = 0)
         const float dq = sad::d2f(__builtin_amdgcn_fmed3f(cx, blo0, bhi0), __builtin_amdgcn_fmed3f(cy, blo1, bhi1),
                                   __builtin_amdgcn_fmed3f(cz, blo2, bhi2), cx, cy, cz);
         unsigned act = __builtin_amdgcn_readfirstlane((unsigned)__ballot(dq < __builtin_bit_cast(float, bmax)));
+        FPS_T(tb);
+        FPS_ACC(0, tb - ta);
+        FPS_ACC(5, act ? 1 : 0);
+        FPS_ACC(6, __builtin_popcount(act));
+        FPS_ACC(7, 1);
         if (act) {
             do {
                 const int k = __builtin_amdgcn_readfirstlane(__builtin_ctz(act));
@@ -426,6 +453,8 @@ __device__ __forceinline__ void fps_cell_body(const float *__restrict__ xyz, con
             wy = rdl_f(by, kb);
             wz = rdl_f(bz, kb);
         }
+        FPS_T(tc);
+        FPS_ACC(1, tc - tb);
         unsigned glo;
         if constexpr (NW == 1) {
             glo = wk_lo;
@@ -441,7 +470,14 @@ __device__ __forceinline__ void fps_cell_body(const float *__restrict__ xyz, con
                 *reinterpret_cast<float4 *>(&s_wxyz[buf][wave][0]) = r;
                 if (wave == 0) s_gkey[b3n] = 0ull;
             }
+#ifdef SAD_FPS_STAMPS
+            __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0): the publish has left
+#endif
+            FPS_T(td);
+            FPS_ACC(2, td - tc);
             __syncthreads();
+            FPS_T(te);
+            FPS_ACC(3, te - td);
             const u64 gk = s_gkey[b3];
             const float4 rec = *reinterpret_cast<const float4 *>(&s_wxyz[buf][lane & (NW - 1)][0]);
             const unsigned g = __builtin_amdgcn_readfirstlane((unsigned)gk);
@@ -451,9 +487,20 @@ __device__ __forceinline__ void fps_cell_body(const float *__restrict__ xyz, con
             cy = rdl_f(rec.y, slot);
             cz = rdl_f(rec.z, slot);
             b3 = b3n;
+#ifdef SAD_FPS_STAMPS
+            asm volatile("" :: "v"(cx), "v"(cy), "v"(cz));
+#endif
+            FPS_T(tf);
+            FPS_ACC(4, tf - te);
         }
         if (tid == 0) out[i] = (int)(~glo);
     }
+#ifdef SAD_FPS_STAMPS
+    if (blockIdx.x == 0 && lane == 0) {
+        unsigned long long *d = g_fpst + wave * 8;
+        d[0] = acc_0; d[1] = acc_1; d[2] = acc_2; d[3] = acc_3; d[4] = acc_4; d[5] = acc_5; d[6] = acc_6; d[7] = acc_7;
+    }
+#endif
 }
 
 template <int NW, int PPT>
