@@ -417,6 +417,9 @@ __device__ __forceinline__ void fps_cell_body(const float *__restrict__ xyz, con
         FPS_ACC(6, __builtin_popcount(act));
         FPS_ACC(7, 1);
         if (act) {
+            // a disturbed wave's chain is the step's critical path: it issues ahead of the three idle siblings on its SIMD
+            // (2.87 -> 2.81 ms per 4 096 samples; keeping the priority through the publish: 2.83)
+            __builtin_amdgcn_s_setprio(3);
             do {
                 const int k = __builtin_amdgcn_readfirstlane(__builtin_ctz(act));
                 act &= act - 1;
@@ -453,6 +456,7 @@ __device__ __forceinline__ void fps_cell_body(const float *__restrict__ xyz, con
             wy = rdl_f(by, kb);
             wz = rdl_f(bz, kb);
         }
+        __builtin_amdgcn_s_setprio(0);
         FPS_T(tc);
         FPS_ACC(1, tc - tb);
         unsigned glo;
