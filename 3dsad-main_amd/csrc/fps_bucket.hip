@@ -604,6 +604,7 @@ __global__ __launch_bounds__(1024) void fps_cellg_kernel(const float4 *__restric
                                   __builtin_amdgcn_fmed3f(cz, blo2, bhi2), cx, cy, cz);
         unsigned long long act = __ballot(dq < __builtin_bit_cast(float, bmax));
         if (act) {
+            __builtin_amdgcn_s_setprio(3);       // (as in fps_cell_body: the disturbed wave's chain ahead of its idle siblings)
             do {
                 const int k = __builtin_amdgcn_readfirstlane(__builtin_ctzll(act));
                 act &= act - 1;
@@ -639,6 +640,7 @@ __global__ __launch_bounds__(1024) void fps_cellg_kernel(const float4 *__restric
             wx = rdl_f(bx, kb);
             wy = rdl_f(by, kb);
             wz = rdl_f(bz, kb);
+            __builtin_amdgcn_s_setprio(0);
         }
         const int buf = i & 1;
         const int b3n = b3 == 2 ? 0 : b3 + 1;
