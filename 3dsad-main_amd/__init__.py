@@ -11,6 +11,10 @@ library is missing or a tensor is not on a GPU.
 """
 __version__ = "0.1.0"
 
+# the package owns its runtime preconditions (GPU_MAX_HW_QUEUES before HIP initialises): _runtime.py
+from . import _runtime
+HW_QUEUES_STATE = _runtime.ensure_hw_queues()
+
 _LAZY = {
     "fps": "ops", "ball_query": "ops", "ball_query_multi": "ops", "knn_query": "ops",
     "group_points": "ops", "gather_points": "ops", "gather_xyz": "ops",

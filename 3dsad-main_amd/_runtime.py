@@ -1,0 +1,76 @@
+"""Runtime preconditions the package owns (no torch import here: this runs at ``import sad_amd``).
+
+HIP multiplexes a process's streams onto ``GPU_MAX_HW_QUEUES`` hardware queues (default 4).  The detector's
+pipeline uses two main streams, three to six sampling streams and a gather stream; when a 3 - 16 ms FPS kernel
+shares a hardware queue with MLP launches (or with another FPS chain) the queue serialises them — measured:
+9.5 - 13.2 k scenes/s instead of 14 k on the f32 benchmark.  The variable is read when the HIP
+runtime initialises, so it has to be in the environment before the first HIP call of the process.  There is no
+reference behaviour to mirror (``/root/reference/README.md:1-2`` is the whole upstream repository).
+"""
+import os
+import sys
+import warnings
+
+HW_QUEUES_ENV = "GPU_MAX_HW_QUEUES"
+HW_QUEUES_DEFAULT = 4          # HIP's default when the variable is unset
+HW_QUEUES_WANTED = 16          # every stream of the largest pipeline (2 main + 8 sampling + gather) on its own queue
+
+
+def _hip_initialised() -> bool:
+    """Has this process made a HIP call through torch already?  (torch not imported = certainly not.)"""
+    torch = sys.modules.get("torch")
+    if torch is None:
+        return False
+    try:
+        return bool(torch.cuda.is_initialized())
+    except Exception:
+        return False
+
+
+def ensure_hw_queues(environ=None, initialised=None) -> str:
+    """Called at ``import sad_amd``.  Leaves a value the user exported alone; otherwise exports
+    ``GPU_MAX_HW_QUEUES=16`` when the HIP runtime has not initialised yet.  Returns what happened:
+    "user" (already set), "set" (exported here), "late" (unset, and HIP is already up: nothing done)."""
+    env = os.environ if environ is None else environ
+    if env.get(HW_QUEUES_ENV):
+        return "user"
+    if _hip_initialised() if initialised is None else initialised:
+        return "late"
+    env[HW_QUEUES_ENV] = str(HW_QUEUES_WANTED)
+    return "set"
+
+
+def hw_queues(environ=None) -> int:
+    """Hardware queues the runtime was (or will be) told to use."""
+    env = os.environ if environ is None else environ
+    try:
+        return max(1, int(env.get(HW_QUEUES_ENV, "") or HW_QUEUES_DEFAULT))
+    except ValueError:
+        return HW_QUEUES_DEFAULT
+
+
+_warned = set()
+
+
+def check_stream_budget(n_streams: int, state: str, environ=None) -> bool:
+    """Warn (once per kind and process) when a pipeline is about to create more streams than there are hardware queues.
+    ``state`` is what ``ensure_hw_queues`` returned at import.  Returns True when the budget is fine."""
+    q = hw_queues(environ)
+    if n_streams <= q and state != "late":
+        return True
+    kind = "late" if (state == "late" and n_streams > HW_QUEUES_DEFAULT) else ("over" if n_streams > q else None)
+    if environ is None:          # (explicit environments are the unit tests: always warn there)
+        if kind in _warned:
+            return False
+        _warned.add(kind)
+    if state == "late" and n_streams > HW_QUEUES_DEFAULT:
+        warnings.warn(f"sad_amd: {n_streams} HIP streams are about to share {HW_QUEUES_DEFAULT} hardware queues: "
+                      f"{HW_QUEUES_ENV} was unset when the HIP runtime initialised (import sad_amd, or export "
+                      f"{HW_QUEUES_ENV}={HW_QUEUES_WANTED}, before the first HIP call).  Sampling chains will serialise "
+                      "with MLP launches (measured: -10 to -30 % throughput).", RuntimeWarning, stacklevel=3)
+        return False
+    if n_streams > q:
+        warnings.warn(f"sad_amd: {n_streams} HIP streams on {HW_QUEUES_ENV}={q} hardware queues: streams that share a "
+                      f"queue serialise (use {HW_QUEUES_WANTED}, or fewer sampling streams).", RuntimeWarning, stacklevel=3)
+        return False
+    return True

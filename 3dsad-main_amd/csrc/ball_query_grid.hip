@@ -307,6 +307,9 @@ __global__ __launch_bounds__(GQ_WAVES * 64) __attribute__((amdgpu_waves_per_eu(8
     // second level: dm[r*64 + l] has bit k set iff word l*WPL + k of bitmap r is non-zero, so the
     // scan touches only the words that received a bit (cost ~ accepted points, not N)
     unsigned *dm = bm + NR * NWP;
+    // (the grid is padded to 8 * ceil(B / 8) scenes: the guard comes before anything is read through `base`, whose block
+    // lies past the end of the workspace for the padding scenes)
+    if (b >= B) return;                         // (workgroup-uniform)
     const char *base = ws + (size_t)b * scene_ws_bytes(N);
     const GridHdr *hdr = reinterpret_cast<const GridHdr *>(base);
     const int *cell_start = reinterpret_cast<const int *>(base + sizeof(GridHdr));
@@ -314,7 +317,6 @@ __global__ __launch_bounds__(GQ_WAVES * 64) __attribute__((amdgpu_waves_per_eu(8
     const float x0 = hdr->x0, y0 = hdr->y0, z0 = hdr->z0, inv = hdr->inv;
     const int gx = hdr->gx, gy = hdr->gy, gz = hdr->gz;
 
-    if (b >= B) return;                         // (workgroup-uniform)
     for (int w = threadIdx.x; w < NR * (NWP + 64) + 1; w += GQ_WAVES * 64) bm_all[w] = 0u;
     __syncthreads();
 

@@ -436,8 +436,16 @@ int *stream_item_queue(hipStream_t st) {
     auto it = queues.find({dev, st});
     if (it != queues.end()) return it->second;
     int *q = nullptr;
-    if (hipMalloc(&q, sizeof(int) * ITEMQ_INTS) != hipSuccess || hipMemset(q, 0, sizeof(int) * ITEMQ_INTS) != hipSuccess) {
+    // (the zero fill is enqueued on the launching stream: torch's streams do not synchronise with the null stream, and the
+    // first launch that pulls from the queue must see the zeros.  Entries are keyed by the raw stream handle and live as long
+    // as the process: a destroyed stream whose handle is reused inherits a queue that its last launch re-armed, i.e. zeros)
+    if (hipMalloc(&q, sizeof(int) * ITEMQ_INTS) != hipSuccess) {
         (void)hipGetLastError();
+        return nullptr;
+    }
+    if (hipMemsetAsync(q, 0, sizeof(int) * ITEMQ_INTS, st) != hipSuccess) {
+        (void)hipGetLastError();
+        (void)hipFree(q);
         return nullptr;
     }
     queues[{dev, st}] = q;

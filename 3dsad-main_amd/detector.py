@@ -21,11 +21,17 @@ from .sa_module import SAModuleMSG
 
 
 class SADDetector(nn.Module):
+    _streams_created = 0          # streams made by every detector of this process (they are never destroyed: torch pools them)
+
     def __init__(self, cfg: DetectorConfig, weights: dict, device, overlap_fps: bool = True,
                  n_fps_streams: int = 3, n_main_streams: int = 2, nested_fps_shortcut: bool = True,
-                 dtype: str = "f32", query_on_sampling_stream: bool = True):
+                 dtype: str = "f32", query_on_sampling_stream: bool = True, streams=None):
         """``dtype="bf16"``: every MLP runs on the bf16 matrix-core path (SPEC.md §14, BASELINE.json
-        configs[4]); sampling, ball query and box decode are unchanged."""
+        configs[4]); sampling, ball query and box decode are unchanged.
+        ``streams`` = (sampling streams, main streams): reuse these instead of creating new ones — a process that builds
+        several detectors should share one set, since every stream ever created keeps its place among the
+        ``GPU_MAX_HW_QUEUES`` hardware queues and streams beyond that number share queues (a detector built after 16
+        streams exist ran its FPS chains at half speed: measured)."""
         super().__init__()
         if dtype not in ("f32", "bf16"):
             raise ValueError("dtype must be 'f32' or 'bf16'")
@@ -73,12 +79,21 @@ class SADDetector(nn.Module):
         # busy (one workgroup per scene, a serial chain of M steps), so with input_ready=True the
         # chains of several consecutive batches run side by side while the main stream works
         # through the grouping / MLP kernels of earlier batches.
-        self._sides = ([torch.cuda.Stream(device=self.device) for _ in range(max(1, n_fps_streams))]
-                       if overlap_fps else [])
+        # (main + sampling streams + the caller's gather stream must not outnumber the hardware queues: _runtime.py)
+        from . import HW_QUEUES_STATE, _runtime
+        n_side, n_main = (max(1, n_fps_streams) if overlap_fps else 0), max(1, n_main_streams)
+        if streams is not None:
+            if len(streams[0]) < n_side or len(streams[1]) < n_main:
+                raise ValueError(f"streams: need {n_side} sampling and {n_main} main streams")
+        SADDetector._streams_created += 0 if streams is not None else n_side + n_main
+        _runtime.check_stream_budget(max(n_side + n_main, SADDetector._streams_created) + 1, HW_QUEUES_STATE)
+        self._sides = (list(streams[0][:n_side]) if streams is not None else
+                       [torch.cuda.Stream(device=self.device) for _ in range(n_side)])
         self._calls = 0
         # submit(): consecutive batches alternate between main streams, so the tail of one batch's
         # kernels (few workgroups left, most CUs idle) overlaps the next batch's kernels.
-        self._mains = [torch.cuda.Stream(device=self.device) for _ in range(max(1, n_main_streams))]
+        self._mains = (list(streams[1][:n_main]) if streams is not None else
+                       [torch.cuda.Stream(device=self.device) for _ in range(n_main)])
         self._submits = 0
 
     def submit(self, points: torch.Tensor, post=None):
@@ -188,6 +203,11 @@ class SADDetector(nn.Module):
             evs = []
             with torch.cuda.stream(side):
                 xyz = points[:, :, :3].contiguous()
+                if feat is not None and self.dtype == "f32" and not ops.PackedMLP.feat_fits_table_kernels(
+                        feat.shape[2], feat.stride(1), feat.data_ptr()):
+                    # e.g. [B,N,7] nuScenes-shaped points: a 4-channel view with row stride 7 cannot be fetched in 16-byte
+                    # chunks; one packed copy (33 MB at 32 x 65 536 points) keeps SA1 on the register-resident kernel
+                    feat = feat.contiguous()
                 # the pooling buffers of every stage, one allocation.  With the row-packing scans made here (prescan), the scan
                 # zero-fills the few groups the chain kernels combine with an atomic max and the buffers stay uninitialised
                 # (217 MB per 32-scene KITTI step not filled); otherwise one zero fill, covered by ev_xyz
@@ -207,7 +227,8 @@ class SADDetector(nn.Module):
                     # the cluster dispatch scans for itself (its query needs the candidates): fine when both branches run table
                     # kernels (the dispatch's own scan prepares `out`), else zero the buffer here
                     m3, cin = self.stages[-1].stage.npoint, self.stages[-1].out_channels
-                    if not all(mlp.wants_prescan(B, m3, cfg.n_cand, s_, self.cluster_cat, cin)
+                    fdt = torch.bfloat16 if (self.dtype == "bf16" and self.stages[-1].agg is not None) else torch.float32
+                    if not all(mlp.wants_prescan(B, m3, cfg.n_cand, s_, self.cluster_cat, cin, feat_dtype=fdt)
                                for mlp, s_ in zip(self.cluster_branches, cfg.cluster_nsamples)):
                         cats[-1].zero_()
                 ev_xyz = torch.cuda.Event()
@@ -219,13 +240,18 @@ class SADDetector(nn.Module):
                     prev = cur
                     cur = self._sample_stage(si, cur)
                     centroids.append(cur)
-                    queries.append(self.stages[si].query(prev, cur, prescan=not ops.AUTOTUNE, cat=cats[si] if prep else None)
+                    # (stage 0 reads `feat`; a later stage reads the previous stage's output, which does not exist yet: a fresh
+                    # contiguous tensor, bf16 only when a bf16 aggregation layer produced it)
+                    prev_agg = si > 0 and self.stages[si - 1].agg is not None
+                    queries.append(self.stages[si].query(prev, cur, prescan=not ops.AUTOTUNE, cat=cats[si] if prep else None,
+                                                         feat=feat if si == 0 else None,
+                                                         feat_dtype=torch.bfloat16 if (self.dtype == "bf16" and prev_agg) else torch.float32)
                                    if self.query_on_sampling_stream else None)
                     ev = torch.cuda.Event()
                     ev.record(side)
                     evs.append(ev)
             points.record_stream(side)
-            for t in centroids + [xyz]:
+            for t in centroids + [xyz] + ([feat] if feat is not None else []):
                 t.record_stream(main)
             for q in queries:
                 if q is not None:
@@ -237,6 +263,9 @@ class SADDetector(nn.Module):
             main.wait_event(ev_xyz)
         else:
             xyz = points[:, :, :3].contiguous()
+            if feat is not None and self.dtype == "f32" and not ops.PackedMLP.feat_fits_table_kernels(
+                    feat.shape[2], feat.stride(1), feat.data_ptr()):
+                feat = feat.contiguous()
             centroids = self._sample_chain(xyz)
             evs = [None] * len(centroids)
             queries = [None] * len(centroids)

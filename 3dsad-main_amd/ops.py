@@ -294,18 +294,25 @@ def rowscan_multi(idxs: Sequence[torch.Tensor], cnts: Sequence[torch.Tensor], N:
     return wss
 
 
-def workspace_status(ws: torch.Tensor) -> dict:
+_ITEMQ_INTS = 2 + 32 * 8      # csrc/common.h: a table carries the per-XCD item queues (and these ints) only when it has this many row starts
+
+
+def workspace_status(ws: torch.Tensor, n_groups: Optional[int] = None) -> dict:
     """Instrumentation ints of a row-packing table (include/sad_amd.h, SAD_WS_*): weight-ring refills of the
     cooperative chain kernel, the id of the dispatch that owns the item queues right now and the conflict flag of the
-    ``mlp_check_inuse`` knob.  Synchronises the device (a test / debugging helper, never on the measured path)."""
+    ``mlp_check_inuse`` knob.  Synchronises the device (a test / debugging helper, never on the measured path).
+    ``n_groups`` = B * M of the table: a table with fewer than 258 row starts has no item queues (the kernels deal such
+    launches statically) and ints 5..7 hold row starts there, so zeros are reported; pass it whenever the table may be small."""
+    if n_groups is not None and n_groups + 1 < _ITEMQ_INTS:
+        return {"refills": 0, "in_use": 0, "conflict": 0}
     torch.cuda.synchronize(ws.device)
     hdr = ws[:32].view(torch.int32).cpu()
     return {"refills": int(hdr[_lib.WS_REFILLS]), "in_use": int(hdr[_lib.WS_INUSE]), "conflict": int(hdr[_lib.WS_CONFLICT])}
 
 
-def check_workspace(ws: torch.Tensor) -> None:
+def check_workspace(ws: torch.Tensor, n_groups: Optional[int] = None) -> None:
     """Raises if two dispatches were seen sharing ``ws`` at the same time (needs ``mlp_check_inuse=1``)."""
-    st = workspace_status(ws)
+    st = workspace_status(ws, n_groups)
     if st["conflict"]:
         raise RuntimeError("row-packing workspace was used by two dispatches at the same time (one dispatch at a time per "
                            "workspace: sad_mlp_args.workspace in include/sad_amd.h)")
@@ -482,11 +489,27 @@ class PackedMLP:
         a.relu_mask = self.relu_mask
         return a
 
-    def wants_prescan(self, B: int, N: int, M: int, S: int, ld_out: int, C: int) -> bool:
+    @staticmethod
+    def feat_fits_table_kernels(C: int, ld_feat: int, ptr: int) -> bool:
+        """Can the register-resident / layer-streamed / cooperative kernels read feature rows of this layout?  They fetch
+        16-byte chunks (C % 4 == 0, row stride % 4 == 0, 16-byte aligned base); a single strided channel (or none) is the
+        other layout they take.  The ONE predicate behind ``wants_prescan`` and ``_grouped_args``: the first decides who
+        prepares the pooling buffer, the second which kernel runs, and they must agree."""
+        return C <= 1 or (C % 4 == 0 and ld_feat % 4 == 0 and ptr % 16 == 0)
+
+    def wants_prescan(self, B: int, N: int, M: int, S: int, ld_out: int, C: int, feat: Optional[torch.Tensor] = None,
+                      feat_dtype=torch.float32) -> bool:
         """Will a grouped call of this shape (with counts) run a kernel that consumes a caller-made row-packing table
-        (geometries 2 / 3 / 4)?  The tiled kernel packs with its own tile height: a table made for it would be wasted."""
+        (geometries 2 / 3 / 4)?  The tiled kernel packs with its own tile height: a table made for it would be wasted —
+        and it expects a ZERO pooling buffer, which the scan does not give it.  ``feat``: the feature tensor the call will
+        get ([B,N,C] point-major, any stride); None = a fresh contiguous float32 [B,N,C] tensor (a stage output)."""
         geom = self._geom.get((True, B, N, M, S, ld_out)) or self.default_geometry
-        if not geom and not AUTOTUNE and (C == 1 or C % 4 == 0):
+        if feat is None:
+            fits = self.feat_fits_table_kernels(C, C, 0)
+        else:
+            fits = (feat.dim() == 3 and feat.stride(2) == 1 and feat.stride(0) == N * feat.stride(1)
+                    and self.feat_fits_table_kernels(feat.shape[2], feat.stride(1), feat.data_ptr()))
+        if not geom and not AUTOTUNE and fits:
             geom = self.preferred_geometry
         return geom % 1000 in (2, 3, 4)
 
@@ -528,7 +551,7 @@ class PackedMLP:
             keep.append(feat_pm)
             # (the register-resident / layer-streamed kernels read feature rows as 16-byte chunks; a single strided
             # channel is the other layout they take)
-            feat_ok16 = C == 1 or (C % 4 == 0 and a.ld_feat % 4 == 0 and feat_pm.data_ptr() % 16 == 0)
+            feat_ok16 = self.feat_fits_table_kernels(C, a.ld_feat, feat_pm.data_ptr())
         if self.dims[0] != C + 3:
             raise ValueError(f"MLP expects {self.dims[0] - 3} feature channels, got {C}")
         if out is None:   # the kernel max-combines into the buffer: it must start at zero
@@ -555,6 +578,12 @@ class PackedMLP:
         a.geometry = self._geom.get((bool(a.idx), a.B, a.N, a.M, a.S, a.ld_out)) or self.default_geometry
         if not a.geometry and cnt is not None and not AUTOTUNE and feat_ok16:
             a.geometry = self.preferred_geometry
+        if a.prescanned and a.geometry % 1000 not in (2, 3, 4):
+            # backstop: a caller-made table means the caller's scan prepared `out` for a table kernel (only the groups those
+            # kernels combine atomically were zeroed); the tiled kernel packs for itself and max-combines into memory it
+            # expects to be zero — never run it on such a buffer
+            raise RuntimeError(f"{self.name or 'PackedMLP'}: a row-packing table (ws) was passed but geometry {a.geometry} packs for "
+                               "itself; ask wants_prescan(..., feat=<the feature tensor>) before making the table")
         if self._layered_ok and cnt is not None and (a.geometry == 3 or AUTOTUNE):
             dims_c = (ctypes.c_int * (self.L + 1))(*self.dims)
             nbytes = lib().sad_mlp_scratch_bytes(B, M, S, self.L, dims_c)
@@ -740,10 +769,16 @@ class PackedMLPBf16:
             return True
         return (feat_pm.dtype == torch.bfloat16 and C % 8 == 0 and feat_pm.stride(1) % 8 == 0 and feat_pm.data_ptr() % 16 == 0)
 
-    def wants_prescan(self, B: int, N: int, M: int, S: int, ld_out: int, C: int) -> bool:
-        """See ``PackedMLP.wants_prescan``: geometry 2 consumes a caller-made row-packing table."""
+    def wants_prescan(self, B: int, N: int, M: int, S: int, ld_out: int, C: int, feat: Optional[torch.Tensor] = None,
+                      feat_dtype=torch.bfloat16) -> bool:
+        """See ``PackedMLP.wants_prescan``: geometry 2 consumes a caller-made row-packing table.  ``feat`` None = a fresh
+        contiguous [B,N,C] tensor of ``feat_dtype`` (a stage output); the same ``_feat_ok_reg`` rule decides in ``_grouped_args``."""
         geom = self._geom.get((True, B, N, M, S, ld_out)) or self.default_geometry
-        if not geom and not AUTOTUNE:
+        if feat is None:
+            fits = C <= 13 or (feat_dtype == torch.bfloat16 and C % 8 == 0)
+        else:
+            fits = (feat.dim() == 3 and feat.stride(2) == 1 and feat.stride(0) == N * feat.stride(1) and self._feat_ok_reg(feat))
+        if not geom and not AUTOTUNE and fits:
             geom = self.preferred_geometry
         return geom == 2
 
@@ -819,8 +854,11 @@ class PackedMLPBf16:
         a.geometry = self._geom.get((bool(a.idx), a.B, a.N, a.M, a.S, a.ld_out)) or self.default_geometry
         if not a.geometry and cnt is not None and not AUTOTUNE and self._feat_ok_reg(feat_pm):
             a.geometry = self.preferred_geometry
-        if cnt is not None and given and a.geometry == 2:
-            a.prescanned = 1          # (the tiled kernel packs with its own tile height and scans for itself)
+        if cnt is not None and given:
+            if a.geometry != 2:       # (same backstop as PackedMLP._grouped_args: the tiled kernel needs a ZERO buffer)
+                raise RuntimeError(f"{self.name or 'PackedMLPBf16'}: a row-packing table (ws) was passed but geometry {a.geometry} "
+                                   "packs for itself; ask wants_prescan(..., feat=<the feature tensor>) before making the table")
+            a.prescanned = 1
         return a, out, keep
 
     def _launch(self, a) -> None:

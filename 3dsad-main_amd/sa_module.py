@@ -57,12 +57,16 @@ class SAModuleMSG(nn.Module):
         return fidx, ops.gather_xyz(xyz, fidx)
 
     def query(self, xyz: torch.Tensor, new_xyz: torch.Tensor, radius_pc: Optional[torch.Tensor] = None,
-              radii: Optional[Sequence[float]] = None, prescan: bool = False, cat: Optional[torch.Tensor] = None):
+              radii: Optional[Sequence[float]] = None, prescan: bool = False, cat: Optional[torch.Tensor] = None,
+              feat: Optional[torch.Tensor] = None, feat_dtype=None):
         """The stage's multi-radius ball query: ([idx_b [B,M,S_b]], [cnt_b [B,M]]) and, with ``prescan``,
         the row-packing tables of the branches as a third element.  ``cat`` (with ``prescan``): the stage's
         UNINITIALISED [B,M,sum C_b] pooling buffer — the scan prepares the slices of the branches that take a table
         (ops.rowscan_multi ``outs``), the slices of the others are zero-filled here; pass the same buffer to
-        ``group_and_pool(cat=...)``."""
+        ``group_and_pool(cat=...)``.  ``feat``: the feature tensor ``group_and_pool`` will get (its stride and alignment
+        decide which kernel runs, hence whether a table is wanted); when it does not exist yet (a caller that queries ahead
+        on another stream) leave it None and it is taken to be a fresh contiguous [B,N,C] tensor of ``feat_dtype``
+        (default: float32, or bfloat16 for a bf16 module)."""
         st = self.stage
         idxs, cnts = ops.ball_query_multi(radii if radii is not None else st.radii, st.nsamples, xyz, new_xyz,
                                           radius_pc, return_counts=True)
@@ -71,8 +75,10 @@ class SAModuleMSG(nn.Module):
             # detector overlaps), so the MLP stream launches no small latency-bound kernels before its chains;
             # only for the branches whose kernel consumes such a table (the tiled kernel packs for itself)
             B, N, M = xyz.shape[0], xyz.shape[1], new_xyz.shape[1]
+            if feat_dtype is None:
+                feat_dtype = torch.float32 if self.dtype == "f32" else torch.bfloat16
             pick = [i for i, (mlp, s) in enumerate(zip(self.branches, st.nsamples))
-                    if mlp.wants_prescan(B, N, M, s, self.cat_channels, self.in_channels)]
+                    if mlp.wants_prescan(B, N, M, s, self.cat_channels, self.in_channels, feat=feat, feat_dtype=feat_dtype)]
             wss = [None] * len(idxs)
             outs = None
             if cat is not None:
@@ -100,7 +106,7 @@ class SAModuleMSG(nn.Module):
         B, M = new_xyz.shape[0], new_xyz.shape[1]
         # (own query: with the row-packing scan behind it, as the detector's sampling stream does — the MLP dispatch is
         # then the same launches in every mode)
-        q = query if query is not None else self.query(xyz, new_xyz, radius_pc, radii, prescan=not ops.AUTOTUNE)
+        q = query if query is not None else self.query(xyz, new_xyz, radius_pc, radii, prescan=not ops.AUTOTUNE, feat=feat_pm)
         idxs, cnts = q[0], q[1]
         wss = q[2] if len(q) > 2 else [None] * len(idxs)
         if keep is not None:

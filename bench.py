@@ -4,24 +4,27 @@
     python bench.py --gpus N --steps K --warmup W        (N > 1: starts its own N ranks with torch.distributed.run)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Workload (BASELINE.json metric / configs[1..3]): per GPU a resident batch of 32 synthetic
-KITTI-shaped 16 384-point scenes -> 3-stage multi-radius SA backbone (fp32) -> size-adaptive
-cluster layer -> box/cls head -> boxes[32,256,9]; with N > 1 every rank processes its own 32 scenes
-(weak scaling) and ONE RCCL all_gather of the boxes closes each step.  A step = one such pass.
-Inputs are already in HBM when the timed region starts.
+Workload (BASELINE.json metric / configs[1..3]): per GPU resident batches of 32 synthetic KITTI-shaped
+16 384-point scenes -> 3-stage multi-radius SA backbone (fp32) -> size-adaptive cluster layer -> box/cls head
+-> boxes[32,256,9]; with N > 1 every rank processes its own scenes (weak scaling) and ONE RCCL all_gather of the
+boxes closes each step.  A step = one such pass over one batch.  Inputs are already in HBM when the timed region
+starts.  The timed region ROTATES over several distinct resident batches (``--batches``, default 4): consecutive
+steps never see the same scenes, the MLP geometry is tuned on batch 0 only, and the parity check is made on the
+LAST batch the timed region submitted.
 
 One JSON line on rank 0: the contract fields plus
-  parity_check — the boxes of the timed configuration (last timed step) against the CPU spec-oracle
-                 on the same scenes (<= 1e-4, labels exact); a failure makes the exit code non-zero;
-  roofline     — the dominant kernel (the fused gather+MLP+max / MLP launches of a step) against the
-                 dense f32 MFMA peak on EXECUTED flops, timed with HIP events on the launching stream
-                 in a non-overlapped pass (one stream, no sibling batch), so that every interval is a
-                 kernel duration; the overlapped sums of the timed region are kept as a note;
+  parity_check — the boxes of the last timed step against the CPU spec-oracle on the same scenes (<= 1e-4, labels
+                 exact); a failure makes the exit code non-zero;
+  roofline     — the dominant kernel (the fused gather+MLP+max / MLP launches of a step) against the dense MFMA
+                 peak of the dtype on EXECUTED flops, timed with HIP events on the launching stream in a
+                 non-overlapped pass (one stream, no sibling batch) and corrected for the measured cost of an empty
+                 event pair, so that every interval is a kernel duration;
   kernels      — fps / ball_query (HBM roofline on algorithmic bytes) from the same serial pass;
-  dense_leg    — the same detector with the padding skip switched off (every grouped row computed):
-                 the throughput floor on scenes whose neighbourhoods are all full;
-  cpu_baseline — this repository's CPU spec-oracle (the upstream reference ships no CPU path) on a
-                 bounded sample of the same scenes, same host: dense SPEC path and padding-skipped.
+  dense_leg    — the same detector with the padding skip switched off (every grouped row computed);
+  bf16_leg     — the same KITTI-shaped batches through the bf16 MFMA mode (SPEC.md §14);
+  configs4_leg — BASELINE.json configs[4] on its own shape: 65 536-point nuScenes-shaped scenes, bf16, 32 per batch;
+  cpu_baseline — this repository's CPU spec-oracle (the upstream reference ships no CPU path) on a bounded sample of
+                 the same scenes, same host: dense SPEC path and padding-skipped.
 Parity is against this repo's spec-oracle; the reference (README-only) ships no implementation.
 """
 import argparse
@@ -36,14 +39,19 @@ sys.path.insert(0, ROOT)
 # HIP multiplexes streams onto 4 hardware queues by default; this pipeline uses two main streams, up to eight
 # sampling streams and the gather stream, and a 3 - 16 ms FPS kernel sharing a queue with MLP launches (or with
 # another FPS chain) would serialise them (measured: six FPS chains side by side keep their single-stream time,
-# eight on 8 queues take twice as long - tools/fps_concurrency.py).  Must be set before the runtime initialises.
+# eight on 8 queues take twice as long - tools/fps_concurrency.py).  Must be set before the runtime initialises;
+# `import sad_amd` does the same for any other caller (3dsad-main_amd/_runtime.py).
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 PEAK_MFMA_F32_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: dense f32 MFMA
 PEAK_MFMA_BF16_TFLOPS = 2500.0 # same guide: dense bf16 MFMA (not the 2:1-sparsity headline)
 PEAK_HBM_GBPS = 8000.0         # HBM3E spec
 PARITY_TOL = 1e-4              # BASELINE.json north_star: fp32 boxes within 1e-4
-TRAFFIC_FILE = "r03_pmc_traffic.json"   # profiles/: HBM bytes of the MLP dispatches (rocprofv3 --pmc passes)
+# profiles/: HBM bytes of the MLP dispatches of one step (rocprofv3 --pmc passes, tools/pmc_traffic.py), per workload;
+# the first file that exists is used
+TRAFFIC_FILES = {("kitti", "f32"): ("r04_pmc_traffic.json", "r03_pmc_traffic.json"),
+                 ("kitti", "bf16"): ("r04_bf16_pmc_traffic.json",),
+                 ("nuscenes", "bf16"): ("r04_nuscenes_bf16_pmc_traffic.json",)}
 
 
 def usable_cores() -> int:
@@ -81,7 +89,7 @@ def cpu_baseline(cfg, weights, pts, repeats: int = 2):
     rec = {"value": round(scenes / best[False], 4), "unit": "scenes/s", "cores": cores,
            "kind": "port (self-authored spec-oracle: the upstream reference is a 2-line README with no CPU path)",
            "value_padding_skipped": round(scenes / best[True], 4),
-           "sample": f"{scenes} scenes of the same batch through oracle.detector_forward (C + AVX2 fmaf chains + "
+           "sample": f"{scenes} scenes of the last timed batch through oracle.detector_forward (C + AVX2 fmaf chains + "
                      f"OpenMP, {cores} threads, brute-force FPS / ball query), best of {repeats}.  `value` computes "
                      "every grouped row (dense SPEC path, ~13x the MLP rows the HIP path executes on these sparse "
                      "scenes); `value_padding_skipped` skips the ball-query padding rows exactly as the HIP kernels do "
@@ -197,129 +205,143 @@ def self_launch(cmd, env=None):
     return rc
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--batch", type=int, default=32, help="scenes per GPU per step")
-    ap.add_argument("--no-overlap", action="store_true", help="run FPS on the main stream")
-    ap.add_argument("--fps-streams", type=int, default=None,
-                    help="sampling streams used round-robin (default: 3 for f32, 6 for bf16 - the bf16 MLP "
-                         "dispatches are short enough that the serial FPS chain of a batch bounds the step otherwise)")
-    ap.add_argument("--main-streams", type=int, default=2, help="main streams used round-robin by consecutive steps")
-    ap.add_argument("--queue-depth", type=int, default=None,
-                    help="steps in flight before the host waits for the oldest (default: max(6, sampling streams + 2))")
-    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg (parity_check then uses 4 scenes)")
-    ap.add_argument("--cpu-scenes", type=int, default=32)
-    ap.add_argument("--no-launch-timing", action="store_true", help="skip the per-launch event passes (roofline / kernels)")
-    ap.add_argument("--no-dense-leg", action="store_true")
-    ap.add_argument("--no-autotune", action="store_true", help="use the built-in geometry heuristic")
-    ap.add_argument("--geometry-file", default=None,
-                    help="JSON {launch name: geometry code} from --save-geometry: no autotune launches (rocprof runs)")
-    ap.add_argument("--save-geometry", default=None, help="write the geometry in use to this JSON file")
-    ap.add_argument("--config", choices=("kitti", "nuscenes"), default="kitti",
-                    help="nuscenes = BASELINE configs[4] shape (65536-pt scenes, 4 extra channels); secondary, "
-                         "use with --dtype bf16 --batch 8 --no-cpu; the headline metric is the kitti default")
-    ap.add_argument("--scene", choices=("kitti", "dense"), default="kitti",
-                    help="dense = the same 16384 points on 20 m x 20 m (most neighbourhoods full): the dense-occupancy "
-                         "floor of the same kernels; secondary, the headline is the KITTI-shaped default")
-    ap.add_argument("--dtype", choices=("f32", "bf16"), default="f32",
-                    help="bf16 = SPEC.md 14 mode (configs[4]): MLPs on the bf16 matrix cores, dense rows; "
-                         "the headline metric is the f32 default")
-    ap.add_argument("--opt", action="append", default=[], help="tuning knob key=value (sad_set_option)")
-    args = ap.parse_args()
-    if args.fps_streams is None:      # the serial FPS chain of a batch (2.9 ms KITTI, 15.6 ms nuScenes) must not bound the step
-        # (f32, 16 hardware queues: 13.55 / 13.89 / 12.90 k scenes/s with 2 / 3 / 4 sampling streams, tools/probe/ab_fps_streams.sh)
-        # bf16 nuScenes (tools/probe/nus_sweep.sh): 32 scenes per batch 3.7 / 4.6 / 5.1 / 5.2 k scenes/s with 3 / 4 / 5 / 6 streams; the
-        # record-streaming FPS slows down as more scenes are in flight (their 1 MB record arrays share the L2)
-        args.fps_streams = 3 if args.dtype == "f32" else 6
-    if args.queue_depth is None:
-        args.queue_depth = max(6, args.fps_streams + 2)
+def default_fps_streams(dtype: str) -> int:
+    """The serial FPS chain of a batch (2.9 ms KITTI, 15.6 ms nuScenes) must not bound the step.
+    f32, 16 hardware queues: 13.55 / 13.89 / 12.90 k scenes/s with 2 / 3 / 4 sampling streams (tools/probe/ab_fps_streams.sh);
+    bf16 nuScenes (tools/probe/nus_sweep.sh): 32 scenes per batch 3.7 / 4.6 / 5.1 / 5.2 k scenes/s with 3 / 4 / 5 / 6 streams."""
+    return 3 if dtype == "f32" else 6
 
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        # `python bench.py --gpus N` as the driver runs it: start the N ranks ourselves (as a child process, before
-        # anything here has imported torch or touched the GPU), relay rank 0's line and exit with the child's code
-        raise SystemExit(self_launch(launch_command(sys.argv[1:], args.gpus, free_port())))
 
+def batch_first_scene(k: int, rank: int, world: int, B: int) -> int:
+    """First scene id of resident batch k on this rank: batches of different ranks and rotation slots never share a scene."""
+    return (k * world + rank) * B
+
+
+class Workload:
+    """What one measurement runs: topology, scene generator, arithmetic, batch size and stream plan."""
+
+    def __init__(self, config: str, scene: str, dtype: str, batch: int, fps_streams=None, main_streams: int = 2,
+                 queue_depth=None, n_batches: int = 4, overlap: bool = True):
+        self.config, self.scene, self.dtype, self.B = config, scene, dtype, batch
+        self.fps_streams = default_fps_streams(dtype) if fps_streams is None else fps_streams
+        self.main_streams = main_streams
+        self.queue_depth = max(6, self.fps_streams + 2) if queue_depth is None else queue_depth
+        self.n_batches = max(1, n_batches)
+        self.overlap = overlap
+
+    def cfg(self):
+        from sad_amd import config
+        return config.KITTI if self.config == "kitti" else config.NUSCENES
+
+    def maker(self):
+        from sad_amd import synth
+        if self.config == "nuscenes":
+            return synth.make_nuscenes_batch
+        return synth.make_batch if self.scene == "kitti" else synth.make_dense_batch
+
+    def peak(self):
+        return PEAK_MFMA_F32_TFLOPS if self.dtype == "f32" else PEAK_MFMA_BF16_TFLOPS
+
+    def describe(self):
+        cfg = self.cfg()
+        return (f"{'configs[1-2]' if self.config == 'kitti' else 'configs[4]'}: batch {self.B} x {cfg.n_points}-pt "
+                f"{'KITTI' if self.config == 'kitti' else 'nuScenes'}-shaped scenes per GPU"
+                f"{' (DENSE variant: 20 m x 20 m extents)' if self.scene == 'dense' else ''}, "
+                f"3-stage multi-radius SA backbone {'fp32' if self.dtype == 'f32' else 'bf16 (SPEC 14)'} + size-adaptive cluster layer + box head; "
+                f"{self.n_batches} distinct resident batches in rotation")
+
+
+def event_overhead_ms(stream, n: int = 31) -> float:
+    """What an EMPTY pair of timing events measures on this stream (median of n): every per-launch interval of the serial
+    pass contains it once.  On 14 - 130 us bf16 dispatches it was 17 % of the summed intervals (round 3: 0.1205 by events
+    against 0.1416 from the rocprofv3 trace of the same launches)."""
+    import torch
+    stream.synchronize()
+    vals = []
+    for _ in range(n):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        e1.record(stream)
+        stream.synchronize()
+        vals.append(e0.elapsed_time(e1))
+    vals.sort()
+    return vals[len(vals) // 2]
+
+
+_STREAMS = {}
+
+
+def shared_streams(dev, n_side: int, n_main: int):
+    """ONE set of sampling / main streams (and one gather stream) for every detector this process builds: each stream
+    ever created keeps a place among the GPU_MAX_HW_QUEUES hardware queues, and the three detectors of a default run
+    would otherwise create 24 (the last one then ran its FPS chains two to a queue: 3.1 k instead of 5.4 k scenes/s)."""
+    import torch
+    from sad_amd.dist import AsyncBoxGather
+    st = _STREAMS.setdefault(str(dev), {"side": [], "main": [], "gather": None})
+    while len(st["side"]) < n_side:
+        st["side"].append(torch.cuda.Stream(device=dev))
+    while len(st["main"]) < n_main:
+        st["main"].append(torch.cuda.Stream(device=dev))
+    if st["gather"] is None:
+        st["gather"] = AsyncBoxGather(dev)
+    return (st["side"][:n_side], st["main"][:n_main]), st["gather"]
+
+
+def measure(w: Workload, steps: int, warmup: int, rank: int, world: int, dev, args, detail: bool):
+    """Build the detector of workload ``w``, run ``warmup`` untimed and exactly ``steps`` timed steps between device
+    synchronisations (and barriers for world > 1), then the per-launch passes.  Returns (record, exit code, context) on
+    rank 0 and (None, 0, None) on the others.  ``detail``: the headline record (every field); otherwise a leg record
+    (value, ms/step, MLP roofline, FPS / ball-query ms)."""
+    import gc
+    from collections import deque
     import numpy as np
     import torch
     import torch.distributed as dist
-    import sad_amd  # noqa: F401
-    from sad_amd import config, ops, synth
+    from sad_amd import _lib, config, ops, synth
     from sad_amd.detector import SADDetector
-    from sad_amd.dist import AsyncBoxGather
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch `python bench.py --gpus N` (it starts its own "
-                         "ranks) or torch.distributed.run with --nproc-per-node N")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the HIP path is the only path (no CPU fallback)")
-    if os.environ.get("SAD_BENCH_ONE_DEVICE"):      # rehearsal of the N>1 path on a one-GPU box
-        local_rank = 0
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    backend = None
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        backend = os.environ.get("SAD_BENCH_BACKEND", "nccl")       # "nccl" is RCCL on ROCm
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:                                                        # rehearsal on a one-GPU box
-            dist.init_process_group(backend)
-
-    from sad_amd import _lib
-    for kv in args.opt:
-        k, v = kv.split("=")
-        _lib.set_option(k, int(v))
-    cfg = config.KITTI if args.config == "kitti" else config.NUSCENES
+    cfg = w.cfg()
+    B = w.B
     weights = synth.make_weights(cfg, 0)
-    det = SADDetector(cfg, weights, dev, overlap_fps=not args.no_overlap, n_fps_streams=args.fps_streams,
-                      n_main_streams=args.main_streams, dtype=args.dtype)
-    PEAK = PEAK_MFMA_F32_TFLOPS if args.dtype == "f32" else PEAK_MFMA_BF16_TFLOPS
-    gather = AsyncBoxGather(dev)       # the step's one collective, off the compute streams
-    B = args.batch
-    if args.config == "nuscenes":
-        make = synth.make_nuscenes_batch
-    else:
-        make = synth.make_batch if args.scene == "kitti" else synth.make_dense_batch
-    points_np = make(rank * B, B, cfg.n_points)
-    points = torch.from_numpy(points_np).to(dev)
+    streams, gather = shared_streams(dev, w.fps_streams if w.overlap else 0, w.main_streams)   # (gather: the step's one collective, off the compute streams)
+    det = SADDetector(cfg, weights, dev, overlap_fps=w.overlap, n_fps_streams=w.fps_streams,
+                      n_main_streams=w.main_streams, dtype=w.dtype, streams=streams)
+    PEAK = w.peak()
+    make = w.maker()
+    batches_np = [make(batch_first_scene(k, rank, world, B), B, cfg.n_points) for k in range(w.n_batches)]
+    batches = [torch.from_numpy(p).to(dev) for p in batches_np]
     torch.cuda.synchronize()
 
-    if os.environ.get("SAD_NO_MERGE_BF16"):
-        ops.MERGE_BF16 = False
-    if args.geometry_file:
+    if args.geometry_file and detail:
         det.set_geometry(json.load(open(args.geometry_file)))
         tuned = det.geometry()
         geometry_source = f"file:{os.path.basename(args.geometry_file)}"
     elif args.no_autotune:
         tuned, geometry_source = {}, "heuristic"
     else:
-        tuned, geometry_source = det.autotune(points), "autotuned on this batch"
-    if args.save_geometry and rank == 0:
+        tuned, geometry_source = det.autotune(batches[0]), "autotuned on batch 0 of the rotation"
+    if args.save_geometry and rank == 0 and detail:
         json.dump(tuned, open(args.save_geometry, "w"), indent=1, sort_keys=True)
     geom_hash = hashlib.sha256(json.dumps(tuned, sort_keys=True).encode()).hexdigest()[:12]
 
     # Bounded run-ahead: the host enqueues a step in ~0.5 ms, the GPU needs ~2.4 ms, so an unbounded loop queues
     # hundreds of steps whose workspaces (~0.3 GB each) cannot be recycled until they have run — the caching
     # allocator then grows until it has to free and re-allocate, which stalls the device for 0.4-0.6 s (measured).
-    # A serving loop bounds its queue the same way: at most `--queue-depth` steps in flight.
-    from collections import deque
+    # A serving loop bounds its queue the same way: at most `queue_depth` steps in flight.
     inflight = deque()
+    submitted = [0]
 
     def step():
-        if len(inflight) >= args.queue_depth:
+        if len(inflight) >= w.queue_depth:
             inflight.popleft().synchronize()
-        out, ev = det.submit(points, post=gather)
+        k = submitted[0] % len(batches)
+        submitted[0] += 1
+        out, ev = det.submit(batches[k], post=gather)
         inflight.append(ev)
-        return out, ev
+        return out, k
 
-    for _ in range(args.warmup):
-        out, _ = step()
+    for _ in range(warmup):
+        step()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -327,15 +349,15 @@ def main():
     # The timed region carries no per-launch events (creating ~40 timing events per sampled step stalled the
     # queue for 15-30 ms once per run: measured); per-launch intervals under overlap are sampled in a few extra
     # steps AFTER the timed region, the roofline figures come from the serial pass further down.
-    step_marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]   # one per step, created up front
+    step_marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]   # one per step, created up front
     # (no cyclic-GC passes of the interpreter inside the timed region: the 1 ms steps of the bf16 mode empty an eight-deep queue
     # during one multi-millisecond pause of the enqueuing thread; one evidence run showed 14 of 200 steps stalled ~5 ms)
-    import gc
     gc.collect()
     gc.disable()
+    out, last = None, 0
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        out, _ = step()
+    for i in range(steps):
+        out, last = step()
         step_marks[i].record(det.last_stream)
     torch.cuda.synchronize()
     if world > 1:
@@ -343,9 +365,13 @@ def main():
         torch.cuda.synchronize()
     elapsed_local = time.perf_counter() - t0
     gc.enable()
+    assert out.shape == (world * B, cfg.n_cand, 9) and bool(torch.isfinite(out).all())
+    got_boxes = out[:B].cpu().numpy()          # rank 0's own scenes come first in the gathered tensor; batch `last`
+    points, points_np = batches[last], batches_np[last]
+
     log = None if args.no_launch_timing else []
     timed_steps = 0
-    if log is not None:
+    if log is not None and detail:
         for i in range(16):
             sample = i % 4 == 2
             ops.LAUNCH_LOG = log if sample else None
@@ -353,16 +379,15 @@ def main():
             step()
             ops.LAUNCH_LOG = None
         torch.cuda.synchronize()
-        inflight.clear()
+    inflight.clear()
     elapsed = elapsed_local
-    assert out.shape == (world * B, cfg.n_cand, 9) and bool(torch.isfinite(out).all())
     rank_info = None
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
         # per-rank view (who is the straggler, which device, which geometry): one small all_gather
-        mine = torch.tensor([B * args.steps / elapsed_local, float(torch.cuda.current_device()),
+        mine = torch.tensor([B * steps / elapsed_local, float(torch.cuda.current_device()),
                              float(int(geom_hash[:6], 16))], dtype=torch.float64, device=dev)
         allr = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allr, mine)
@@ -376,171 +401,184 @@ def main():
                      "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
                      "note": "each rank autotunes its own geometry (same kernels, same bits; picks may differ "
                              "by a few per cent in speed); elapsed is the MAX over ranks between two barriers"}
+    if rank != 0:
+        return None, 0, None
 
     rc = 0
-    if rank == 0:
-        work = config.work_per_scene(cfg)
-        steps = args.steps
-        # completion-to-completion intervals of consecutive steps (steps alternate between the main
-        # streams; an interval between steps on different streams can be ~0 or ~2 steps: use pairs)
-        nm = max(1, args.main_streams)
-        gaps = [step_marks[i].elapsed_time(step_marks[i + nm]) / nm for i in range(0, len(step_marks) - nm)]
-        slow_at = [i for i, g in enumerate(gaps) if g > 2 * sorted(gaps)[len(gaps) // 2]]
-        gaps.sort()
-        res = {
-            "metric": ("scenes/sec (16384-pt KITTI-shaped) through SA+cluster path" if args.config == "kitti" else
-                       "scenes/sec (65536-pt nuScenes-shaped, configs[4]) through SA+cluster path"),
-            "value": round(world * B * steps / elapsed, 2),
-            "unit": "scenes/s",
-            "n_gpus": world, "steps": steps, "warmup": args.warmup,
-            "ms_per_step": round(1e3 * elapsed / steps, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"{'configs[1-2]' if args.config == 'kitti' else 'configs[4]'}: batch {B} x {cfg.n_points}-pt "
-                                   f"{'KITTI' if args.config == 'kitti' else 'nuScenes'}-shaped scenes per GPU"
-                                   f"{' (DENSE variant: 20 m x 20 m extents)' if args.scene == 'dense' else ''}, "
-                                   f"3-stage multi-radius SA backbone {'fp32' if args.dtype == 'f32' else 'bf16 (SPEC 14)'} + size-adaptive cluster layer + box head",
-                       "scenes_per_gpu": B, "global_batch": world * B, "n_points": cfg.n_points, "scene": args.scene,
-                       "parallelism": f"batch-sharded x{world}, one all_gather of boxes",
-                       "fps_overlap": not args.no_overlap, "fps_streams": args.fps_streams, "main_streams": args.main_streams, "opts": args.opt,
-                       "queue_depth": args.queue_depth,
-                       "mlp_geometry": tuned if tuned else "heuristic", "mlp_geometry_source": geometry_source,
-                       "mlp_geometry_hash": geom_hash},
-        }
-        if gaps:
-            res["step_ms"] = {"p50": round(gaps[len(gaps) // 2], 3), "min": round(gaps[0], 3), "p99": round(gaps[(len(gaps) * 99) // 100], 3),
-                              "max": round(gaps[-1], 3), "over_2x_p50": sum(1 for g in gaps if g > 2 * gaps[len(gaps) // 2]), "over_2x_p50_at_steps": slow_at[:8],
-                              "note": f"completion-to-completion over {nm} consecutive steps / {nm} (HIP events on the main streams)"}
-        if rank_info is not None:
-            res["ranks"] = rank_info
-        elif world == 1:
-            res["ranks"] = {"backend": None, "ranks_seen": 1, "note": "N = 1: no process group, no collective; "
-                            "the RCCL path (N > 1) is unmeasured until the driver has a multi-GPU node"}
-        got_boxes = out[:B].cpu().numpy()          # rank 0's own scenes come first in the gathered tensor
+    work = config.work_per_scene(cfg)
+    # completion-to-completion intervals of consecutive steps (steps alternate between the main
+    # streams; an interval between steps on different streams can be ~0 or ~2 steps: use pairs)
+    nm = max(1, w.main_streams)
+    gaps = [step_marks[i].elapsed_time(step_marks[i + nm]) / nm for i in range(0, len(step_marks) - nm)]
+    slow_at = [i for i, g in enumerate(gaps) if g > 2 * sorted(gaps)[len(gaps) // 2]]
+    gaps.sort()
+    res = {
+        "metric": ("scenes/sec (16384-pt KITTI-shaped) through SA+cluster path" if w.config == "kitti" else
+                   "scenes/sec (65536-pt nuScenes-shaped, configs[4]) through SA+cluster path"),
+        "value": round(world * B * steps / elapsed, 2),
+        "unit": "scenes/s",
+        "n_gpus": world, "steps": steps, "warmup": warmup,
+        "ms_per_step": round(1e3 * elapsed / steps, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": w.dtype, "data": "synthetic",
+        "config": {"workload": w.describe(),
+                   "scenes_per_gpu": B, "global_batch": world * B, "n_points": cfg.n_points, "scene": w.scene,
+                   "resident_batches": len(batches), "parity_batch": last,
+                   "parallelism": f"batch-sharded x{world}, one all_gather of boxes",
+                   "fps_overlap": w.overlap, "fps_streams": w.fps_streams, "main_streams": w.main_streams, "opts": args.opt,
+                   "queue_depth": w.queue_depth,
+                   "mlp_geometry": tuned if tuned else "heuristic", "mlp_geometry_source": geometry_source,
+                   "mlp_geometry_hash": geom_hash},
+    }
+    if gaps:
+        res["step_ms"] = {"p50": round(gaps[len(gaps) // 2], 3), "min": round(gaps[0], 3), "p99": round(gaps[(len(gaps) * 99) // 100], 3),
+                          "max": round(gaps[-1], 3), "over_2x_p50": sum(1 for g in gaps if g > 2 * gaps[len(gaps) // 2]), "over_2x_p50_at_steps": slow_at[:8],
+                          "note": f"completion-to-completion over {nm} consecutive steps / {nm} (HIP events on the main streams)"}
+    if rank_info is not None:
+        res["ranks"] = rank_info
+    elif world == 1 and detail:
+        res["ranks"] = {"backend": None, "ranks_seen": 1, "note": "N = 1: no process group, no collective; "
+                        "the RCCL path (N > 1) is unmeasured until the driver has a multi-GPU node"}
 
-        if log:
-            tsteps = max(1, timed_steps)
-            per_kind, per_name = {}, {}
-            for kind, name, e0, e1 in log:
-                ms = e0.elapsed_time(e1)
-                per_kind[kind] = per_kind.get(kind, 0.0) + ms
-                per_name[(kind, name)] = per_name.get((kind, name), 0.0) + ms
-            exec_flops, row_frac, per_flops = executed_flops(det, points, cfg, dense=(args.dtype == "bf16" and False))
-            n_mlp = sum(1 for k, _, _, _ in log if k == "mlp") // tsteps
-            # ---- serial pass: ONE stream, sampling not overlapped, no sibling batch: every event
-            # interval is the duration of that launch's kernels (plus sub-microsecond packet gaps)
-            # (a pass is synchronised before the next starts and the per-launch MEDIAN over the passes is
-            # used: an interval also contains any time the stream waited for the host, e.g. one allocator miss)
-            NSER = 7
-            det.overlap_fps, ov = False, det.overlap_fps
-            passes = []
-            try:
+    if log is not None:
+        tsteps = max(1, timed_steps)
+        per_kind, per_name = {}, {}
+        for kind, name, e0, e1 in log:
+            ms = e0.elapsed_time(e1)
+            per_kind[kind] = per_kind.get(kind, 0.0) + ms
+            per_name[(kind, name)] = per_name.get((kind, name), 0.0) + ms
+        exec_flops, row_frac, per_flops = executed_flops(det, points, cfg)
+        # ---- serial pass: ONE stream, sampling not overlapped, no sibling batch: every event
+        # interval is the duration of that launch's kernels (plus the cost of the event pair itself, measured and
+        # subtracted) (a pass is synchronised before the next starts and the per-launch MEDIAN over the passes is
+        # used: an interval also contains any time the stream waited for the host, e.g. one allocator miss)
+        NSER = 7
+        det.overlap_fps, ov = False, det.overlap_fps
+        passes = []
+        try:
+            det(points)
+            torch.cuda.synchronize()
+            for _ in range(NSER):
+                ops.LAUNCH_LOG = []
                 det(points)
                 torch.cuda.synchronize()
-                for _ in range(NSER):
-                    ops.LAUNCH_LOG = []
-                    det(points)
-                    torch.cuda.synchronize()
-                    passes.append(ops.LAUNCH_LOG)
-                    ops.LAUNCH_LOG = None
+                passes.append(ops.LAUNCH_LOG)
+                ops.LAUNCH_LOG = None
+        finally:
+            det.overlap_fps = ov
+            ops.LAUNCH_LOG = None
+        ev_ms = event_overhead_ms(torch.cuda.current_stream())
+        ser_log = passes[0]
+        n_mlp = sum(1 for k, _, _, _ in ser_log if k == "mlp")
+        ser_kind, ser_name, raw_kind = {}, {}, {}
+        for li, (k, n, _, _) in enumerate(ser_log):
+            raw = sorted(p[li][2].elapsed_time(p[li][3]) for p in passes)[NSER // 2]
+            ms = max(0.0, raw - ev_ms)
+            raw_kind[k] = raw_kind.get(k, 0.0) + raw
+            ser_kind[k] = ser_kind.get(k, 0.0) + ms
+            ser_name[(k, n)] = ser_name.get((k, n), 0.0) + ms
+        mlp_ms = ser_kind.get("mlp", 0.0)
+        ach = exec_flops / (mlp_ms * 1e-3) / 1e12 if mlp_ms > 0 else 0.0
+        traffic, traffic_file = None, None
+        if w.scene == "kitti":
+            for fn in TRAFFIC_FILES.get((w.config, w.dtype), ()):
+                tpath = os.path.join(ROOT, "profiles", fn)
+                if os.path.exists(tpath):
+                    # HBM bytes of the same launches from the committed rocprofv3 --pmc passes (bench.py cannot
+                    # collect PMC counters itself): corrected FETCH_SIZE + WRITE_SIZE, per step like `achieved`
+                    tj = json.load(open(tpath))
+                    traffic, traffic_file = tj["fetch_bytes_per_step"] + tj["write_bytes_per_step"], fn
+                    break
+        ov_ms = per_kind.get("mlp", 0.0) / tsteps
+        kname = ("mlp_reg / mlp_coop / mlp_layer / mlp_rows / mlp_chain kernels" if w.dtype == "f32"
+                 else "mlp_bf16_reg / bf16_rows / mlp_bf16 kernels")
+        res["roofline"] = {
+            "kernel": f"{kname} ({n_mlp} dispatches per step, summed)",
+            "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK,
+            "unit": "TFLOP/s", "frac": round(ach / PEAK, 4), "traffic": traffic,
+            "traffic_note": (f"HBM bytes per step of the step's MLP dispatches from profiles/{traffic_file} (rocprofv3 --pmc, "
+                             "FETCH_SIZE and WRITE_SIZE in separate passes, gfx950 corrections of MI355X_MICROARCH.md); "
+                             "the kernels are MFMA-bound, not HBM-bound") if traffic else None,
+            "flop_per_step": exec_flops, "ms_per_step": round(mlp_ms, 4),
+            "ms_per_step_uncorrected": round(raw_kind.get("mlp", 0.0), 4), "event_pair_ms": round(ev_ms, 5),
+            "note": "achieved = flops the kernels EXECUTE per step / the summed duration of the step's MLP dispatches, "
+                    "HIP events on the launching stream in a serial pass (one stream, nothing overlapped) on the batch the parity "
+                    f"check uses, per-dispatch median of {NSER} passes right after the timed region, minus the measured interval of an "
+                    "EMPTY event pair per dispatch (what the pair itself costs; `ms_per_step_uncorrected` keeps the raw sum).  Grouped rows "
+                    "that only repeat a group's first neighbour (ball-query padding) are skipped exactly (a duplicate row cannot change "
+                    "the max-pool), so executed flops < SPEC-dense flops; tools/roofline_from_profiles.py recomputes the same fraction "
+                    "from the committed rocprofv3 kernel trace",
+            "executed_row_fraction": round(row_frac, 4), "spec_dense_flop_per_step": work["mlp_flops"] * B}
+        if detail:
+            res["roofline"]["under_overlap"] = {
+                "ms_per_step_summed": round(ov_ms, 3), "sampled_steps": tsteps,
+                "note": "the same launches in extra steps run exactly like the timed region (two main streams run "
+                        "consecutive batches side by side): intervals stretch (kernels share the chip) and their "
+                        "sum may exceed ms_per_step; not a kernel-quality figure"}
+        # ---- the same dispatches back to back (f32): in the serial pass every step begins with ~3 ms of FPS on 32 of
+        # 256 CUs, the chip clocks down meanwhile and the MLP launches behind it run several % slower than the
+        # same launches at the clock the timed region holds (tools/insitu_probe.py) — so each dispatch of one
+        # serial step is enqueued again, 1 + 5 times in a row, and timed with one pair of events
+        if w.dtype == "f32" and detail:
+            det.overlap_fps, ov = False, det.overlap_fps
+            try:
+                ops.RERUN_LOG = []
+                det(points)
+                torch.cuda.synchronize()
+                reruns, ops.RERUN_LOG = ops.RERUN_LOG, None
             finally:
                 det.overlap_fps = ov
-                ops.LAUNCH_LOG = None
-            ser_log = passes[0]
-            ser_kind, ser_name = {}, {}
-            for li, (k, n, _, _) in enumerate(ser_log):
-                ms = sorted(p[li][2].elapsed_time(p[li][3]) for p in passes)[NSER // 2]
-                ser_kind[k] = ser_kind.get(k, 0.0) + ms
-                ser_name[(k, n)] = ser_name.get((k, n), 0.0) + ms
-            mlp_ms = ser_kind.get("mlp", 0.0)
-            ach = exec_flops / (mlp_ms * 1e-3) / 1e12 if mlp_ms > 0 else 0.0
-            traffic = None
-            tpath = os.path.join(ROOT, "profiles", TRAFFIC_FILE)
-            if args.dtype == "f32" and args.config == "kitti" and args.scene == "kitti" and os.path.exists(tpath):
-                # HBM bytes of the same launches from the committed rocprofv3 --pmc passes (bench.py cannot
-                # collect PMC counters itself): corrected FETCH_SIZE + WRITE_SIZE, per step like `achieved`
-                tj = json.load(open(tpath))
-                traffic = tj["fetch_bytes_per_step"] + tj["write_bytes_per_step"]
-            ov_ms = per_kind.get("mlp", 0.0) / tsteps
-            res["roofline"] = {
-                "kernel": f"{'mlp_chain / mlp_multi kernels' if args.dtype == 'f32' else 'mlp_bf16_kernel'} ({n_mlp} launches per step, summed)",
-                "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK,
-                "unit": "TFLOP/s", "frac": round(ach / PEAK, 4), "traffic": traffic,
-                "traffic_note": f"HBM bytes per step of the step's MLP dispatches from profiles/{TRAFFIC_FILE} (rocprofv3 --pmc, "
-                                "FETCH_SIZE and WRITE_SIZE in separate passes, gfx950 corrections of MI355X_MICROARCH.md); "
-                                "the kernel is MFMA-bound, not HBM-bound" if traffic else None,
-                "flop_per_step": exec_flops, "ms_per_step": round(mlp_ms, 3),
-                "note": "achieved = flops the kernels EXECUTE per step / the summed duration of the step's MLP launches, "
-                        "HIP events on the launching stream in a serial pass (one stream, nothing overlapped), per-launch median of "
-                        f"{NSER} passes right after the timed region.  Grouped rows that only repeat a group's first neighbour "
-                        "(ball-query padding) are skipped exactly (a duplicate row cannot change the max-pool), so executed "
-                        "flops < SPEC-dense flops; tools/roofline_from_profiles.py recomputes the same fraction from the "
-                        "committed rocprofv3 kernel trace",
-                "executed_row_fraction": round(row_frac, 4), "spec_dense_flop_per_step": work["mlp_flops"] * B,
-                "under_overlap": {"ms_per_step_summed": round(ov_ms, 3), "sampled_steps": tsteps,
-                                  "note": "the same launches in extra steps run exactly like the timed region (two main streams run "
-                                          "consecutive batches side by side): intervals stretch (kernels share the chip) and their "
-                                          "sum may exceed ms_per_step; not a kernel-quality figure"}}
-            # ---- the same dispatches back to back (f32): in the serial pass every step begins with ~3 ms of FPS on 32 of
-            # 256 CUs, the chip clocks down meanwhile and the MLP launches behind it run several % slower than the
-            # same launches at the clock the timed region holds (tools/insitu_probe.py) — so each dispatch of one
-            # serial step is enqueued again, 1 + 5 times in a row, and timed with one pair of events
-            if args.dtype == "f32":
-                det.overlap_fps, ov = False, det.overlap_fps
-                try:
-                    ops.RERUN_LOG = []
-                    det(points)
-                    torch.cuda.synchronize()
-                    reruns, ops.RERUN_LOG = ops.RERUN_LOG, None
-                finally:
-                    det.overlap_fps = ov
-                    ops.RERUN_LOG = None
-                steady = {}
-                cur = torch.cuda.current_stream()
-                for name, fn in reruns:
+                ops.RERUN_LOG = None
+            steady = {}
+            cur = torch.cuda.current_stream()
+            for name, fn in reruns:
+                fn()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(cur)
+                for _ in range(5):
                     fn()
-                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    e0.record(cur)
-                    for _ in range(5):
-                        fn()
-                    e1.record(cur)
-                    torch.cuda.synchronize()
-                    steady[name] = steady.get(name, 0.0) + e0.elapsed_time(e1) / 5
-                del reruns
-                st_ms = sum(steady.values())
-                res["roofline"]["steady_clock"] = {
-                    "ms_per_step": round(st_ms, 3), "achieved": round(exec_flops / (st_ms * 1e-3) / 1e12, 2),
-                    "frac": round(exec_flops / (st_ms * 1e-3) / 1e12 / PEAK, 4),
-                    "per_launch_ms": {n: round(v, 4) for n, v in sorted(steady.items())},
-                    "note": "the same dispatches (same arguments, from one more serial step), each enqueued 5 times in a row: "
-                            "durations at the clock a continuously busy chip holds.  In the serial pass above every step starts with "
-                            "~3 ms of FPS on 32 CUs and the MLP launches behind it run at a lower clock; the timed region (two "
-                            "main streams, FPS overlapped) is continuously busy.  `frac` above stays the in-step figure"}
-            kern = []
-            fps_ms = ser_kind.get("fps", 0.0)
-            if fps_ms > 0:
-                nested = getattr(det, "nested_fps_shortcut", True)
-                serial = cfg.stages[0].npoint if nested else work["fps_steps"]
-                kern.append({"kernel": "fps_sort_kernel + fps_cell_kernel ("
-                                       + ("stage 1 only: stages 2-3 reuse its prefix, proven identical)" if nested else "3 stages)"),
-                             "ms_per_step": round(fps_ms, 3),
-                             "updates_per_s": round(work["fps_updates"] * B / (fps_ms * 1e-3) / 1e9, 2),
-                             "unit": "G distance-updates/s (plain-scan equivalent; most are skipped exactly)",
-                             "serial_steps": serial,
-                             "us_per_serial_step": round(1e3 * fps_ms / serial, 3),
-                             "bound": "serial latency (neither HBM nor MFMA); in the timed region it runs on sampling streams under the MLP kernels"})
-            bq_ms = ser_kind.get("ball_query", 0.0)
-            if bq_ms > 0:
-                gbps = work["ball_query_bytes"] * B / (bq_ms * 1e-3) / 1e9
-                kern.append({"kernel": "ball query: grid_build/grid_query (SA1, SA2) + ball_query_kernel scan (SA3, adaptive cluster query)",
-                             "ms_per_step": round(bq_ms, 3),
-                             "per_launch_ms": {n: round(v, 4) for (k, n), v in sorted(ser_name.items()) if k == "ball_query"},
-                             "bound": "hbm", "achieved": round(gbps, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
-                             "frac": round(gbps / PEAK_HBM_GBPS, 5), "algorithmic_bytes_per_step": work["ball_query_bytes"] * B,
-                             "pair_tests_per_s": round(work["pair_tests"] * B / (bq_ms * 1e-3) / 1e12, 3),
-                             "note": "serial pass, HIP events per launch.  BASELINE's >= 70 % of HBM peak is not reachable: the "
-                                     "PMC traffic equals the algorithmic bytes (nothing is re-read), the kernels are bound by the "
-                                     "latency of the per-centroid dependent instruction chain (LDS bitmap restore of index order), not by bytes"})
+                e1.record(cur)
+                torch.cuda.synchronize()
+                steady[name] = steady.get(name, 0.0) + e0.elapsed_time(e1) / 5
+            del reruns
+            st_ms = sum(steady.values())
+            res["roofline"]["steady_clock"] = {
+                "ms_per_step": round(st_ms, 3), "achieved": round(exec_flops / (st_ms * 1e-3) / 1e12, 2),
+                "frac": round(exec_flops / (st_ms * 1e-3) / 1e12 / PEAK, 4),
+                "per_launch_ms": {n: round(v, 4) for n, v in sorted(steady.items())},
+                "note": "the same dispatches (same arguments, from one more serial step), each enqueued 5 times in a row: "
+                        "durations at the clock a continuously busy chip holds.  In the serial pass above every step starts with "
+                        "~3 ms of FPS on 32 CUs and the MLP launches behind it run at a lower clock; the timed region (two "
+                        "main streams, FPS overlapped) is continuously busy.  `frac` above stays the in-step figure"}
+        kern = []
+        fps_ms = ser_kind.get("fps", 0.0)
+        if fps_ms > 0:
+            nested = getattr(det, "nested_fps_shortcut", True)
+            serial = cfg.stages[0].npoint if nested else work["fps_steps"]
+            kern.append({"kernel": "fps_sort_kernel + fps_cell_kernel / fps_cellg_kernel ("
+                                   + ("stage 1 only: stages 2-3 reuse its prefix, proven identical)" if nested else "3 stages)"),
+                         "ms_per_step": round(fps_ms, 3),
+                         "cu_ms_per_step": round(fps_ms * B, 1),
+                         "updates_per_s": round(work["fps_updates"] * B / (fps_ms * 1e-3) / 1e9, 2),
+                         "unit": "G distance-updates/s (plain-scan equivalent; most are skipped exactly)",
+                         "serial_steps": serial,
+                         "us_per_serial_step": round(1e3 * fps_ms / serial, 3),
+                         "bound": "serial latency (neither HBM nor MFMA); one workgroup (one CU) per scene: cu_ms_per_step = CUs held x ms; "
+                                  "in the timed region it runs on sampling streams under the MLP kernels"})
+        bq_ms = ser_kind.get("ball_query", 0.0)
+        if bq_ms > 0:
+            gbps = work["ball_query_bytes"] * B / (bq_ms * 1e-3) / 1e9
+            kern.append({"kernel": "ball query: grid_build/grid_query (SA1, SA2) + ball_query_kernel scan (SA3, adaptive cluster query)",
+                         "ms_per_step": round(bq_ms, 3),
+                         "per_launch_ms": {n: round(v, 4) for (k, n), v in sorted(ser_name.items()) if k == "ball_query"},
+                         "bound": "hbm", "achieved": round(gbps, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+                         "frac": round(gbps / PEAK_HBM_GBPS, 5), "algorithmic_bytes_per_step": work["ball_query_bytes"] * B,
+                         "pair_tests_per_s": round(work["pair_tests"] * B / (bq_ms * 1e-3) / 1e12, 3),
+                         "note": "serial pass, HIP events per launch.  BASELINE's >= 70 % of HBM peak is not reachable: the "
+                                 "PMC traffic equals the algorithmic bytes (nothing is re-read), the kernels are bound by the "
+                                 "per-centroid instruction chain that restores index order (~300 vector instructions for ~20 "
+                                 "candidates), not by bytes"})
+        if detail:
             # the unfused group_points operator (not on the fused path; part of the drop-in surface):
             # an HBM-bound gather, timed here on the SA2 branch shape with its own HIP events
             gC, gN, gM, gS = 64, 4096, 1024, 32
@@ -561,53 +599,192 @@ def main():
                          "achieved": round(g_bytes / (g_ms * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
                          "frac": round(g_bytes / (g_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4),
                          "algorithmic_bytes": g_bytes})
-            res["kernels"] = kern
-            res["mlp_launches"] = {n: {"ms": round(v, 4), "executed_gflop": round(flops_of(n, per_flops) / 1e9, 2),
-                                       "tflops": round(flops_of(n, per_flops) / (v * 1e-3) / 1e12, 1) if v > 0 else None,
-                                       "frac": round(flops_of(n, per_flops) / (v * 1e-3) / 1e12 / PEAK, 3) if v > 0 else None,
-                                       "ms_under_overlap": round(per_name.get(("mlp", n), 0.0) / tsteps, 4)}
-                                   for (k, n), v in sorted(ser_name.items()) if k == "mlp"}
+            del gfeat, gidx
+        res["kernels"] = kern
+        res["mlp_launches"] = {n: {"ms": round(v, 4), "executed_gflop": round(flops_of(n, per_flops) / 1e9, 2),
+                                   "tflops": round(flops_of(n, per_flops) / (v * 1e-3) / 1e12, 1) if v > 0 else None,
+                                   "frac": round(flops_of(n, per_flops) / (v * 1e-3) / 1e12 / PEAK, 3) if v > 0 else None,
+                                   **({"ms_under_overlap": round(per_name.get(("mlp", n), 0.0) / tsteps, 4)} if detail else {})}
+                               for (k, n), v in sorted(ser_name.items()) if k == "mlp"}
+        if detail:
             res["mlp_launch_order"] = [n for k, n, _, _ in ser_log if k == "mlp"]
 
-        # ---- dense leg: the same kernels with the padding skip off (every grouped row computed) ----
-        if not args.no_dense_leg and args.dtype == "f32" and world == 1:
-            _lib.set_option("mlp_nodedup", 1)
-            try:
-                for _ in range(2):
-                    det.submit(points)
-                torch.cuda.synchronize()
-                nd = 8
-                td = time.perf_counter()
-                for _ in range(nd):
-                    dout, _ = det.submit(points)
-                torch.cuda.synchronize()
-                dd = time.perf_counter() - td
-            finally:
-                _lib.set_option("mlp_nodedup", 0)
-            res["dense_leg"] = {"value": round(B * nd / dd, 1), "unit": "scenes/s", "steps": nd,
-                                "tflops_spec_dense": round(work["mlp_flops"] * B * nd / dd / 1e12, 1),
-                                "same_boxes": bool(torch.equal(dout, out[:B])),
-                                "note": "sad_set_option(mlp_nodedup=1): every padded grouped row is computed (SPEC-dense flops, "
-                                        "geometry tuned for the sparse rows) - the floor for scenes whose neighbourhoods are all "
-                                        "full; the headline's 13x fewer rows are a property of the KITTI-shaped scene density "
-                                        "(~3 points per square metre), not of the kernels"}
+    # ---- dense leg: the same kernels with the padding skip off (every grouped row computed) ----
+    if detail and not args.no_dense_leg and w.dtype == "f32" and world == 1:
+        _lib.set_option("mlp_nodedup", 1)
+        try:
+            for _ in range(2):
+                det.submit(points)
+            torch.cuda.synchronize()
+            nd = 8
+            td = time.perf_counter()
+            for _ in range(nd):
+                dout, _ = det.submit(points)
+            torch.cuda.synchronize()
+            dd = time.perf_counter() - td
+        finally:
+            _lib.set_option("mlp_nodedup", 0)
+        res["dense_leg"] = {"value": round(B * nd / dd, 1), "unit": "scenes/s", "steps": nd,
+                            "tflops_spec_dense": round(work["mlp_flops"] * B * nd / dd / 1e12, 1),
+                            "same_boxes": bool(np.array_equal(dout.cpu().numpy(), got_boxes)),
+                            "note": "sad_set_option(mlp_nodedup=1): every padded grouped row is computed (SPEC-dense flops, "
+                                    "geometry tuned for the sparse rows) - the floor for scenes whose neighbourhoods are all "
+                                    "full; the headline's 13x fewer rows are a property of the KITTI-shaped scene density "
+                                    "(~3 points per square metre), not of the kernels"}
+    ctx = {"cfg": cfg, "weights": weights, "points_np": points_np, "got_boxes": got_boxes}
+    del det, batches
+    torch.cuda.empty_cache()
+    return res, rc, ctx
 
+
+def leg_record(res: dict) -> dict:
+    """The part of a measurement that a secondary leg reports inside the headline line."""
+    out = {k: res[k] for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype") if k in res}
+    out["workload"] = res["config"]["workload"]
+    out["fps_streams"] = res["config"]["fps_streams"]
+    out["scenes_per_gpu"] = res["config"]["scenes_per_gpu"]
+    if "step_ms" in res:
+        out["step_ms_p50"] = res["step_ms"]["p50"]
+    if "roofline" in res:
+        r = res["roofline"]
+        out["roofline"] = {k: r[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "flop_per_step",
+                                             "ms_per_step", "ms_per_step_uncorrected", "event_pair_ms")}
+        out["mlp_ms_per_step"] = r["ms_per_step"]
+    for k in res.get("kernels", []):
+        if k["kernel"].startswith("fps"):
+            out["fps_ms_per_step"] = k["ms_per_step"]
+            out["fps_cu_ms_per_step"] = k["cu_ms_per_step"]
+            out["fps_us_per_serial_step"] = k["us_per_serial_step"]
+        elif k["kernel"].startswith("ball query"):
+            out["ball_query_ms_per_step"] = k["ms_per_step"]
+            out["ball_query_hbm_frac"] = k["frac"]
+    if "mlp_launches" in res:
+        out["mlp_launches"] = {n: {"ms": v["ms"], "frac": v["frac"]} for n, v in res["mlp_launches"].items()}
+    out["parity_check"] = res.get("parity_check")
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=32, help="scenes per GPU per step")
+    ap.add_argument("--batches", type=int, default=4, help="distinct resident batches the timed region rotates over")
+    ap.add_argument("--no-overlap", action="store_true", help="run FPS on the main stream")
+    ap.add_argument("--fps-streams", type=int, default=None,
+                    help="sampling streams used round-robin (default: 3 for f32, 6 for bf16 - the bf16 MLP "
+                         "dispatches are short enough that the serial FPS chain of a batch bounds the step otherwise)")
+    ap.add_argument("--main-streams", type=int, default=2, help="main streams used round-robin by consecutive steps")
+    ap.add_argument("--queue-depth", type=int, default=None,
+                    help="steps in flight before the host waits for the oldest (default: max(6, sampling streams + 2))")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg (parity_check then uses 4 scenes)")
+    ap.add_argument("--cpu-scenes", type=int, default=32)
+    ap.add_argument("--no-launch-timing", action="store_true", help="skip the per-launch event passes (roofline / kernels)")
+    ap.add_argument("--no-dense-leg", action="store_true")
+    ap.add_argument("--no-legs", action="store_true", help="skip the secondary bf16_leg / configs4_leg of the default run")
+    ap.add_argument("--leg-steps", type=int, nargs=2, default=(100, 30), metavar=("BF16", "CONFIGS4"),
+                    help="timed steps of the two secondary legs")
+    ap.add_argument("--no-autotune", action="store_true", help="use the built-in geometry heuristic")
+    ap.add_argument("--geometry-file", default=None,
+                    help="JSON {launch name: geometry code} from --save-geometry: no autotune launches (rocprof runs)")
+    ap.add_argument("--save-geometry", default=None, help="write the geometry in use to this JSON file")
+    ap.add_argument("--config", choices=("kitti", "nuscenes"), default="kitti",
+                    help="nuscenes = BASELINE configs[4] shape (65536-pt scenes, 4 extra channels); secondary, "
+                         "use with --dtype bf16 --no-cpu; the headline metric is the kitti default")
+    ap.add_argument("--scene", choices=("kitti", "dense"), default="kitti",
+                    help="dense = the same 16384 points on 20 m x 20 m (most neighbourhoods full): the dense-occupancy "
+                         "floor of the same kernels; secondary, the headline is the KITTI-shaped default")
+    ap.add_argument("--dtype", choices=("f32", "bf16"), default="f32",
+                    help="bf16 = SPEC.md 14 mode (configs[4]): MLPs on the bf16 matrix cores; "
+                         "the headline metric is the f32 default")
+    ap.add_argument("--opt", action="append", default=[], help="tuning knob key=value (sad_set_option)")
+    args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` as the driver runs it: start the N ranks ourselves (as a child process, before
+        # anything here has imported torch or touched the GPU), relay rank 0's line and exit with the child's code
+        raise SystemExit(self_launch(launch_command(sys.argv[1:], args.gpus, free_port())))
+
+    import torch
+    import torch.distributed as dist
+    import sad_amd  # noqa: F401
+    from sad_amd import ops
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch `python bench.py --gpus N` (it starts its own "
+                         "ranks) or torch.distributed.run with --nproc-per-node N")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path is the only path (no CPU fallback)")
+    if os.environ.get("SAD_BENCH_ONE_DEVICE"):      # rehearsal of the N>1 path on a one-GPU box
+        local_rank = 0
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        backend = os.environ.get("SAD_BENCH_BACKEND", "nccl")       # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:                                                        # rehearsal on a one-GPU box
+            dist.init_process_group(backend)
+
+    from sad_amd import _lib
+    for kv in args.opt:
+        k, v = kv.split("=")
+        _lib.set_option(k, int(v))
+    if os.environ.get("SAD_NO_MERGE_BF16"):
+        ops.MERGE_BF16 = False
+
+    head = Workload(args.config, args.scene, args.dtype, args.batch, args.fps_streams, args.main_streams,
+                    args.queue_depth, args.batches, overlap=not args.no_overlap)
+    res, rc, ctx = measure(head, args.steps, args.warmup, rank, world, dev, args, detail=True)
+
+    if rank == 0:
+        cfg, weights, points_np = ctx["cfg"], ctx["weights"], ctx["points_np"]
         want = None
         if not args.no_cpu and world == 1:
-            n_cpu = max(1, min(B, args.cpu_scenes))
+            n_cpu = max(1, min(args.batch, args.cpu_scenes))
             res["cpu_baseline"], want = cpu_baseline(cfg, weights, points_np[:n_cpu])
         else:
             import oracle
             oracle.build()
-            want = oracle.detector_forward(points_np[:min(B, 4)], cfg, weights, skip_padding=True)
+            want = oracle.detector_forward(points_np[:min(args.batch, 4)], cfg, weights, skip_padding=True)
         if args.dtype == "f32":
-            res["parity_check"] = parity_check(got_boxes, want)
+            res["parity_check"] = parity_check(ctx["got_boxes"], want)
+            res["parity_check"]["batch"] = res["config"]["parity_batch"]
             if not res["parity_check"]["ok"]:
                 rc = 1
         else:
             res["parity_check"] = {"ok": None, "note": "bf16 mode (SPEC 14) is verified stage by stage with teacher forcing in "
                                                        "tests/test_gpu_bf16.py; an end-to-end box comparison is not meaningful "
                                                        "(one rounding flip may move an index decision)"}
+        del ctx
+
+    # ---- secondary legs of the default run (one GPU, the headline workload): the bf16 mode on the same scenes, and
+    # BASELINE configs[4] on its own shape; short, after the headline, each a full measurement of its own detector
+    default_run = (world == 1 and args.config == "kitti" and args.scene == "kitti" and args.dtype == "f32"
+                   and not args.no_legs and not args.no_overlap and not args.opt)
+    if default_run:
+        import copy
+        largs = copy.copy(args)
+        largs.geometry_file, largs.save_geometry = None, None
+        bf_note = {"ok": None, "note": "bf16 mode (SPEC 14): verified stage by stage in tests/test_gpu_bf16.py"}
+        for key, wl, nsteps in (("bf16_leg", Workload("kitti", "kitti", "bf16", args.batch, None, 2, None, args.batches), args.leg_steps[0]),
+                                ("configs4_leg", Workload("nuscenes", "kitti", "bf16", 32, None, 2, None, 2), args.leg_steps[1])):
+            t_leg = time.perf_counter()
+            try:
+                lres, _, lctx = measure(wl, nsteps, wl.fps_streams + 2, rank, world, dev, largs, detail=False)
+                del lctx
+                lres["parity_check"] = bf_note
+                res[key] = leg_record(lres)
+                res[key]["wall_s"] = round(time.perf_counter() - t_leg, 1)
+            except Exception as e:          # a leg must never take the headline line down with it
+                res[key] = {"error": f"{type(e).__name__}: {e}"}
+                rc = rc or 1
+    if rank == 0:
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.barrier()

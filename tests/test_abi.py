@@ -196,3 +196,32 @@ def test_boundary_is_reentrant_across_threads(sad):
     t.start()
     t.join()
     assert seen == [b""]
+
+
+def test_package_owns_hw_queue_precondition(monkeypatch):
+    """The package (not only bench.py) exports GPU_MAX_HW_QUEUES before HIP initialises, leaves a user's value alone, and
+    warns when a pipeline creates more streams than there are hardware queues.  Pure env logic."""
+    import warnings
+    from sad_amd import _runtime
+    env = {}
+    assert _runtime.ensure_hw_queues(env, initialised=False) == "set" and env["GPU_MAX_HW_QUEUES"] == "16"
+    assert _runtime.ensure_hw_queues(env, initialised=False) == "user"          # second import: already there
+    env = {"GPU_MAX_HW_QUEUES": "8"}
+    assert _runtime.ensure_hw_queues(env, initialised=False) == "user" and env["GPU_MAX_HW_QUEUES"] == "8"
+    env = {}
+    assert _runtime.ensure_hw_queues(env, initialised=True) == "late" and "GPU_MAX_HW_QUEUES" not in env
+    assert _runtime.hw_queues({}) == 4 and _runtime.hw_queues({"GPU_MAX_HW_QUEUES": "16"}) == 16
+    assert _runtime.hw_queues({"GPU_MAX_HW_QUEUES": "x"}) == 4
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        assert _runtime.check_stream_budget(6, "set", {"GPU_MAX_HW_QUEUES": "16"})        # default detector: 2 + 3 + 1
+        assert _runtime.check_stream_budget(4, "late", {})                                # fits HIP's default 4
+    with pytest.warns(RuntimeWarning, match="hardware queues"):
+        assert not _runtime.check_stream_budget(6, "late", {})
+    with pytest.warns(RuntimeWarning, match="share a"):
+        assert not _runtime.check_stream_budget(9, "user", {"GPU_MAX_HW_QUEUES": "8"})
+    # the import itself did it for this process (conftest imports nothing that touches the GPU first)
+    import sad_amd
+    assert sad_amd.HW_QUEUES_STATE in ("set", "user")
+    import os
+    assert os.environ.get("GPU_MAX_HW_QUEUES")

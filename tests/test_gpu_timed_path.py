@@ -206,3 +206,58 @@ def test_bench_configuration_b32_submit_autotuned(orc, sad, dev):
     got2 = out2.cpu().numpy()
     np.testing.assert_array_equal(got2[..., 8], want2[..., 8])
     assert _rel(got2, want2) <= TOL
+
+
+@pytest.mark.parametrize("pack_features", [True, False])
+def test_unaligned_feature_view_with_poisoned_buffers(orc, sad, dev, pack_features):
+    """Regression (round-3 advisor finding): with 4 extra channels the SA1 feature view of [B,N,7] points has row stride 7
+    and a 12-byte offset, so the register-resident kernels cannot fetch it in 16-byte chunks.  The row-packing scan used to
+    prepare the pooling buffer for them anyway while the tiled kernel ran (it max-combines into memory it expects to be
+    ZERO) — silently wrong or NaN results on the default submit() path.  Now ``wants_prescan`` and ``_grouped_args``
+    share one layout predicate and the detector packs the features once; both routes (packed copy -> table kernels;
+    strided view handed straight to a stage -> tiled kernel on a zero-filled slice) must give the oracle's results with
+    every uninitialised buffer poisoned with NaN.  TINY topology with ``in_feat = 4``: the SA1 chains are the nuScenes
+    shapes (7 -> 16 -> 16 -> 32), sizes the oracle finishes in a second."""
+    import dataclasses
+    import torch
+    from sad_amd import config, ops, synth
+    from sad_amd.detector import SADDetector
+    cfg = dataclasses.replace(config.TINY, in_feat=4)
+    B = 3
+    w = synth.make_weights(cfg, 0)
+    base = synth.make_tiny_batch(40, B, cfg.n_points)
+    extra = np.random.default_rng(7).uniform(0.0, 1.0, (B, cfg.n_points, 3)).astype(np.float32)
+    pts = np.ascontiguousarray(np.concatenate([base, extra], 2))           # [B,N,7]
+    otr = {}
+    want = orc.detector_forward(pts, cfg, w, otr)
+    P = _t(pts, dev)
+    if pack_features:
+        det = SADDetector(cfg, w, dev, overlap_fps=True, n_fps_streams=2, n_main_streams=2)
+        det.poison_buffers = True
+        assert det.stages[0].branches[0].preferred_geometry % 1000 in (2, 3, 4), "the SA1 shape is expected to be a compiled one"
+        outs = [det.submit(P)[0] for _ in range(3)]
+        torch.cuda.synchronize()
+        for i, out in enumerate(outs):
+            got = out.cpu().numpy()
+            assert np.isfinite(got).all(), f"submit {i}: non-finite boxes"
+            np.testing.assert_array_equal(got[..., 8], want[..., 8], err_msg=f"labels, submit {i}")
+            assert _rel(got, want) <= TOL, f"submit {i}: {_rel(got, want):.3e}"
+    else:
+        # the stage on its own, fed the strided view: query(prescan=True, cat=<NaN buffer>, feat=view) must not prepare the
+        # buffer for a table kernel that will not run
+        m = SADDetector(cfg, w, dev).stages[0]
+        xyz = P[:, :, :3].contiguous()
+        view = P[:, :, 3:]
+        assert not ops.PackedMLP.feat_fits_table_kernels(view.shape[2], view.stride(1), view.data_ptr())
+        _, new_xyz = m.sample(xyz)
+        cat = torch.full((B, m.stage.npoint, m.cat_channels), float("nan"), dtype=torch.float32, device=dev)
+        q = m.query(xyz, new_xyz, prescan=True, cat=cat, feat=view)
+        assert all(t is None for t in q[2]), "a row-packing table was made for a layout the table kernels cannot read"
+        out = m.group_and_pool(xyz, view, new_xyz, query=q, cat=cat)
+        torch.cuda.synchronize()
+        assert np.array_equal(out.cpu().numpy(), otr["sa1"]["out"]), "SA1 features differ from the oracle"
+        # and the backstop: a table handed to a chain whose kernel packs for itself is refused, not run
+        idxs, cnts = q[0], q[1]
+        ws = ops.rowscan_multi(idxs[:1], cnts[:1], xyz.shape[1])[0]
+        with pytest.raises(RuntimeError, match="packs for itself"):
+            m.branches[0].grouped(xyz, view, new_xyz, idxs[0], out=torch.zeros_like(cat), cnt=cnts[0], ws=ws)
