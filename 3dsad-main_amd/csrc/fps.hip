@@ -316,7 +316,7 @@ SAD_API int sad_fps_f32(const float *xyz, int B, int N, int M, int32_t *idx, voi
         hipLaunchKernelGGL(fps_big_kernel, dim3(B), dim3(1024), 0, st, xyz, N, M, (float *)workspace, idx);
         return sad::check_launch("sad_fps_f32");
     }
-    const int variant = sad::get_option(sad::OPT_FPS_VARIANT);   // 0 auto (cell buckets), 1 pair, 2 key, 3 wave buckets, 4 cell buckets, 5 cell buckets over sorted records for any N >= 2048
+    const int variant = sad::get_option(sad::OPT_FPS_VARIANT);   // 0 auto (cell buckets), 1 pair, 2 key, 3 wave buckets, 4 cell buckets, 5 cell buckets over sorted records for any N >= 2048, 6 cell buckets (first form of the kernel)
     if (workspace && N >= 2048 && (variant == 0 || variant >= 3))
         return sad::launch_fps_bucket(xyz, B, N, M, idx, workspace, st);
     if (N <= 2048) {

@@ -513,6 +513,327 @@ __global__ __launch_bounds__(NW * 64) void fps_cell_kernel(const float *__restri
     fps_cell_body<NW, PPT>(xyz, perm_in, N, M, idx_out);
 }
 
+// ---- cell-bucket kernel, second form ("lane-direct publish", round 4) ----------------------------------------------
+// Same buckets, same skip test, same proof — what changed is what a serial step makes every wave ISSUE.  Measured on
+// the first form: a step is not only the disturbed wave's dependent chain, the four waves of a SIMD also share its
+// vector issue port, and every one of them ran ~31 vector instructions per step just to publish its (unchanged) best
+// and read the winner (mbcnt lane election of the LDS atomic, 8 v_mov of wave-uniform values into LDS data registers,
+// 4 v_readlane of the wave's best point), the disturbed wave ~85 more (5 v_readlane + 5 v_writelane per bucket update to
+// cache the bucket's best point in the bucket's state lane, 4 more per wave best).  Here
+//  * a bucket keeps only (box, max min-distance, LANE of the point that attains it): two v_writelane per update;
+//  * the wave's best point is never moved: the lane that owns it (lane `wl`, register slot `kb`) writes the wave's
+//    record and key itself — ds_write_b128 / ds_max_u64 under a one-lane exec mask, no readlane, no v_mov;
+//  * a wave republishes its record only when (kb, wl, key) changed (and once more for the other record buffer);
+//    its key lives on in lane wl's registers: an undisturbed wave's step is the skip test, one LDS atomic, the
+//    barrier and the read of the winner;
+//  * the wave best is recomputed only when the best bucket itself was updated or an updated bucket reaches its key;
+//  * the 64-lane max uses single-instruction row_bcast DPP steps (hipcc expands the builtin into mov + mov_dpp + max).
+typedef float f4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ unsigned lds_off(const void *p) { return (unsigned)(size_t)p; }   // low half of a flat LDS address
+__device__ __forceinline__ unsigned wave_max_u32_b(unsigned v) {   // wave-uniform result (SGPR)
+    v = row_max_u32<4>(v);
+    // row_bcast:15 -> rows 1, 3; row_bcast:31 -> rows 2, 3; dst == src1, so the rows left out keep their value
+    // (no wait states are inserted inside asm: two after the VALU write of v, two between the DPP steps)
+    asm("s_nop 1\n\tv_max_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_max_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf" : "+v"(v));
+    return __builtin_amdgcn_readlane(v, 63);
+}
+
+#ifdef SAD_FPS_STAMPS2
+// measurement build of the second form: s_memtime ticks per phase, summed by every wave of workgroup 0 over the steps in
+// which IT held the sampled point (its chain is the step's critical path), second half of the run:
+// [0] barrier -> centre known, [1] skip test, [2] bucket updates, [3] wave best, [4] record, [5] key atomic issued -> barrier passed,
+// [6] such steps, [7] buckets updated in them
+__device__ unsigned long long g_fpst2[16 * 8];
+extern "C" __attribute__((visibility("default"))) int sad_debug_read_fps_stamps2(unsigned long long *dst) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_fpst2), sizeof(unsigned long long) * 16 * 8);
+}
+#define FPS2_T(v) const unsigned long long v = __builtin_amdgcn_s_memtime()
+#define FPS2_ACC(slot, expr) do { if (s.crit) s.acc[slot] += (expr); } while (0)
+#else
+#define FPS2_T(v)
+#define FPS2_ACC(slot, expr)
+#endif
+
+// State of one wave (everything is a register; the struct exists so that the six unrolled step bodies share one text).
+template <int NW, int PPT>
+struct Cell2 {
+    typedef float fvec __attribute__((ext_vector_type(PPT)));
+    typedef unsigned uvec __attribute__((ext_vector_type(PPT)));
+    fvec px, py, pz, md;
+    uvec ni;                                  // ~original index (larger = lower index, for the tie rule)
+    float blo0, blo1, blo2, bhi0, bhi1, bhi2; // lane k: bounding box of bucket k
+    unsigned bmax, blane;                     // lane k: bucket k's max min-distance (bits) and the lane that attains it
+    float cx, cy, cz;                         // the centre sampled last (wave-uniform)
+    int kb, wl;                               // the wave's best point: bucket (register slot) kb, lane wl
+    unsigned wk_hi;                           // its min-distance bits
+    unsigned long long wlmask;                // 1 << wl: the exec mask of the publishing lane
+    unsigned klo, khi;                        // the wave's key, valid in lane wl
+    unsigned pending;                         // the other record buffer still holds the previous best
+    unsigned a_key, a_rec_mine, a_rec0;       // LDS byte addresses: key slots, own record, record of wave 0
+    int wave;
+#ifdef SAD_FPS_STAMPS2
+    unsigned long long acc[8], t_bar;
+    bool crit, sample;
+#endif
+};
+
+// The rare part of a step: bucket updates, the wave's new best, its record.  BUF = record buffer of this step.
+// Everything here is on the step's critical path when this wave holds the sampled point (its bucket is always disturbed),
+// so the text is kept short: no divergent control flow (lane-masked work runs under an exec mask set inside asm, which
+// keeps every flag in a scalar register), one register-indexed region per group of reads, popcounts for the tie checks.
+template <int NW, int PPT, int BUF>
+__device__ __forceinline__ void cell2_slow(Cell2<NW, PPT> &s, unsigned act, int lane) {
+    constexpr int PSTEPS = PPT > 16 ? 5 : 4;
+    constexpr unsigned long long PMASK = PPT >= 32 ? 0xffffffffull : ((1ull << PPT) - 1ull);
+    unsigned publish = s.pending;
+    s.pending = 0u;
+    FPS2_T(ts0);
+    FPS2_ACC(7, __builtin_popcount(act));
+    if (act) {
+        __builtin_amdgcn_s_setprio(3);        // the disturbed wave's chain ahead of its idle siblings on the SIMD
+        // the wave best must be recomputed when its bucket is updated, or when an updated bucket ends up with the same
+        // key high word (min-distances only fall, so none can end up above it)
+        const unsigned kb_hit = (act >> s.kb) & 1u;
+        unsigned top = 0u;
+        do {
+            const int k = __builtin_amdgcn_readfirstlane(__builtin_ctz(act));
+            act &= act - 1;
+            float x = s.px[k], y = s.py[k], z = s.pz[k], om = s.md[k];
+            // (pinned: without it hipcc folds the register-indexed read of md[k] into v_min_u32's operand AFTER
+            // s_set_gpr_idx_off, i.e. reads md[0] — seen in the disassembly of this kernel, ROCm 7.2)
+            asm volatile("" : "+v"(x), "+v"(y), "+v"(z), "+v"(om));
+            const float d = sad::d2f(x, y, z, s.cx, s.cy, s.cz);
+            // min on the bit patterns: both are >= +0 (no NaN: SPEC §2), integer order = float order, and
+            // v_min_u32 needs no canonicalising v_max first
+            const unsigned db = __builtin_bit_cast(unsigned, d), ob = __builtin_bit_cast(unsigned, om);
+            const unsigned mb = db < ob ? db : ob;
+            s.md[k] = __builtin_bit_cast(float, mb);
+#if defined(SAD_FPS_DUP) && SAD_FPS_DUP == 2      // measurement: the 64-lane reduction a second time
+            { unsigned t = mb ^ 1u; asm volatile("" : "+v"(t)); unsigned r = wave_max_u32_b(t); asm volatile("" :: "s"(r)); }
+#endif
+            const unsigned hi = wave_max_u32_b(mb);
+            const unsigned long long tie = __ballot(mb == hi);
+            int l = __builtin_ctzll(tie);
+            if (__builtin_popcountll(tie) > 1) {                      // several lanes attain the max: lowest index wins
+                const unsigned n = s.ni[k];
+                const unsigned lo = wave_max_u32_b(mb == hi ? n : 0u);
+                l = __builtin_ctzll(__ballot(mb == hi && n == lo));
+            }
+            // bucket k's state lane: its new maximum and the lane that holds it (both writes through one m0)
+            asm("s_mov_b32 m0, %4\n\tv_writelane_b32 %0, %2, m0\n\tv_writelane_b32 %1, %3, m0"
+                : "+v"(s.bmax), "+v"(s.blane) : "s"(hi), "s"(l), "s"(k));
+            top = hi > top ? hi : top;
+        } while (act);
+        FPS2_T(ts1);
+        FPS2_ACC(2, ts1 - ts0);
+        if (kb_hit | (top >= s.wk_hi ? 1u : 0u)) {
+            const unsigned nh = __builtin_amdgcn_readlane(half_max_u32<PSTEPS>(s.bmax), 0);
+            const unsigned long long wt = __ballot(s.bmax == nh) & PMASK;
+            int nk = __builtin_ctzll(wt);
+            int nl = (int)__builtin_amdgcn_readlane(s.blane, nk);
+            if (__builtin_popcountll(wt) > 1) {                       // equal maxima in several buckets: lowest index wins
+                unsigned best_n = 0u;
+                unsigned long long rest = wt;
+                do {
+                    const int k2 = __builtin_amdgcn_readfirstlane(__builtin_ctzll(rest));
+                    rest &= rest - 1;
+                    const int l2 = (int)__builtin_amdgcn_readlane(s.blane, k2);
+                    const unsigned n2 = __builtin_amdgcn_readlane(s.ni[k2], l2);
+                    if (n2 >= best_n) { best_n = n2; nk = k2; nl = l2; }   // (indices are unique: >= only matters for the first)
+                } while (rest);
+            }
+            s.kb = nk; s.wl = nl; s.wk_hi = nh;
+            s.wlmask = 1ull << nl;
+            publish = 3u;                     // new key + record (even if it came out the same: rare, and cheaper than comparing)
+        }
+        __builtin_amdgcn_s_setprio(0);
+        FPS2_T(ts2);
+        FPS2_ACC(3, ts2 - ts1);
+    }
+    FPS2_T(ts3);
+    if (publish) {
+        // the owner of the wave's best point (lane wl, register slot kb) publishes it from its own registers: every lane reads
+        // slot kb, lane wl alone writes (exec is all ones here and is restored inside the statement)
+        f4v r;
+        r.x = s.px[s.kb]; r.y = s.py[s.kb]; r.z = s.pz[s.kb]; r.w = 0.f;
+        if (publish & 2u) {
+            const unsigned n = s.ni[s.kb];
+            asm volatile("s_mov_b64 exec, %4\n\t"
+                         "v_lshl_or_b32 %0, %2, 4, %3\n\t"            // index order kept (the top four bits fall off: N < 2^28)
+                         "v_mov_b32 %1, %5\n\t"
+                         "ds_write_b128 %6, %7 offset:%8\n\t"
+                         "s_mov_b64 exec, -1"
+                         : "+v"(s.klo), "+v"(s.khi) : "v"(n), "s"(s.wave), "s"(s.wlmask), "s"(s.wk_hi),
+                           "v"(s.a_rec_mine), "v"(r), "n"(BUF * 256) : "memory");
+            s.pending = 1u;                   // the other buffer gets the record in the next step
+        } else {
+            asm volatile("s_mov_b64 exec, %0\n\tds_write_b128 %1, %2 offset:%3\n\ts_mov_b64 exec, -1"
+                         :: "s"(s.wlmask), "v"(s.a_rec_mine), "v"(r), "n"(BUF * 256) : "memory");
+        }
+    }
+    FPS2_T(ts4);
+    FPS2_ACC(4, ts4 - ts3);
+}
+
+// One sampling step.  BUF / B3: record buffer and key slot of this step (compile-time: the loop is unrolled six times, so
+// every LDS address is a base register plus an immediate); W0: this is wave 0, which also clears the next key slot and
+// stores the sampled index.  What an undisturbed wave issues: the skip test (10 vector instructions), one LDS atomic
+// under a one-lane exec mask, the barrier, two LDS reads, four lane reads — and about as many scalar instructions.
+template <int NW, int PPT, int BUF, int B3, bool W0>
+__device__ __forceinline__ void cell2_step(Cell2<NW, PPT> &s, int lane, int *__restrict__ out_i) {
+    constexpr int B3N = B3 == 2 ? 0 : B3 + 1;
+    FPS2_T(ta);
+    FPS2_ACC(0, ta - s.t_bar);
+    FPS2_ACC(6, 1);
+    const float dq = sad::d2f(__builtin_amdgcn_fmed3f(s.cx, s.blo0, s.bhi0), __builtin_amdgcn_fmed3f(s.cy, s.blo1, s.bhi1),
+                              __builtin_amdgcn_fmed3f(s.cz, s.blo2, s.bhi2), s.cx, s.cy, s.cz);
+    unsigned act = __builtin_amdgcn_readfirstlane((unsigned)__ballot(dq < __builtin_bit_cast(float, s.bmax)));
+#if defined(SAD_FPS_ABL) && SAD_FPS_ABL == 1
+    act = 0;                                  // ablation: no bucket updates (timing only, wrong results)
+#endif
+    FPS2_T(tb);
+    FPS2_ACC(1, tb - ta);
+    if (act | s.pending) cell2_slow<NW, PPT, BUF>(s, act, lane);
+    FPS2_T(tc);
+    {
+        const u64 key = ((u64)s.khi << 32) | s.klo;
+        // (exec is all ones here — whole waves, top level of the loop — and is restored inside the statement)
+        asm volatile("s_mov_b64 exec, %0\n\tds_max_u64 %1, %2 offset:%3\n\ts_mov_b64 exec, -1"
+                     :: "s"(s.wlmask), "v"(s.a_key), "v"(key), "n"(B3 * 8) : "memory");
+        if (W0) {
+            const u64 zero = 0ull;
+            asm volatile("s_mov_b64 exec, 1\n\tds_write_b64 %0, %1 offset:%2\n\ts_mov_b64 exec, -1"
+                         :: "v"(s.a_key), "v"(zero), "n"(B3N * 8) : "memory");
+        }
+        // After the barrier: the winning key (one broadcast read), then the winner's record alone (a second broadcast
+        // read at an address computed from the key in vector registers: no scalar round trip).  Sixteen waves reading all
+        // sixteen records at once (64 lanes x 16 bytes each) queued in the LDS pipeline for ~200 cycles; two dependent
+        // single-address reads take less, and the centre arrives lane-uniform in vector registers: no v_readlane.
+        unsigned gk;                          // low word of the winning key: (index order << 4) | wave
+        f4v rec;
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#ifdef SAD_FPS_STAMPS2
+        { FPS2_T(td); FPS2_ACC(5, td - tc); s.t_bar = td; }
+#endif
+        {
+            unsigned ra;
+            asm volatile("ds_read_b32 %0, %3 offset:%5\n\t"
+                         "s_waitcnt lgkmcnt(0)\n\t"
+                         "v_and_b32 %2, 15, %0\n\t"                  // the winner's wave (low four bits of the key's low word)
+                         "v_lshl_add_u32 %2, %2, 4, %4\n\t"          // its record: 16 bytes per wave
+                         "ds_read_b128 %1, %2 offset:%6\n\t"
+                         "s_waitcnt lgkmcnt(0)"
+                         : "=&v"(gk), "=&v"(rec), "=&v"(ra) : "v"(s.a_key), "v"(s.a_rec0), "n"(B3 * 8), "n"(BUF * 256) : "memory");
+        }
+        s.cx = rec.x; s.cy = rec.y; s.cz = rec.z;
+#ifdef SAD_FPS_STAMPS2
+        asm volatile("" :: "v"(s.cx), "v"(s.cy), "v"(s.cz));
+        s.crit = ((__builtin_amdgcn_readfirstlane(gk) & 15) == (unsigned)s.wave) && s.sample;
+#endif
+        if (W0) {
+            if (lane == 0) *out_i = (int)(0x0fffffffu - (gk >> 4));
+        }
+    }
+}
+
+template <int NW, int PPT, bool W0>
+__device__ __forceinline__ void cell2_loop(Cell2<NW, PPT> &s, int lane, int M, int *__restrict__ out) {
+    int i = 1;                                // step i: record buffer i & 1, key slot i % 3  (i = 1: 1, 1)
+    for (; i + 6 <= M; i += 6) {
+#ifdef SAD_FPS_STAMPS2
+        s.sample = blockIdx.x == 0 && i >= M / 2;
+#endif
+        cell2_step<NW, PPT, 1, 1, W0>(s, lane, out + i);
+        cell2_step<NW, PPT, 0, 2, W0>(s, lane, out + i + 1);
+        cell2_step<NW, PPT, 1, 0, W0>(s, lane, out + i + 2);
+        cell2_step<NW, PPT, 0, 1, W0>(s, lane, out + i + 3);
+        cell2_step<NW, PPT, 1, 2, W0>(s, lane, out + i + 4);
+        cell2_step<NW, PPT, 0, 0, W0>(s, lane, out + i + 5);
+    }
+    // the last M - i < 6 steps, same order
+    if (i < M) cell2_step<NW, PPT, 1, 1, W0>(s, lane, out + i);
+    if (i + 1 < M) cell2_step<NW, PPT, 0, 2, W0>(s, lane, out + i + 1);
+    if (i + 2 < M) cell2_step<NW, PPT, 1, 0, W0>(s, lane, out + i + 2);
+    if (i + 3 < M) cell2_step<NW, PPT, 0, 1, W0>(s, lane, out + i + 3);
+    if (i + 4 < M) cell2_step<NW, PPT, 1, 2, W0>(s, lane, out + i + 4);
+}
+
+template <int NW, int PPT>
+__global__ __launch_bounds__(NW * 64) void fps_cell2_kernel(const float *__restrict__ xyz, const int *__restrict__ perm_in,
+                                                            int N, int M, int *__restrict__ idx_out) {
+    static_assert(PPT <= 32 && NW <= 16 && NW >= 2, "bucket state lives in lanes 0..31; one record per wave");
+    __shared__ u64 s_gkey[3];
+    __shared__ __attribute__((aligned(16))) float s_wxyz[2][16][4];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const float *p = xyz + (size_t)blockIdx.x * N * 3;
+    const int *perm = perm_in + (size_t)blockIdx.x * N;
+    int *out = idx_out + (size_t)blockIdx.x * M;
+
+    Cell2<NW, PPT> s;
+    s.blo0 = s.blo1 = s.blo2 = s.bhi0 = s.bhi1 = s.bhi2 = 0.f;
+    s.bmax = 0u; s.blane = 0u;
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+        const int pos = (k * NW + wave) * 64 + lane;
+        const bool real = pos < N;
+        float x = 0.f, y = 0.f, z = 0.f;
+        unsigned n = 0x80000000u;             // padding: distance 0 and the largest index never beat a real point
+        if (real) {
+            const int j = perm[pos];
+            x = p[j * 3 + 0];
+            y = p[j * 3 + 1];
+            z = p[j * 3 + 2];
+            n = ~(unsigned)j;
+        }
+        s.px[k] = x; s.py[k] = y; s.pz[k] = z; s.ni[k] = n;
+        s.md[k] = real ? __builtin_inff() : 0.f;
+        float lo[3] = {real ? x : 3.0e38f, real ? y : 3.0e38f, real ? z : 3.0e38f};
+        float hi[3] = {real ? x : -3.0e38f, real ? y : -3.0e38f, real ? z : -3.0e38f};
+#pragma unroll
+        for (int d = 0; d < 3; ++d)
+            for (int off = 32; off >= 1; off >>= 1) {
+                const float a = __shfl_xor(lo[d], off, 64), b = __shfl_xor(hi[d], off, 64);
+                lo[d] = a < lo[d] ? a : lo[d];
+                hi[d] = b > hi[d] ? b : hi[d];
+            }
+        const bool any_real = __ballot(real) != 0ull;
+        if (lane == k) {
+            s.blo0 = lo[0]; s.blo1 = lo[1]; s.blo2 = lo[2];
+            s.bhi0 = hi[0]; s.bhi1 = hi[1]; s.bhi2 = hi[2];
+            s.bmax = any_real ? 0x7f800000u : 0u;   // +inf: the first step updates every real bucket
+        }
+    }
+    s.cx = p[0]; s.cy = p[1]; s.cz = p[2];
+    if (tid == 0) out[0] = 0;
+    if (tid < 3) s_gkey[tid] = 0ull;
+    if (tid < 2 * 16 * 4) (&s_wxyz[0][0][0])[tid] = 0.f;
+    __syncthreads();
+    s.a_key = lds_off(&s_gkey[0]);
+    s.a_rec_mine = lds_off(&s_wxyz[0][wave][0]);           // + 256 for the second buffer
+    s.a_rec0 = lds_off(&s_wxyz[0][0][0]);
+    s.wave = wave;
+    s.kb = 0; s.wl = 0; s.wk_hi = 0u; s.wlmask = 1ull;
+    s.klo = (unsigned)wave; s.khi = 0u;       // (a wave without a real point keeps key 0 | wave and never wins: wave 0 has one)
+    s.pending = 1u;
+#ifdef SAD_FPS_STAMPS2
+    for (int q = 0; q < 8; ++q) s.acc[q] = 0;
+    s.t_bar = 0; s.crit = false; s.sample = false;
+#endif
+    if (wave == 0) cell2_loop<NW, PPT, true>(s, lane, M, out);
+    else cell2_loop<NW, PPT, false>(s, lane, M, out);
+#ifdef SAD_FPS_STAMPS2
+    if (blockIdx.x == 0 && lane == 0)
+        for (int q = 0; q < 8; ++q) g_fpst2[wave * 8 + q] = s.acc[q];
+#endif
+}
+
+template <int NW, int PPT>
+void launch_cell2(const float *xyz, const int *perm, int B, int N, int M, int *idx, hipStream_t st) {
+    hipLaunchKernelGGL((fps_cell2_kernel<NW, PPT>), dim3(B), dim3(NW * 64), 0, st, xyz, perm, N, M, idx);
+}
+
 template <int NW, int PPT>
 void launch_cell(const float *xyz, const int *perm, int B, int N, int M, int *idx, hipStream_t st) {
     hipLaunchKernelGGL((fps_cell_kernel<NW, PPT>), dim3(B), dim3(NW * 64), 0, st, xyz, perm, N, M, idx);
@@ -665,6 +986,217 @@ __global__ __launch_bounds__(1024) void fps_cellg_kernel(const float4 *__restric
     }
 }
 
+// ---- record-streaming cell kernel, second form (round 4): the step skeleton of fps_cell2_kernel ------------------------
+// (unrolled six times so that every LDS address is a base plus an immediate; the key atomic and the record are written by
+// the bucket's state lane under a one-lane exec mask — that lane holds the bucket's best point already, so nothing is
+// moved; the winning key is read first and then the winner's record alone; an undisturbed wave does not touch its record).
+// The state is plain locals and the step a macro: with the state in a struct handed to inlined functions (as in
+// fps_cell2) the 64-slot instantiation stayed in scratch — SROA gave up on the struct with two 32-wide register-indexed
+// vectors — and every flag loaded from there counts as divergent.
+// one bucket update: slot KS of the wave (register KI of the vector MD).  The two halves of the 64 slots run in SEPARATE
+// loops, each touching one 32-wide vector only: with "if (k < 32) md0[k] ... else md1[k - 32] ..." around the read and
+// again around the write, hipcc copied a whole 32-register vector into a temporary and back on every update
+// (32 v_mov_b64: the first form of this kernel paid that too)
+#define CELLG2_UPD(MD, KI, KS)                                                                                        \
+    {                                                                                                                 \
+        const float4 r = rec[(KS) * 1024];                                                                            \
+        const unsigned n = __builtin_bit_cast(unsigned, r.w);                                                         \
+        const float d = sad::d2f(r.x, r.y, r.z, cx, cy, cz);                                                          \
+        float om = MD[KI];                                                                                            \
+        asm volatile("" : "+v"(om)); /* keeps the register-indexed read a separate v_mov (see fps_cell2) */           \
+        const unsigned db = __builtin_bit_cast(unsigned, d), ob = __builtin_bit_cast(unsigned, om);                   \
+        const unsigned mb = db < ob ? db : ob;                                                                        \
+        MD[KI] = __builtin_bit_cast(float, mb);                                                                       \
+        const unsigned hi = wave_max_u32_b(mb);                                                                       \
+        const unsigned long long tie = __ballot(mb == hi);                                                            \
+        int l = __builtin_ctzll(tie);                                                                                 \
+        if (__builtin_popcountll(tie) > 1) {                                                                          \
+            const unsigned lo = wave_max_u32_b(mb == hi ? n : 0u);                                                    \
+            l = __builtin_ctzll(__ballot(mb == hi && n == lo));                                                       \
+        }                                                                                                             \
+        const unsigned bn = __builtin_amdgcn_readlane(n, l);                                                          \
+        const unsigned ux = __builtin_amdgcn_readlane(__builtin_bit_cast(unsigned, r.x), l);                          \
+        const unsigned uy = __builtin_amdgcn_readlane(__builtin_bit_cast(unsigned, r.y), l);                          \
+        const unsigned uz = __builtin_amdgcn_readlane(__builtin_bit_cast(unsigned, r.z), l);                          \
+        asm("s_mov_b32 m0, %10\n\tv_writelane_b32 %0, %5, m0\n\tv_writelane_b32 %1, %6, m0\n\t"                     \
+            "v_writelane_b32 %2, %7, m0\n\tv_writelane_b32 %3, %8, m0\n\tv_writelane_b32 %4, %9, m0"                 \
+            : "+v"(bmax), "+v"(bidx), "+v"(bx), "+v"(by), "+v"(bz)                                                    \
+            : "s"(hi), "s"(bn), "s"(ux), "s"(uy), "s"(uz), "s"(KS));                                                  \
+        top = hi > top ? hi : top;                                                                                    \
+    }
+
+#define CELLG2_SLOW(BUF)                                                                                              \
+    {                                                                                                                 \
+        unsigned publish = pending;                                                                                   \
+        pending = 0u;                                                                                                 \
+        if (act) {                                                                                                    \
+            __builtin_amdgcn_s_setprio(3);                                                                            \
+            const unsigned kb_hit = (unsigned)(act >> kb) & 1u;                                                       \
+            unsigned top = 0u;                                                                                        \
+            unsigned alo = (unsigned)act, ahi = (unsigned)(act >> 32);                                                \
+            while (alo) {                                                                                             \
+                const int k = __builtin_amdgcn_readfirstlane(__builtin_ctz(alo));                                     \
+                alo &= alo - 1;                                                                                       \
+                CELLG2_UPD(md0, k, k)                                                                                 \
+            }                                                                                                         \
+            if (PPT > 32) {                                                                                           \
+                while (ahi) {                                                                                         \
+                    const int k = __builtin_amdgcn_readfirstlane(__builtin_ctz(ahi));                                 \
+                    ahi &= ahi - 1;                                                                                   \
+                    CELLG2_UPD(md1, k, k + 32)                                                                        \
+                }                                                                                                     \
+            }                                                                                                         \
+            if (kb_hit | (top >= wk_hi ? 1u : 0u)) {                                                                  \
+                const unsigned nh = wave_max_u32_b(bmax);                                                             \
+                const unsigned long long wt = __ballot(bmax == nh);                                                   \
+                int nk = __builtin_ctzll(wt);                                                                         \
+                if (__builtin_popcountll(wt) > 1) { /* equal maxima in several buckets: lowest index wins */         \
+                    const unsigned lo = wave_max_u32_b(bmax == nh ? bidx : 0u);                                       \
+                    nk = __builtin_ctzll(__ballot(bmax == nh && bidx == lo));                                         \
+                }                                                                                                     \
+                kb = __builtin_amdgcn_readfirstlane(nk);                                                              \
+                wk_hi = nh;                                                                                           \
+                publish = 3u;                                                                                         \
+            }                                                                                                         \
+            __builtin_amdgcn_s_setprio(0);                                                                            \
+        }                                                                                                             \
+        if (publish) {                                                                                                \
+            f4v pr;                                                                                                   \
+            pr.x = bx; pr.y = by; pr.z = bz; pr.w = 0.f;                                                              \
+            if (publish & 2u) {                                                                                       \
+                /* lane kb alone: it holds the bucket's best point; index order kept in the key (N < 2^28) */         \
+                asm volatile("s_lshl_b64 exec, 1, %4\n\tv_lshl_or_b32 %0, %2, 4, %3\n\tv_mov_b32 %1, %5\n\t"         \
+                             "ds_write_b128 %6, %7 offset:%8\n\ts_mov_b64 exec, -1"                                   \
+                             : "+v"(klo), "+v"(khi) : "v"(bidx), "s"(wave), "s"(kb), "v"(bmax),                       \
+                               "v"(a_rec_mine), "v"(pr), "n"((BUF) * 256) : "memory");                                \
+                pending = 1u;                                                                                         \
+            } else {                                                                                                  \
+                asm volatile("s_lshl_b64 exec, 1, %0\n\tds_write_b128 %1, %2 offset:%3\n\ts_mov_b64 exec, -1"        \
+                             :: "s"(kb), "v"(a_rec_mine), "v"(pr), "n"((BUF) * 256) : "memory");                      \
+            }                                                                                                         \
+        }                                                                                                             \
+    }
+
+#define CELLG2_STEP(BUF, B3, OUT_I)                                                                                   \
+    {                                                                                                                 \
+        const float dq = sad::d2f(__builtin_amdgcn_fmed3f(cx, blo0, bhi0), __builtin_amdgcn_fmed3f(cy, blo1, bhi1),   \
+                                  __builtin_amdgcn_fmed3f(cz, blo2, bhi2), cx, cy, cz);                               \
+        const unsigned long long act0 = __ballot(dq < __builtin_bit_cast(float, bmax));                               \
+        unsigned long long act = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(act0 >> 32)) << 32) | \
+                                 (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)act0);        \
+        if ((act != 0ull) | (pending != 0u)) CELLG2_SLOW(BUF)                                                         \
+        const u64 key = ((u64)khi << 32) | klo;                                                                       \
+        asm volatile("s_lshl_b64 exec, 1, %0\n\tds_max_u64 %1, %2 offset:%3\n\ts_mov_b64 exec, -1"                    \
+                     :: "s"(kb), "v"(a_key), "v"(key), "n"((B3) * 8) : "memory");                                     \
+        if (W0) {                                                                                                     \
+            const u64 zero = 0ull;                                                                                    \
+            asm volatile("s_mov_b64 exec, 1\n\tds_write_b64 %0, %1 offset:%2\n\ts_mov_b64 exec, -1"                   \
+                         :: "v"(a_key), "v"(zero), "n"(((B3) == 2 ? 0 : (B3) + 1) * 8) : "memory");                   \
+        }                                                                                                             \
+        unsigned gk, ra;                                                                                              \
+        f4v wrec;                                                                                                     \
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier\n\t"                                                          \
+                     "ds_read_b32 %0, %3 offset:%5\n\t"                                                               \
+                     "s_waitcnt lgkmcnt(0)\n\t"                                                                       \
+                     "v_and_b32 %2, 15, %0\n\t"                                                                       \
+                     "v_lshl_add_u32 %2, %2, 4, %4\n\t"                                                               \
+                     "ds_read_b128 %1, %2 offset:%6\n\t"                                                              \
+                     "s_waitcnt lgkmcnt(0)"                                                                           \
+                     : "=&v"(gk), "=&v"(wrec), "=&v"(ra) : "v"(a_key), "v"(a_rec0), "n"((B3) * 8), "n"((BUF) * 256)   \
+                     : "memory");                                                                                     \
+        cx = wrec.x; cy = wrec.y; cz = wrec.z;                                                                        \
+        if (W0) {                                                                                                     \
+            if (lane == 0) out[OUT_I] = (int)(0x0fffffffu - (gk >> 4));                                               \
+        }                                                                                                             \
+    }
+
+template <int PPT, bool W0>      // W0: the body of wave 0 (it also clears the next key slot and stores the sampled index)
+__device__ __forceinline__ void cellg2_body(const float4 *__restrict__ rec_in, int N, int NP, int M, int *__restrict__ idx_out,
+                                            u64 *s_gkey, float (*s_wxyz)[16][4]) {
+    constexpr int NW = 16;
+    constexpr int VW = PPT < 32 ? PPT : 32;
+    typedef float fvec32 __attribute__((ext_vector_type(VW)));
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int *out = idx_out + (size_t)blockIdx.x * M;
+    const float4 *rec = rec_in + (size_t)blockIdx.x * NP + wave * 64 + lane;      // slot k of this wave: rec[k * 1024]
+
+    fvec32 md0, md1;       // min-distance of point `lane` of slot k: md0[k] (k < 32) / md1[k - 32]
+    float blo0 = 0.f, blo1 = 0.f, blo2 = 0.f, bhi0 = 0.f, bhi1 = 0.f, bhi2 = 0.f;
+    float bx = 0.f, by = 0.f, bz = 0.f;
+    unsigned bmax = 0u, bidx = 0x80000000u;
+#pragma unroll 1
+    for (int k = 0; k < PPT; ++k) {
+        const bool real = (k * NW + wave) * 64 + lane < N;
+        const float4 r = rec[k * 1024];
+        if (k < 32) md0[k & (VW - 1)] = real ? __builtin_inff() : 0.f; else md1[k & (VW - 1)] = real ? __builtin_inff() : 0.f;
+        float lo[3] = {real ? r.x : 3.0e38f, real ? r.y : 3.0e38f, real ? r.z : 3.0e38f};
+        float hi[3] = {real ? r.x : -3.0e38f, real ? r.y : -3.0e38f, real ? r.z : -3.0e38f};
+#pragma unroll
+        for (int d = 0; d < 3; ++d)
+            for (int off = 32; off >= 1; off >>= 1) {
+                const float a = __shfl_xor(lo[d], off, 64), b = __shfl_xor(hi[d], off, 64);
+                lo[d] = a < lo[d] ? a : lo[d];
+                hi[d] = b > hi[d] ? b : hi[d];
+            }
+        const bool any_real = __ballot(real) != 0ull;
+        if (lane == k) {
+            blo0 = lo[0]; blo1 = lo[1]; blo2 = lo[2];
+            bhi0 = hi[0]; bhi1 = hi[1]; bhi2 = hi[2];
+            bmax = any_real ? 0x7f800000u : 0u;
+        }
+    }
+    float cx, cy, cz;
+    {   // the first sample is original index 0: find its record (one lane of one wave owns it)
+        if (tid < 3) s_gkey[tid] = 0ull;
+        if (tid < 2 * 16 * 4) (&s_wxyz[0][0][0])[tid] = 0.f;
+        __syncthreads();
+        for (int k = 0; k < PPT; ++k) {
+            const float4 r = rec[k * 1024];
+            if (__builtin_bit_cast(unsigned, r.w) == 0xffffffffu) {
+                s_wxyz[0][0][0] = r.x; s_wxyz[0][0][1] = r.y; s_wxyz[0][0][2] = r.z;
+            }
+        }
+        __syncthreads();
+        cx = s_wxyz[0][0][0]; cy = s_wxyz[0][0][1]; cz = s_wxyz[0][0][2];
+        __syncthreads();
+        if (tid < 4) s_wxyz[0][0][tid] = 0.f;
+        __syncthreads();
+    }
+    if (tid == 0) out[0] = 0;
+    const unsigned a_key = lds_off(&s_gkey[0]);
+    const unsigned a_rec_mine = lds_off(&s_wxyz[0][wave][0]);
+    const unsigned a_rec0 = lds_off(&s_wxyz[0][0][0]);
+    int kb = 0;
+    unsigned wk_hi = 0u, klo = (unsigned)wave, khi = 0u, pending = 1u;
+    int i = 1;                                // step i: record buffer i & 1, key slot i % 3
+    for (; i + 6 <= M; i += 6) {
+        CELLG2_STEP(1, 1, i)
+        CELLG2_STEP(0, 2, i + 1)
+        CELLG2_STEP(1, 0, i + 2)
+        CELLG2_STEP(0, 1, i + 3)
+        CELLG2_STEP(1, 2, i + 4)
+        CELLG2_STEP(0, 0, i + 5)
+    }
+    if (i < M) CELLG2_STEP(1, 1, i)
+    if (i + 1 < M) CELLG2_STEP(0, 2, i + 1)
+    if (i + 2 < M) CELLG2_STEP(1, 0, i + 2)
+    if (i + 3 < M) CELLG2_STEP(0, 1, i + 3)
+    if (i + 4 < M) CELLG2_STEP(1, 2, i + 4)
+}
+#undef CELLG2_STEP
+#undef CELLG2_SLOW
+#undef CELLG2_UPD
+
+template <int PPT>      // slots per wave: 64 (up to 65 536 points) or 16 (up to 16 384 points)
+__global__ __launch_bounds__(1024) void fps_cellg2_kernel(const float4 *__restrict__ rec_in, int N, int NP, int M,
+                                                          int *__restrict__ idx_out) {
+    __shared__ u64 s_gkey[3];
+    __shared__ __attribute__((aligned(16))) float s_wxyz[2][16][4];
+    if (threadIdx.x < 64) cellg2_body<PPT, true>(rec_in, N, NP, M, idx_out, s_gkey, s_wxyz);
+    else cellg2_body<PPT, false>(rec_in, N, NP, M, idx_out, s_gkey, s_wxyz);
+}
+
 template <int THREADS, int PPT>
 void launch_bucket(const float *xyz, const int *perm, int B, int N, int M, int *idx, hipStream_t st) {
     hipLaunchKernelGGL((fps_bucket_kernel<THREADS, PPT>), dim3(B), dim3(THREADS), 0, st, xyz, perm, N, M, idx);
@@ -684,8 +1216,13 @@ int launch_fps_cellg(const float *xyz, int B, int N, int M, int32_t *idx, void *
     float4 *rec = (float4 *)((unsigned char *)workspace + off);
     hipLaunchKernelGGL(fps_sort_kernel, dim3(B), dim3(SORT_T), sizeof(int) * SORT_CELLS, st, xyz, N, perm);
     hipLaunchKernelGGL(fps_records_kernel, dim3(64, B), dim3(256), 0, st, xyz, perm, N, NP, rec);
-    if (NP == 16384) hipLaunchKernelGGL((fps_cellg_kernel<16>), dim3(B), dim3(1024), 0, st, rec, N, NP, M, idx);
-    else hipLaunchKernelGGL((fps_cellg_kernel<64>), dim3(B), dim3(1024), 0, st, rec, N, NP, M, idx);
+    if (get_option(OPT_FPS_VARIANT) == 6) {      // the first form of the kernel
+        if (NP == 16384) hipLaunchKernelGGL((fps_cellg_kernel<16>), dim3(B), dim3(1024), 0, st, rec, N, NP, M, idx);
+        else hipLaunchKernelGGL((fps_cellg_kernel<64>), dim3(B), dim3(1024), 0, st, rec, N, NP, M, idx);
+    } else {
+        if (NP == 16384) hipLaunchKernelGGL((fps_cellg2_kernel<16>), dim3(B), dim3(1024), 0, st, rec, N, NP, M, idx);
+        else hipLaunchKernelGGL((fps_cellg2_kernel<64>), dim3(B), dim3(1024), 0, st, rec, N, NP, M, idx);
+    }
     return check_launch("sad_fps_f32 (cell, global records)");
 }
 
@@ -696,7 +1233,7 @@ int launch_fps_bucket(const float *xyz, int B, int N, int M, int32_t *idx, void 
     int *perm = (int *)workspace;
     hipLaunchKernelGGL(fps_sort_kernel, dim3(B), dim3(SORT_T), sizeof(int) * SORT_CELLS, st, xyz, N, perm);
     if (int e = check_launch("sad_fps_f32 (sort)")) return e;
-    if (get_option(OPT_FPS_VARIANT) != 3) {   // default: cell-bucket kernel (3 = wave/thread-bucket kernel)
+    if (get_option(OPT_FPS_VARIANT) != 3) {   // default: cell-bucket kernel (3 = wave/thread-bucket kernel, 6 = first form of the cell kernel)
         // geometry = waves * 100 + slots; fps_threads option overrides (for sweeps)
         const int nb = (N + 63) / 64;                       // buckets
         int geo = get_option(OPT_FPS_THREADS);
@@ -705,6 +1242,18 @@ int launch_fps_bucket(const float *xyz, int B, int N, int M, int32_t *idx, void 
         if (nw * ppt < nb || !(nw == 1 || nw == 2 || nw == 4 || nw == 8 || nw == 16) ||
             !(ppt == 4 || ppt == 8 || ppt == 16 || ppt == 32))
             return fail(SAD_EINVAL, "sad_fps_f32: cell geometry %d cannot hold %d buckets", geo, nb);
+        if (get_option(OPT_FPS_VARIANT) != 6 && nw >= 2) {      // second form of the cell kernel (lane-direct publish); 6 = the first form
+#define SAD_CELL2(NW_, PPT_) case NW_ * 100 + PPT_: launch_cell2<NW_, PPT_>(xyz, perm, B, N, M, idx, st); break;
+            switch (geo) {
+                SAD_CELL2(16, 4) SAD_CELL2(16, 8) SAD_CELL2(16, 16)
+                SAD_CELL2(8, 4) SAD_CELL2(8, 8) SAD_CELL2(8, 16) SAD_CELL2(8, 32)
+                SAD_CELL2(4, 4) SAD_CELL2(4, 8) SAD_CELL2(4, 16) SAD_CELL2(4, 32)
+                SAD_CELL2(2, 8) SAD_CELL2(2, 16) SAD_CELL2(2, 32)
+                default: return fail(SAD_EINVAL, "sad_fps_f32: cell geometry %d not built", geo);
+            }
+#undef SAD_CELL2
+            return check_launch("sad_fps_f32 (cell, lane-direct)");
+        }
 #define SAD_CELL(NW_, PPT_) case NW_ * 100 + PPT_: launch_cell<NW_, PPT_>(xyz, perm, B, N, M, idx, st); break;
         switch (geo) {
             SAD_CELL(16, 4) SAD_CELL(16, 8) SAD_CELL(16, 16)
