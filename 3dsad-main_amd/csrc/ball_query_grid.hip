@@ -286,8 +286,8 @@ __device__ __forceinline__ float readlane_f(float v, int l) {                  /
 template <int NR>
 __global__ __launch_bounds__(GQ_WAVES * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) void grid_query_kernel(const float *__restrict__ new_xyz,
                                                                    const char *__restrict__ ws,
-                                                                   GQParams prm, int N, int M, int B, int nbx) {
-    extern __shared__ unsigned bm_all[];        // NR * (NWP + 64) words (zero between centroids) + the lock word
+                                                                   GQParams prm, int N, int M, int B, int nbx, int nsets) {
+    extern __shared__ unsigned bm_all[];        // nsets x (NR * (NWP + 64) words (zero between centroids) + the lock word)
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // XCD-aware order: workgroups go to the 8 XCDs round-robin; all centroid blocks of scene
@@ -300,10 +300,14 @@ __global__ __launch_bounds__(GQ_WAVES * 64) __attribute__((amdgpu_waves_per_eu(8
     while ((64 << wshift) < NW) ++wshift;
     const int WPL = 1 << wshift;
     const int NWP = WPL * 64;                   // padded words per bitmap
-    // ONE bitmap set per workgroup, taken under a lock: only centroids with more than 128 candidates use it (0.05 % of a
-    // KITTI-shaped scene), and a set per wave (27 KB per workgroup at N = 16 384) capped the kernel at five waves per SIMD
-    unsigned *bm = bm_all;
-    unsigned *lock = bm_all + NR * (NWP + 64);
+    // Bitmap sets are shared under a lock: only centroids with more than 128 candidates use one (0.05 % of a KITTI-shaped
+    // scene), and a set per wave (27 KB per workgroup at N = 16 384) capped the kernel at five waves per SIMD.  ONE set per
+    // workgroup (round 3) made the four waves of a workgroup take turns on dense scenes, where most centroids come here
+    // (20 m x 20 m scenes: SA1 query 0.205 -> 0.369 ms); with a set per TWO waves (`nsets` = 2 whenever two sets still leave
+    // room for eight workgroups per CU) a wave shares its lock with one sibling.
+    const int SETW = NR * (NWP + 64) + 1;       // words of a set, its lock word last
+    unsigned *bm = bm_all + (nsets == 2 ? (wave >> 1) * SETW : 0);
+    unsigned *lock = bm + NR * (NWP + 64);
     // second level: dm[r*64 + l] has bit k set iff word l*WPL + k of bitmap r is non-zero, so the
     // scan touches only the words that received a bit (cost ~ accepted points, not N)
     unsigned *dm = bm + NR * NWP;
@@ -317,7 +321,7 @@ __global__ __launch_bounds__(GQ_WAVES * 64) __attribute__((amdgpu_waves_per_eu(8
     const float x0 = hdr->x0, y0 = hdr->y0, z0 = hdr->z0, inv = hdr->inv;
     const int gx = hdr->gx, gy = hdr->gy, gz = hdr->gz;
 
-    for (int w = threadIdx.x; w < NR * (NWP + 64) + 1; w += GQ_WAVES * 64) bm_all[w] = 0u;
+    for (int w = threadIdx.x; w < nsets * SETW; w += GQ_WAVES * 64) bm_all[w] = 0u;
     __syncthreads();
 
     // The wave's GQ_CPW = 4 centroids are independent: their dependent memory round trips (centroid -> cell starts -> first
@@ -559,10 +563,13 @@ void launch_query(const float *new_xyz, const char *ws, const GQParams &prm, int
     const int NW = (N + 31) >> 5;
     int WPL = 1;
     while (64 * WPL < NW) WPL <<= 1;
-    const size_t lds = sizeof(unsigned) * ((size_t)NR * (WPL * 64 + 64) + 1);
+    const size_t set_bytes = sizeof(unsigned) * ((size_t)NR * (WPL * 64 + 64) + 1);
+    // (eight workgroups per CU keep their 160 KB / 8 each; bq_variant = 2: one set, the round-3 layout, for A/B runs)
+    const int nsets = (2 * set_bytes <= 20 * 1024 && sad::get_option(sad::OPT_BQ_VARIANT) != 2) ? 2 : 1;
+    const size_t lds = set_bytes * nsets;
     const int nbx = (M + GQ_WAVES * GQ_CPW - 1) / (GQ_WAVES * GQ_CPW);
     const long long nwg = 8LL * ((B + 7) / 8) * nbx;
-    hipLaunchKernelGGL((grid_query_kernel<NR>), dim3((unsigned)nwg), dim3(GQ_WAVES * 64), lds, st, new_xyz, ws, prm, N, M, B, nbx);
+    hipLaunchKernelGGL((grid_query_kernel<NR>), dim3((unsigned)nwg), dim3(GQ_WAVES * 64), lds, st, new_xyz, ws, prm, N, M, B, nbx, nsets);
 }
 
 }  // namespace

@@ -6,8 +6,11 @@ import numpy as np, torch
 import sad_amd
 from sad_amd import config, ops, synth
 dev = torch.device("cuda:0")
+from sad_amd import _lib
+if os.environ.get("BQ_VARIANT"): _lib.set_option("bq_variant", int(os.environ["BQ_VARIANT"]))
 cfg = config.KITTI
-pts = torch.from_numpy(synth.make_batch(0, 32)).to(dev)
+dense = len(sys.argv) > 1 and sys.argv[1] == "dense"      # 20 m x 20 m scenes: most centroids have > 128 candidates
+pts = torch.from_numpy((synth.make_dense_batch if dense else synth.make_batch)(0, 32)).to(dev)
 xyz = pts[:, :, :3].contiguous()
 c1 = ops.gather_xyz(xyz, ops.fps(xyz, 4096))
 c2 = c1[:, :1024].contiguous()
@@ -23,5 +26,6 @@ t1 = timeit(lambda: ops.ball_query_multi(st1.radii, st1.nsamples, xyz, c1, retur
 t2 = timeit(lambda: ops.ball_query_multi(st2.radii, st2.nsamples, c1, c2, return_counts=True))
 work = config.work_per_scene(cfg)
 b1 = 32 * sum(16384 * 12 + 4096 * 12 + 4096 * s * 4 for s in st1.nsamples)
+print("dense scenes" if dense else "KITTI-shaped scenes")
 print(f"SA1 ball query (16384 -> 4096 x 3 radii, 32 scenes): {t1:.1f} us = {b1 / t1 / 1e3:.0f} GB/s of algorithmic bytes ({b1 / 1e6:.1f} MB)")
 print(f"SA2 ball query (4096 -> 1024 x 3 radii, 32 scenes): {t2:.1f} us")
