@@ -20,13 +20,19 @@
 
 namespace {
 
-constexpr int GRID_MAXC = 16384;   // cells per scene (LDS histogram: 64 KB)
+constexpr int GRID_MAXC = 32768;   // cells per scene (LDS histogram: 128 KB of the CU's 160 KB; the build runs one workgroup per CU)
+// The cell edge starts at 1.001 r_max and grows by this factor until the grid fits GRID_MAXC cells.  Round 1-3 doubled it
+// with 16 384 cells: a KITTI-shaped scene (70 x 80 x 2 m) at r_max = 0.8 ended with 1.6 m cells — 27 cells = a 4.8 m cube,
+// ~70 candidates per centroid of which ~3 are accepted — where 0.8 m cells (26 400 of them) give ~17.  Any edge >= r_max is
+// exact (header comment); the candidate count goes with its square.
+constexpr float GRID_GROW = 1.18920712f;   // 2^(1/4)
 constexpr int BUILD_T = 1024;
 
 struct GridHdr {      // 16 floats / ints at the start of each scene's workspace block
     float x0, y0, z0, inv;
     int gx, gy, gz, ncell;
-    int pad[8];
+    float invz;           // cell scale along z: `inv`, or 0 when the z split was given up (every point and centroid in layer 0)
+    int pad[7];
 };
 
 __host__ __device__ inline size_t scene_ws_bytes(int N) {
@@ -97,7 +103,6 @@ __global__ __launch_bounds__(BUILD_T) void grid_build_kernel(const float *__rest
     if (lane == 0)
 #pragma unroll
         for (int d = 0; d < 3; ++d) { red[d][wave] = lo[d]; red[3 + d][wave] = hi[d]; }
-    for (int c = tid; c < GRID_MAXC + 64; c += BUILD_T) hist[c] = 0;
     __syncthreads();
 #pragma unroll
     for (int d = 0; d < 3; ++d)
@@ -118,6 +123,7 @@ __global__ __launch_bounds__(BUILD_T) void grid_build_kernel(const float *__rest
     }
     sane = sane && (cs_min > 0.f) && (cs_min < 1.0e30f);
     float cs = cs_min;
+    bool flat = false;
     int gx = 1, gy = 1, gz = 1;
     for (int it = 0; sane; ++it) {
         const float inv = 1.0f / cs;
@@ -131,21 +137,29 @@ __global__ __launch_bounds__(BUILD_T) void grid_build_kernel(const float *__rest
         gy = (int)fy + 1;
         gz = (int)fz + 1;
         if ((long long)gx * gy * gz <= GRID_MAXC) break;
-        cs = cs * 2.0f;
+        // flat scenes (lidar: a few cells high): give up the z split before coarsening x and y — one cell in z keeps the
+        // candidate count of the fine x-y grid (its three z layers were all visited anyway); 128 x 128 x 3 cells of a
+        // 102 m nuScenes-shaped scene at r_max = 0.8 do not fit, 128 x 128 x 1 do
+        if (gz <= 4 && (long long)gx * gy <= GRID_MAXC) { gz = 1; flat = true; break; }
+        cs = cs * GRID_GROW;
     }
     if (!sane) {
         gx = gy = gz = 1;
         lo[0] = lo[1] = lo[2] = 0.f;
     }
     const float inv = sane ? 1.0f / cs : 0.f;
+    const float invz = flat ? 0.f : inv;
     const int ncell = gx * gy * gz;
     if (tid == 0) {
         hdr->x0 = lo[0]; hdr->y0 = lo[1]; hdr->z0 = lo[2]; hdr->inv = inv;
         hdr->gx = gx; hdr->gy = gy; hdr->gz = gz; hdr->ncell = ncell;
+        hdr->invz = invz;
     }
-    // 3. histogram
+    // 3. histogram (only the cells this grid has, rounded up to whole threads of the scan, are ever touched)
+    for (int c = tid; c < BUILD_T * ((ncell + BUILD_T - 1) / BUILD_T); c += BUILD_T) hist[c] = 0;
+    __syncthreads();
     auto cell_of = [&](float x, float y, float z) {
-        int ix = cell_coord(x, lo[0], inv, gx), iy = cell_coord(y, lo[1], inv, gy), iz = cell_coord(z, lo[2], inv, gz);
+        int ix = cell_coord(x, lo[0], inv, gx), iy = cell_coord(y, lo[1], inv, gy), iz = cell_coord(z, lo[2], invz, gz);
         ix = ix < 0 ? 0 : (ix > gx - 1 ? gx - 1 : ix);
         iy = iy < 0 ? 0 : (iy > gy - 1 ? gy - 1 : iy);
         iz = iz < 0 ? 0 : (iz > gz - 1 ? gz - 1 : iz);
@@ -153,15 +167,10 @@ __global__ __launch_bounds__(BUILD_T) void grid_build_kernel(const float *__rest
     };
     for_points([&](int, float x, float y, float z) { atomicAdd(&hist[cell_of(x, y, z)], 1); });
     __syncthreads();
-    // 4. exclusive scan over the cells: thread t owns cells [t*CPT, (t+1)*CPT)
-    constexpr int CPT = GRID_MAXC / BUILD_T;   // 16
-    int loc[CPT];
+    // 4. exclusive scan over the cells of THIS grid (ncell <= GRID_MAXC): thread t owns cells [t*cpt, (t+1)*cpt)
+    const int cpt = (ncell + BUILD_T - 1) / BUILD_T;       // <= GRID_MAXC / BUILD_T = 32
     int sum = 0;
-#pragma unroll
-    for (int k = 0; k < CPT; ++k) {
-        loc[k] = sum;
-        sum += hist[tid * CPT + k];
-    }
+    for (int k = 0; k < cpt; ++k) sum += hist[tid * cpt + k];
     int incl = sum;                             // inclusive scan of `sum` over the wave
     for (int off = 1; off < 64; off <<= 1) {
         const int v = __shfl_up(incl, off, 64);
@@ -171,15 +180,15 @@ __global__ __launch_bounds__(BUILD_T) void grid_build_kernel(const float *__rest
     __syncthreads();
     int wbase = 0;
     for (int w = 0; w < wave; ++w) wbase += wsum[w];
-    const int tbase = wbase + incl - sum;
-#pragma unroll
-    for (int k = 0; k < CPT; ++k) {
-        const int c = tid * CPT + k;
-        const int s = tbase + loc[k];
-        hist[c] = s;                            // becomes the running write offset of the cell
-        cell_start[c] = s;                      // cells >= ncell are empty: start = N
+    int run = wbase + incl - sum;
+    for (int k = 0; k < cpt; ++k) {
+        const int c = tid * cpt + k;
+        const int v = hist[c];
+        hist[c] = run;                          // becomes the running write offset of the cell
+        cell_start[c] = run;                    // (cells in [ncell, BUILD_T * cpt) are empty: start = N; none beyond is ever read)
+        run += v;
     }
-    if (tid == BUILD_T - 1) cell_start[GRID_MAXC] = tbase + sum;   // = N
+    if (tid == BUILD_T - 1) cell_start[BUILD_T * cpt] = run;   // = N (covers cell_start[ncell] when ncell is a multiple of cpt)
     __syncthreads();
     // 5. scatter records (order inside a cell is irrelevant: the query restores index order)
     for_points([&](int j, float x, float y, float z) {
@@ -318,7 +327,7 @@ __global__ __launch_bounds__(GQ_WAVES * 64) __attribute__((amdgpu_waves_per_eu(8
     const GridHdr *hdr = reinterpret_cast<const GridHdr *>(base);
     const int *cell_start = reinterpret_cast<const int *>(base + sizeof(GridHdr));
     const float4 *rec = reinterpret_cast<const float4 *>(base + sizeof(GridHdr) + sizeof(int) * (size_t)(GRID_MAXC + 16));
-    const float x0 = hdr->x0, y0 = hdr->y0, z0 = hdr->z0, inv = hdr->inv;
+    const float x0 = hdr->x0, y0 = hdr->y0, z0 = hdr->z0, inv = hdr->inv, invz = hdr->invz;
     const int gx = hdr->gx, gy = hdr->gy, gz = hdr->gz;
 
     for (int w = threadIdx.x; w < nsets * SETW; w += GQ_WAVES * 64) bm_all[w] = 0u;
@@ -328,19 +337,22 @@ __global__ __launch_bounds__(GQ_WAVES * 64) __attribute__((amdgpu_waves_per_eu(8
     // records) are issued for all of them before any is processed, and the bookkeeping in front of the records is done for
     // all four at once: lane 16 c + r holds run r (of nine: three x-adjacent cells each) of centroid c.
     static_assert(GQ_CPW == 4, "the prologue lays four centroids out in the four rows of 16 lanes");
-    const int m0 = (bx * GQ_WAVES + wave) * GQ_CPW;
     const int mir63 = 4 * (63 - lane), x32 = 4 * (lane ^ 32);
     const int pcen = lane >> 4, prun = lane & 15;
+    float r2[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) r2[r] = prm.radii[r] * prm.radii[r];
+    const int m0 = (bx * GQ_WAVES + wave) * GQ_CPW;
     const int mq = m0 + pcen < M ? m0 + pcen : M - 1;
     const float *qp = new_xyz + ((size_t)b * M + mq) * 3;
     const float qx = qp[0], qy = qp[1], qz = qp[2];
     int rsv = 0, rlv = 0;                       // start / length of this lane's run
     {
-        const int ix = cell_coord(qx, x0, inv, gx), iy = cell_coord(qy, y0, inv, gy), iz = cell_coord(qz, z0, inv, gz);
+        const int ix = cell_coord(qx, x0, inv, gx), iy = cell_coord(qy, y0, inv, gy), iz = cell_coord(qz, z0, invz, gz);
         const int dy = prun % 3 - 1, dz = prun / 3 - 1;
         const int yy = iy + dy, zz = iz + dz;
         const int xlo = ix - 1 < 0 ? 0 : ix - 1, xhi = ix + 1 > gx - 1 ? gx - 1 : ix + 1;
-        if (prun < 9 && yy >= 0 && yy < gy && zz >= 0 && zz < gz && xlo <= xhi) {
+        if (prun < 9 && m0 + pcen < M && yy >= 0 && yy < gy && zz >= 0 && zz < gz && xlo <= xhi) {     // (no runs for a centroid past the end)
             const int c0 = (zz * gy + yy) * gx;
             rsv = cell_start[c0 + xlo];
             rlv = cell_start[c0 + xhi + 1] - rsv;
@@ -366,6 +378,136 @@ __global__ __launch_bounds__(GQ_WAVES * 64) __attribute__((amdgpu_waves_per_eu(8
         }
         return src;
     };
+    // ---- packed path (round 4): the four centroids of the wave in ONE sort ------------------------------------------------
+    // The pair / single paths below sort every CANDIDATE of a centroid (two to four sorts and compactions per wave, and a
+    // nine-step record walk per candidate list: 1 180 vector instructions per wave, rocprofv3) although on lidar-density
+    // scenes only ~15 % of the candidates are accepted by any radius.  Here
+    //  * the runs are expanded through LDS: lane 16 c + r (run r of centroid c) writes the record numbers of its run into
+    //    the wave's table tab[c][offset + i] — a few fire-and-forget ds_write, the four centroids side by side — and the
+    //    candidate lists are then read back one candidate per lane (no record walk, every record load issued at once);
+    //  * a candidate is KEPT only if some radius accepts it: ballot + prefix count give it its place behind the ones kept so
+    //    far, a forward ds_permute moves its key (centroid << 28 | index << 4 | accept bits) there;
+    //  * when the four centroids keep at most 64 points together (the rule on KITTI- and nuScenes-shaped scenes) ONE 64-lane
+    //    sort orders all of them, and per radius a ballot restricted to the lane's own centroid gives the slot.
+    // Waves with a centroid of more than 64 candidates, or more than 64 kept points, take the older paths below.
+    const int Tmax = max(max(T0, T1), max(T2, T3));
+    if (!prm.no_sort && Tmax <= 64) {
+        int *tab = reinterpret_cast<int *>(bm_all + nsets * SETW) + wave * 256;      // [4 centroids][64 candidates]
+        int ml = rlv;                           // longest run of the wave
+        ml = max(ml, __builtin_amdgcn_update_dpp(0, ml, 0xB1, 0xF, 0xF, true));
+        ml = max(ml, __builtin_amdgcn_update_dpp(0, ml, 0x4E, 0xF, 0xF, true));
+        ml = max(ml, __builtin_amdgcn_update_dpp(0, ml, 0x141, 0xF, 0xF, true));
+        ml = max(ml, __builtin_amdgcn_update_dpp(0, ml, 0x140, 0xF, 0xF, true));
+        const int maxlen = max(max(__builtin_amdgcn_readlane(ml, 0), __builtin_amdgcn_readlane(ml, 16)),
+                               max(__builtin_amdgcn_readlane(ml, 32), __builtin_amdgcn_readlane(ml, 48)));
+        int *trow = tab + pcen * 64 + offv;
+        for (int it = 0; it < maxlen; ++it)     // (wave-uniform trip count; offv + rlv <= T <= 64)
+            if (it < rlv) trow[it] = rsv + it;
+        unsigned packed = 0xFFFFFFF0u;          // lane p: the p-th kept key (empty: sorts last, accepted by no radius)
+        int nacc = 0;                           // keys kept so far (wave-uniform)
+        bool fits = true;
+        // (same wave: the table reads below are ordered behind the writes by the LDS queue and the compiler's lgkmcnt wait)
+        const bool pair0 = T0 <= 32 && T1 <= 32, pair1 = T2 <= 32 && T3 <= 32;
+        const int half = lane >> 5, hi = lane & 31;
+        // record numbers and records of all passes first (independent loads: one round trip for the wave), then the keys
+        bool val[4];
+        float4 prs[4];
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const bool paired = p ? pair1 : pair0;
+            const int Ta = p ? T2 : T0, Tb = p ? T3 : T1;
+            if (paired) {
+                val[2 * p] = hi < (half ? Tb : Ta);
+                prs[2 * p] = rec[val[2 * p] ? tab[(2 * p + half) * 64 + hi] : 0];
+                val[2 * p + 1] = false;
+                prs[2 * p + 1] = make_float4(0.f, 0.f, 0.f, 0.f);
+            } else {
+                val[2 * p] = lane < Ta;
+                prs[2 * p] = rec[val[2 * p] ? tab[(2 * p) * 64 + lane] : 0];
+                val[2 * p + 1] = lane < Tb;
+                prs[2 * p + 1] = rec[val[2 * p + 1] ? tab[(2 * p + 1) * 64 + lane] : 0];
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const bool paired = p ? pair1 : pair0;
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) {
+                if (paired && h2) continue;     // (wave-uniform)
+                const int q = 2 * p + h2;
+                if (!paired && (q == 0 ? T0 : q == 1 ? T1 : q == 2 ? T2 : T3) == 0) continue;
+                const float4 pr = prs[q];
+                const int ca = paired ? 2 * p : q, cb = paired ? 2 * p + 1 : q;
+                const float cxa = readlane_f(qx, 16 * ca), cya = readlane_f(qy, 16 * ca), cza = readlane_f(qz, 16 * ca);
+                float cx = cxa, cy = cya, cz = cza;
+                unsigned cidx = (unsigned)ca;
+                if (paired) {
+                    const float cxb = readlane_f(qx, 16 * cb), cyb = readlane_f(qy, 16 * cb), czb = readlane_f(qz, 16 * cb);
+                    cx = half ? cxb : cxa; cy = half ? cyb : cya; cz = half ? czb : cza;
+                    cidx = half ? (unsigned)cb : (unsigned)ca;
+                }
+                const float d = sad::d2f(pr.x, pr.y, pr.z, cx, cy, cz);
+                unsigned acc = 0u;
+#pragma unroll
+                for (int r = 0; r < NR; ++r) acc |= d < r2[r] ? 1u << r : 0u;
+                const bool ok = val[q] && acc != 0u;
+                const unsigned long long bal = __ballot(ok);
+                const int nok = __builtin_popcountll(bal);
+                if (nacc + nok > 64) fits = false;
+                if (fits) {                     // (wave-uniform)
+                    const unsigned key = (cidx << 28) | ((unsigned)__float_as_int(pr.w) << 4) | acc;
+                    const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
+                    // forward permute: lane nacc + rank receives this key; the lanes that keep nothing send theirs to lane
+                    // nacc + nok (mod 64), outside [nacc, nacc + nok) — whatever lands outside that range is discarded
+                    const int dst = ok ? nacc + rank : nacc + nok;
+                    const unsigned got = (unsigned)__builtin_amdgcn_ds_permute(dst << 2, (int)key);
+                    packed = (unsigned)(lane - nacc) < (unsigned)nok ? got : packed;
+                    nacc += nok;
+                }
+            }
+        }
+        if (fits) {
+            const unsigned key = bitonic_sort64(packed, mir63);
+            const int jidx = (int)((key >> 4) & 0x00FFFFFFu);
+            const unsigned cl = key >> 28;      // the lane's centroid (15: an empty lane)
+            // the lanes of each centroid (contiguous after the sort), and per lane the mask of its own centroid's lanes
+            unsigned long long seg[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) seg[c] = __ballot(cl == (unsigned)c);
+            unsigned mlo = 0u, mhi = 0u;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                mlo = cl == (unsigned)c ? (unsigned)seg[c] : mlo;
+                mhi = cl == (unsigned)c ? (unsigned)(seg[c] >> 32) : mhi;
+            }
+            const unsigned cm = cl < 4u ? cl : 0u;
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                const int S = prm.nsample[r];
+                int32_t *out0 = prm.idx[r] + ((size_t)b * M + m0) * S;
+                const bool ok = (key >> r) & 1u;
+                const unsigned long long bal = __ballot(ok);
+                const unsigned slot = __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32) & mhi, __builtin_amdgcn_mbcnt_lo((unsigned)bal & mlo, 0u));
+                if (ok && slot < (unsigned)S) out0[cm * (unsigned)S + slot] = jidx;
+                // SPEC.md §3 padding: the remaining slots repeat the first (lowest) accepted index; none accepted: zeros
+                int tot[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    if (m0 + c >= M) { tot[c] = 0; continue; }      // (wave-uniform)
+                    const unsigned long long bc = bal & seg[c];
+                    const int total = __builtin_popcountll(bc);
+                    int first = 0;
+                    if (bc) first = __builtin_amdgcn_readlane(jidx, __builtin_ctzll(bc));
+                    if (lane >= total && lane < S) out0[c * S + lane] = first;       // (nsample <= 64: one store covers the row)
+                    tot[c] = total < S ? total : S;
+                }
+                if (prm.cnt[r] && lane < 4 && m0 + lane < M)
+                    prm.cnt[r][(size_t)b * M + m0 + lane] = lane == 0 ? tot[0] : lane == 1 ? tot[1] : lane == 2 ? tot[2] : tot[3];
+            }
+            return;
+        }
+    }
+
     // Two neighbouring centroids with at most 32 candidates each (most pairs of a lidar-density scene: mean 20) share ONE pass:
     // lanes 0..31 carry the first, lanes 32..63 the second — keys, a 32-lane sort per half and the compaction cost the same
     // instructions for two centroids as for one.
@@ -387,9 +529,6 @@ __global__ __launch_bounds__(GQ_WAVES * 64) __attribute__((amdgpu_waves_per_eu(8
             prb[p] = rec[lane < Tb ? record_of(2 * p + 1, lane) : 0];
         }
     }
-    float r2[NR];
-#pragma unroll
-    for (int r = 0; r < NR; ++r) r2[r] = prm.radii[r] * prm.radii[r];
     // ONE copy of the per-pair code (the records rotate through registers): unrolled, the kernel was 160 KB of instructions,
     // more than the instruction cache two CUs share
 #pragma unroll 1
@@ -566,7 +705,7 @@ void launch_query(const float *new_xyz, const char *ws, const GQParams &prm, int
     const size_t set_bytes = sizeof(unsigned) * ((size_t)NR * (WPL * 64 + 64) + 1);
     // (eight workgroups per CU keep their 160 KB / 8 each; bq_variant = 2: one set, the round-3 layout, for A/B runs)
     const int nsets = (2 * set_bytes <= 20 * 1024 && sad::get_option(sad::OPT_BQ_VARIANT) != 2) ? 2 : 1;
-    const size_t lds = set_bytes * nsets;
+    const size_t lds = set_bytes * nsets + sizeof(int) * GQ_WAVES * 4 * 64;      // + the packed path's candidate tables
     const int nbx = (M + GQ_WAVES * GQ_CPW - 1) / (GQ_WAVES * GQ_CPW);
     const long long nwg = 8LL * ((B + 7) / 8) * nbx;
     hipLaunchKernelGGL((grid_query_kernel<NR>), dim3((unsigned)nwg), dim3(GQ_WAVES * 64), lds, st, new_xyz, ws, prm, N, M, B, nbx, nsets);
@@ -604,13 +743,13 @@ SAD_API int sad_ball_query_grid_f32(const float *xyz, const float *new_xyz, int 
     static std::atomic<uint64_t> attr_done0{0}, attr_done4{0}, attr_done16{0};
     const size_t blds = sizeof(int) * (GRID_MAXC + 64);
     if (N <= 4 * BUILD_T) {
-        sad::lds_attr_once(attr_done4, reinterpret_cast<const void *>(&grid_build_kernel<4>), 96 * 1024);
+        sad::lds_attr_once(attr_done4, reinterpret_cast<const void *>(&grid_build_kernel<4>), 144 * 1024);
         hipLaunchKernelGGL(grid_build_kernel<4>, dim3(B), dim3(BUILD_T), blds, st, xyz, N, rmax * 1.001f, (char *)workspace);
     } else if (N <= 16 * BUILD_T) {
-        sad::lds_attr_once(attr_done16, reinterpret_cast<const void *>(&grid_build_kernel<16>), 96 * 1024);
+        sad::lds_attr_once(attr_done16, reinterpret_cast<const void *>(&grid_build_kernel<16>), 144 * 1024);
         hipLaunchKernelGGL(grid_build_kernel<16>, dim3(B), dim3(BUILD_T), blds, st, xyz, N, rmax * 1.001f, (char *)workspace);
     } else {
-        sad::lds_attr_once(attr_done0, reinterpret_cast<const void *>(&grid_build_kernel<0>), 96 * 1024);
+        sad::lds_attr_once(attr_done0, reinterpret_cast<const void *>(&grid_build_kernel<0>), 144 * 1024);
         hipLaunchKernelGGL(grid_build_kernel<0>, dim3(B), dim3(BUILD_T), blds, st, xyz, N, rmax * 1.001f, (char *)workspace);
     }
     if (int e = sad::check_launch("sad_ball_query_grid_f32 (build)")) return e;

@@ -170,6 +170,30 @@ def test_ball_query_grid_duplicates_and_plane(orc, sad, dev):
         np.testing.assert_array_equal(got, orc.ball_query(r, s, xyz, new_xyz))
 
 
+def test_ball_query_grid_flat_scene_gives_up_the_z_split(orc, sad, dev):
+    """A wide, thin cloud whose fine grid does not fit the cell table: the build keeps the fine x-y cells and puts every
+    point and centroid in ONE z layer (round 4; 100 m x 100 m x 2.2 m at r_max = 0.8 -> 126 x 126 x 1 cells).  The first
+    version of that change left the centroids' z cell uncollapsed — balls of the upper layers came out empty — and no test
+    had a flat scene large enough to notice; centroids above, below and beside the cloud are queried as well."""
+    from sad_amd import ops
+    rng = np.random.default_rng(41)
+    N, M = 20000, 600
+    xyz = np.empty((2, N, 3), np.float32)
+    xyz[:, :, 0] = rng.uniform(-50, 50, (2, N))
+    xyz[:, :, 1] = rng.uniform(-50, 50, (2, N))
+    xyz[:, :, 2] = rng.uniform(-2.0, 0.2, (2, N))
+    new_xyz = np.ascontiguousarray(xyz[:, ::N // M][:, :M]).copy()
+    new_xyz[:, 0:40, 2] += 0.5               # above the cloud's top layer (still within reach of it)
+    new_xyz[:, 40:80, 2] -= 0.5              # below its bottom layer
+    new_xyz[:, 80:100, 0] = 50.3             # just outside in x
+    radii, ns = (0.2, 0.4, 0.8), (32, 32, 64)
+    outs = ops.ball_query_multi(radii, ns, _t(xyz, dev), _t(new_xyz, dev), return_counts=True)
+    for o, c, r, s in zip(outs[0], outs[1], radii, ns):
+        want = orc.ball_query(r, s, xyz, new_xyz)
+        np.testing.assert_array_equal(o.cpu().numpy(), want)
+    assert int(outs[1][2].max()) > 1, "the widest ball should hold several points somewhere"
+
+
 def test_ball_query_adaptive_and_multi(orc, sad, dev):
     from sad_amd import ops, synth
     g = np.load(os.path.join(GOLDEN, "adaptive.npz"))
