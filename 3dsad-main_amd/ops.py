@@ -27,7 +27,7 @@ def _stream() -> int:
 # C-ABI call with HIP events recorded on the stream the kernel is launched on and appends
 # (kind, name, start_event, end_event).  None (the default) adds nothing to the launch path.
 LAUNCH_LOG: Optional[list] = None
-# When a list, every f32 MLP dispatch appends (name, fn): fn() enqueues the SAME dispatch again (same arguments; the
+# When a list, every MLP dispatch appends (name, fn): fn() enqueues the SAME dispatch again (same arguments; the
 # tensors it reads are kept alive by the entry).  bench.py re-times the dispatches of a step back to back with it.
 RERUN_LOG: Optional[list] = None
 
@@ -665,6 +665,10 @@ def grouped_multi(calls) -> None:
         if bf16:
             arr = (ctypes.POINTER(_lib.MlpBf16Args) * len(args))(*[ctypes.pointer(a) for a in args])
             check(lib().sad_mlp_chain_multi_bf16(arr, len(args), _stream()), "sad_mlp_chain_multi_bf16")
+            if RERUN_LOG is not None:
+                outs = [c[5] for c in calls]
+                RERUN_LOG.append(("+".join(c[0].name for c in calls), lambda arr=arr, args=args, keep=(keep, outs): check(
+                    lib().sad_mlp_chain_multi_bf16(arr, len(args), _stream()), "sad_mlp_chain_multi_bf16")))
         else:
             arr = (ctypes.POINTER(MlpArgs) * len(args))(*[ctypes.pointer(a) for a in args])
             check(lib().sad_mlp_chain_multi_f32(arr, len(args), _stream()), "sad_mlp_chain_multi_f32")
@@ -807,7 +811,7 @@ class PackedMLPBf16:
         rows of each group are computed — the ball query's padding rows cannot change the max.
         ``ws``: the row-packing table of (idx, cnt) from ``rowscan_multi`` (geometry 2 then launches no scan)."""
         a, out, _keep = self._grouped_args(xyz, feat_pm, new_xyz, idx, out, col_off, cnt, ws)
-        self._launch(a)
+        self._launch(a, _keep + [out])
         return out
 
     def _grouped_args(self, xyz, feat_pm, new_xyz, idx, out, col_off, cnt, ws=None):
@@ -861,8 +865,9 @@ class PackedMLPBf16:
             a.prescanned = 1
         return a, out, keep
 
-    def _launch(self, a) -> None:
-        """Enqueue; with AUTOTUNE on, the first call for a shape times 64 / 128 / 256 rows per tile."""
+    def _launch(self, a, keep=None) -> None:
+        """Enqueue; with AUTOTUNE on, the first call for a shape times 64 / 128 / 256 rows per tile.  ``keep``: tensors the
+        launch reads or writes (kept alive by a RERUN_LOG entry)."""
         key = (bool(a.idx), a.B, a.N, a.M, a.S, a.ld_out)
         geom = self._geom.get(key)
         preferred = a.geometry          # the un-tuned choice of _grouped_args (0 while autotuning)
@@ -892,6 +897,9 @@ class PackedMLPBf16:
         a.geometry = geom or self.default_geometry or preferred
         with _timed("mlp", self.name):
             check(lib().sad_mlp_chain_bf16(ctypes.byref(a), _stream()), "sad_mlp_chain_bf16")
+        if RERUN_LOG is not None:
+            RERUN_LOG.append((self.name, lambda a=a, keep=keep: check(
+                lib().sad_mlp_chain_bf16(ctypes.byref(a), _stream()), "sad_mlp_chain_bf16")))
 
     def rows(self, x: torch.Tensor, out: Optional[torch.Tensor] = None, col_off: int = 0,
              out_dtype=torch.float32) -> torch.Tensor:
@@ -916,7 +924,7 @@ class PackedMLPBf16:
         a.B, a.N, a.M, a.S, a.C = 1, 0, R, 1, C
         a.out, a.out_bf16 = out.data_ptr(), int(out.dtype == torch.bfloat16)
         a.ld_out, a.col_off = out.stride(-2), col_off
-        self._launch(a)
+        self._launch(a, [x2, out])
         return out
 
 

@@ -3,7 +3,8 @@
 Units and corrections as /opt/skills/guides/MI355X_MICROARCH.md prescribes: both counters are in KiB... (see `note`)."""
 import csv, glob, json, os, sys
 root, out = sys.argv[1], sys.argv[2]
-MLP = ("mlp_reg_kernel", "mlp_coop_kernel", "mlp_layer_kernel", "mlp_chain_kernel", "mlp_chain2_kernel", "mlp_multi_kernel", "mlp_rows_kernel", "rowscan_")
+def is_mlp(n):      # every MLP kernel of either arithmetic + the row-packing scans (not the one-off weight packing)
+    return ("mlp_" in n or "bf16_rows_kernel" in n or "rowscan_" in n) and "pack_kernel" not in n
 def total(passname, counter):
     tot, steps = 0.0, 0
     for f in glob.glob(os.path.join(root, passname, "*", "*_counter_collection.csv")) + glob.glob(os.path.join(root, "pmc_" + passname, "*", "*_counter_collection.csv")):
@@ -11,9 +12,9 @@ def total(passname, counter):
             if r["Counter_Name"] != counter:
                 continue
             n = r["Kernel_Name"]
-            if "fps_cell_kernel" in n or "fps_cellg_kernel" in n:
-                steps += 1          # one per forward pass
-            if any(k in n for k in MLP):
+            if "fps_cell" in n:     # fps_cell / fps_cell2 / fps_cellg / fps_cellg2: one per forward pass
+                steps += 1
+            if is_mlp(n):
                 tot += float(r["Counter_Value"])
     return tot, steps
 fetch, s1 = total("fetch", "FETCH_SIZE")
@@ -21,8 +22,7 @@ write, s2 = total("write", "WRITE_SIZE")
 # FETCH_SIZE / WRITE_SIZE are reported in kilobytes; on gfx950 FETCH_SIZE counts 32-byte requests as 64-byte units
 # halved, i.e. the raw value is doubled (MI355X_MICROARCH.md, HBM section) — same correction as in round 1
 res = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes, tools/profile_r03.sh pmc / tools/pmc.sh: bench.py --geometry-file "
-                 "<geometry of the run> --main-streams 1 --steps 3 --warmup 1), summed over the MLP dispatches (mlp_reg / mlp_coop / mlp_layer / "
-                 "mlp_chain / mlp_multi / mlp_rows kernels + their row-packing scans) and divided by the forward passes of the run; FETCH_SIZE doubled "
+                 "<geometry of the run> --main-streams 1 --steps 3 --warmup 1), summed over the MLP dispatches (every mlp_* / bf16_rows kernel + the row-packing scans) and divided by the forward passes of the run; FETCH_SIZE doubled "
                  "per the gfx950 correction of MI355X_MICROARCH.md (HBM section); gather-width reads uncalibrated",
        "forward_passes": s1,
        "fetch_size_raw_kb_per_step": fetch / max(1, s1),
