@@ -330,8 +330,11 @@ __global__ __launch_bounds__(GQ_WAVES * 64) __attribute__((amdgpu_waves_per_eu(8
     const float x0 = hdr->x0, y0 = hdr->y0, z0 = hdr->z0, inv = hdr->inv, invz = hdr->invz;
     const int gx = hdr->gx, gy = hdr->gy, gz = hdr->gz;
 
-    for (int w = threadIdx.x; w < nsets * SETW; w += GQ_WAVES * 64) bm_all[w] = 0u;
+    // Only the lock words are initialised here; a bitmap set is zeroed by the first wave that takes it (under its lock): the
+    // sort paths never touch the sets, and zeroing 14 KB per workgroup cost every wave ~60 vector instructions of its ~700.
+    if (threadIdx.x < (unsigned)nsets) bm_all[threadIdx.x * SETW + NR * (NWP + 64)] = 0u;
     __syncthreads();
+    bool set_clean = false;                     // this wave has zeroed (or already used and cleaned) its set
 
     // The wave's GQ_CPW = 4 centroids are independent: their dependent memory round trips (centroid -> cell starts -> first
     // records) are issued for all of them before any is processed, and the bookkeeping in front of the records is done for
@@ -641,6 +644,11 @@ __global__ __launch_bounds__(GQ_WAVES * 64) __attribute__((amdgpu_waves_per_eu(8
             if (lane == 0)
                 while (atomicCAS(lock, 0u, 1u) != 0u) __builtin_amdgcn_s_sleep(4);
             __threadfence_block();
+            if (!set_clean) {                       // (wave-uniform) first use by this wave: whatever LDS held before, or what a
+                for (int w = lane; w < NR * (NWP + 64); w += 64) bm[w] = 0u;     // sibling left clean, becomes zero
+                __threadfence_block();
+                set_clean = true;
+            }
             for (int i0 = 0; i0 < T; i0 += 64) {
                 const int i = i0 + lane;
                 const bool valid = i < T;
