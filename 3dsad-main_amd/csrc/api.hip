@@ -42,7 +42,6 @@ SAD_API int sad_set_option(const char *key, int value) {
     if (!strcmp(key, "mlp_layer_queue")) { sad::g_opt[sad::OPT_MLP_LAYER_QUEUE].store(value, std::memory_order_relaxed); return SAD_OK; }
     if (!strcmp(key, "mlp_check_inuse")) { sad::g_opt[sad::OPT_MLP_CHECK_INUSE].store(value, std::memory_order_relaxed); return SAD_OK; }
     if (!strcmp(key, "group_variant")) { sad::g_opt[sad::OPT_GROUP_VARIANT].store(value, std::memory_order_relaxed); return SAD_OK; }   // 1 = L2-gather kernel only
-    if (!strcmp(key, "bq_blocks")) { sad::g_opt[sad::OPT_BQ_BLOCKS].store(value, std::memory_order_relaxed); return SAD_OK; }
     if (!strcmp(key, "bq_variant")) { sad::g_opt[sad::OPT_BQ_VARIANT].store(value, std::memory_order_relaxed); return SAD_OK; }
     if (!strcmp(key, "fps_threads")) { sad::g_opt[sad::OPT_FPS_THREADS].store(value, std::memory_order_relaxed); return SAD_OK; }
     if (!strcmp(key, "fps_variant")) { sad::g_opt[sad::OPT_FPS_VARIANT].store(value, std::memory_order_relaxed); return SAD_OK; }

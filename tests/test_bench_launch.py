@@ -82,3 +82,36 @@ def test_parent_launches_before_importing_torch():
         rec = json.loads(r.stdout.strip())
         assert rec["argv"][:2] == ["--nnodes=1", "--nproc-per-node=2"]
         assert rec["argv"][-6:] == ["--gpus", "2", "--steps", "20", "--warmup", "5"]
+
+
+def test_bench_batch_rotation_and_workload_defaults():
+    """Round 4: the timed region rotates over distinct resident batches; no scene is shared between the batches of a rank or
+    between ranks; the secondary legs keep their own stream plan.  Pure host logic (no torch, no GPU)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", BENCH)
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    B, world = 32, 8
+    seen = set()
+    for rank in range(world):
+        for k in range(4):
+            first = b.batch_first_scene(k, rank, world, B)
+            scenes = set(range(first, first + B))
+            assert not (scenes & seen)
+            seen |= scenes
+    assert len(seen) == world * 4 * B
+    w = b.Workload("kitti", "kitti", "f32", 32)
+    assert (w.fps_streams, w.main_streams, w.queue_depth, w.n_batches) == (3, 2, 6, 4)
+    w = b.Workload("nuscenes", "kitti", "bf16", 32, n_batches=2)
+    assert (w.fps_streams, w.queue_depth, w.n_batches) == (6, 8, 2) and w.peak() == b.PEAK_MFMA_BF16_TFLOPS
+    assert "nuScenes" in w.describe() and "configs[4]" in w.describe()
+    res = {"metric": "m", "value": 1.0, "unit": "scenes/s", "steps": 3, "warmup": 1, "ms_per_step": 2.0, "dtype": "bf16",
+           "config": {"workload": "w", "fps_streams": 6, "scenes_per_gpu": 32},
+           "roofline": {"bound": "mfma", "achieved": 1.0, "peak": 2.0, "unit": "TFLOP/s", "frac": 0.5, "traffic": None, "flop_per_step": 1,
+                        "ms_per_step": 1.0, "ms_per_step_uncorrected": 1.1, "event_pair_ms": 0.003, "frac_source": "back_to_back",
+                        "in_step": {"frac": 0.4}},
+           "kernels": [{"kernel": "fps_sort_kernel + ...", "ms_per_step": 2.0, "cu_ms_per_step": 64.0, "us_per_serial_step": 0.5},
+                       {"kernel": "ball query: ...", "ms_per_step": 0.15, "frac": 0.1}]}
+    leg = b.leg_record(res)
+    assert leg["roofline"]["frac"] == 0.5 and leg["roofline"]["in_step_frac"] == 0.4 and leg["fps_cu_ms_per_step"] == 64.0
+    assert leg["ball_query_hbm_frac"] == 0.1 and leg["mlp_ms_per_step"] == 1.0

@@ -194,6 +194,36 @@ def test_ball_query_grid_flat_scene_gives_up_the_z_split(orc, sad, dev):
     assert int(outs[1][2].max()) > 1, "the widest ball should hold several points somewhere"
 
 
+def test_ball_query_grid_packed_path_and_its_fallbacks(orc, sad, dev):
+    """The packed path of the grid query (round 4: the four centroids of a wave keep only ACCEPTED candidates and share one
+    sort) and both ways out of it: tight clusters of duplicated points make every candidate an accepted one, so a wave of
+    four 10-point clusters packs 40 keys (success, nothing rejected), four 40-point clusters keep 160 (more than 64: the
+    pair / single sorts take over), and 70-point clusters exceed the 64-candidate table (straight to the older paths).
+    Cluster sizes are mixed along the centroid order so that waves see every combination."""
+    from sad_amd import ops
+    rng = np.random.default_rng(64)
+    sizes = [10, 40, 70, 3, 32, 33, 64, 65, 1, 20]
+    pts, cen = [], []
+    for c in range(260):
+        n = sizes[c % len(sizes)]
+        centre = np.array([3.0 * (c % 20), 3.0 * (c // 20), 0.5 * (c % 3)], np.float32)      # clusters 3 m apart
+        jitter = rng.uniform(-0.05, 0.05, (n, 3)).astype(np.float32)
+        jitter[: n // 2] = jitter[0]                                                         # half of them exact duplicates
+        pts.append(centre + jitter)
+        cen.append(centre)
+    xyz = np.concatenate(pts, 0)
+    perm = rng.permutation(len(xyz))                 # cell order != index order
+    xyz = np.ascontiguousarray(xyz[perm][None])
+    assert xyz.shape[1] >= ops.GRID_MIN_POINTS
+    new_xyz = np.ascontiguousarray(np.stack(cen, 0)[None])
+    radii, ns = (0.05, 0.2, 0.8), (16, 32, 64)
+    outs, cnts = ops.ball_query_multi(radii, ns, _t(xyz, dev), _t(new_xyz, dev), return_counts=True)
+    for o, c, r, s in zip(outs, cnts, radii, ns):
+        want = orc.ball_query(r, s, xyz, new_xyz)
+        np.testing.assert_array_equal(o.cpu().numpy(), want)
+    assert int(cnts[2].max()) == 64 and int(cnts[2].min()) == 1
+
+
 def test_ball_query_adaptive_and_multi(orc, sad, dev):
     from sad_amd import ops, synth
     g = np.load(os.path.join(GOLDEN, "adaptive.npz"))

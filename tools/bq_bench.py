@@ -8,7 +8,6 @@ from sad_amd import config, ops, synth
 dev = torch.device("cuda:0")
 from sad_amd import _lib
 if os.environ.get("BQ_VARIANT"): _lib.set_option("bq_variant", int(os.environ["BQ_VARIANT"]))
-if os.environ.get("BQ_BLOCKS"): _lib.set_option("bq_blocks", int(os.environ["BQ_BLOCKS"]))
 cfg = config.KITTI
 dense = len(sys.argv) > 1 and sys.argv[1] == "dense"      # 20 m x 20 m scenes: most centroids have > 128 candidates
 nus = len(sys.argv) > 1 and sys.argv[1] == "nus"          # nuScenes-shaped: 65 536 points on 102 m x 102 m, 16 384 / 4 096 centroids
