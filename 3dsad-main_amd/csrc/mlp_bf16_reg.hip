@@ -40,7 +40,16 @@ constexpr int WHOLE_BIT = 1 << 30;
 constexpr int RS = SAD_BR_RS;        // fragments (1 KB each) per ring stage
 constexpr int RNS = 3;               // ring slots: being read / complete / being written
 constexpr int RING_F4 = RNS * RS * 64;
-constexpr int PFD = SAD_BR_PFD;      // ring reads run this many fragments ahead of the MFMA that consumes them
+constexpr int PFD_DEFAULT = SAD_BR_PFD;   // ring reads run this many fragments ahead of the MFMA that consumes them
+#ifndef SAD_BR_F2
+#define SAD_BR_F2 3
+#endif
+#ifndef SAD_BR_PFD2
+#define SAD_BR_PFD2 2
+#endif
+// SA3 family: three workgroups per CU (168 registers) with reads two fragments ahead — 107 us against 121 with two workgroups of 207
+// registers and four ahead on the KITTI-shaped batch (three workgroups at four ahead: 113, 19 registers spilled instead of 10)
+__host__ __device__ constexpr int pfd_of(int family) { return family == 2 ? SAD_BR_PFD2 : PFD_DEFAULT; }
 // Staged pooled output.  A wave owns 4 KB of LDS: STAGE_F floats = slots x CB channels, slot = ordinal of a group inside
 // the tile, CB = 128 / 64 / 32 channels per block for tiles with <= 8 / 16 / 32 groups.  EVERY row of an output tile
 // max-combines into its group's slot with one LDS atomic per register (ds_max_u32 on the bit patterns: values are >= +0
@@ -118,7 +127,7 @@ __device__ __forceinline__ NextRows fetch_rows(const BfRegChain &c, int tile, in
 
 // STATICW: the chain's whole fragment stream sits in LDS for the lifetime of the workgroup (the narrow first-stage chains:
 // 3 - 22 fragments) — no ring, no barriers, the waves of a workgroup are independent; `rs.ring` then points at that image.
-template <int KS0, int NO0, int NO1, int NO2, bool VEC0, int NW, bool STATICW>
+template <int KS0, int NO0, int NO1, int NO2, bool VEC0, int NW, bool STATICW, int PFD>
 __device__ __forceinline__ void br_tile(const BfRegChain &c, const int tile, const float *__restrict__ sbias, const int lane, const int wave,
                                         Ring &rs, const float4 *__restrict__ sbase, const float4 *__restrict__ nbase, float *stage,
                                         const int total, NextRows &rows, const BfRegChain &nc, const int ntile, const int ntotal) {
@@ -317,10 +326,16 @@ __device__ __forceinline__ void br_tile(const BfRegChain &c, const int tile, con
         SAD_BACC(6, tk1, tk0);
 #endif
         // register i of this lane half = row 16h + i of the tile, channel 32 o + r
+#ifdef SAD_BR_ABL       // measurement builds (tools/probe/build_variant.sh): 1 no pooling atomics, 2 no flush, 3 neither (wrong results)
+        if (SAD_BR_ABL == 3) { asm volatile("" :: "v"(acc)); return; }
+#endif
         if (pi.ngroups > 0) {
             const int nobm = (1 << (pi.cbs - 5)) - 1;               // output tiles per block - 1
             const int ob = o & nobm;
             char *sp = reinterpret_cast<char *>(stage) + 128 * ob;
+#ifdef SAD_BR_ABL
+            if (SAD_BR_ABL == 1) { asm volatile("" :: "v"(acc)); } else
+#endif
             if (pi.kind == 1) {
                 // each half of the tile lies inside one group: a plain max chain across the registers, one LDS atomic per half
                 float m = relu1(acc[0]);
@@ -337,6 +352,9 @@ __device__ __forceinline__ void br_tile(const BfRegChain &c, const int tile, con
                     atomicMax(reinterpret_cast<unsigned *>(sp + pi.soff[i]), __builtin_bit_cast(unsigned, v));      // ds_max_u32
                 }
             }
+#ifdef SAD_BR_ABL
+            if (SAD_BR_ABL == 2) return;
+#endif
             if (ob == nobm) {
                 // block complete: every group leaves as one row of CB channels, then its slot is zero again
                 const int cbs = pi.cbs;
@@ -346,24 +364,45 @@ __device__ __forceinline__ void br_tile(const BfRegChain &c, const int tile, con
                 for (int s0 = 0; s0 < pi.ngroups; s0 += 64 >> (cbs - 2)) {       // (wave-uniform)
                     const int sidx = s0 + (lane >> (cbs - 2));
                     float4 *src = reinterpret_cast<float4 *>(stage + (s0 << cbs)) + lane;
-                    if (sidx < pi.ngroups) {
+#if defined(SAD_BR_ABL) && SAD_BR_ABL == 4      // (4: plain stores where a group continues in another tile, 5: no global stores at all)
+                    const bool whole = true;
+#else
+                    const bool whole = (sidx > 0 || pi.whole_first) && (sidx < pi.ngroups - 1 || pi.whole_last);
+#endif
+                    if (sidx < pi.ngroups && whole) {
                         const float4 v = *src;
                         *src = make_float4(0.f, 0.f, 0.f, 0.f);
-                        const bool whole = (sidx > 0 || pi.whole_first) && (sidx < pi.ngroups - 1 || pi.whole_last);
+#if defined(SAD_BR_ABL) && SAD_BR_ABL == 5
+                        asm volatile("" :: "v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
+                        continue;
+#endif
                         float *orow = c_out + (long long)(pi.g_first + sidx) * ldo + col_off + ch;
-                        if (whole && vec_out && ch + 3 < cout_last) {
+                        if (vec_out && ch + 3 < cout_last) {
                             *reinterpret_cast<float4 *>(orow) = v;
                         } else if (ch < cout_last) {
                             const float e[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-                            for (int k = 0; k < 4; ++k) {
-                                if (ch + k >= cout_last) continue;
-                                if (whole) orow[k] = e[k];
-                                else atomic_max_pos(orow + k, e[k]);
-                            }
+                            for (int k = 0; k < 4; ++k)
+                                if (ch + k < cout_last) orow[k] = e[k];
                         }
                     }
                 }
+                // the first / last group of the tile when it continues in another tile: an atomic max per channel, one channel
+                // per lane — an instruction then covers 64 consecutive floats (four per lane at a 16-byte stride touched every
+                // 64-byte line of the row four times: the atomics cost ~10 % of every dispatch that way)
+                auto combine = [&](const int sidx) {
+                    float *srow = stage + (sidx << cbs);
+                    float *orow = c_out + (long long)(pi.g_first + sidx) * ldo + col_off + ch0;
+                    for (int cc = lane; cc < (1 << cbs); cc += 64) {
+                        const float v = srow[cc];
+                        srow[cc] = 0.f;
+                        if (ch0 + cc < cout_last) atomic_max_pos(orow + cc, v);
+                    }
+                };
+#if !defined(SAD_BR_ABL) || SAD_BR_ABL != 4
+                if (!pi.whole_first) combine(0);
+                if (!pi.whole_last && pi.ngroups > 1) combine(pi.ngroups - 1);
+#endif
             }
         }
 #ifdef SAD_BR_STAMPS
@@ -404,26 +443,26 @@ __device__ __forceinline__ void run_br(const BfRegChain &c, int shape, int tile,
                                        const float4 *sbase, const float4 *nbase, float *stage, int total, NextRows &rows,
                                        const BfRegChain &nc, int ntile, int ntotal) {
     if constexpr (FAMILY == 0) {
-        if (shape == 0) br_tile<1, 1, 1, 1, false, NW, true>(c, tile, sb, lane, wave, rs, sbase, nbase, stage, total, rows, nc, ntile, ntotal);
-        else if (shape == 1) br_tile<1, 1, 1, 2, false, NW, true>(c, tile, sb, lane, wave, rs, sbase, nbase, stage, total, rows, nc, ntile, ntotal);
-        else br_tile<1, 2, 2, 4, false, NW, true>(c, tile, sb, lane, wave, rs, sbase, nbase, stage, total, rows, nc, ntile, ntotal);
+        if (shape == 0) br_tile<1, 1, 1, 1, false, NW, true, pfd_of(FAMILY)>(c, tile, sb, lane, wave, rs, sbase, nbase, stage, total, rows, nc, ntile, ntotal);
+        else if (shape == 1) br_tile<1, 1, 1, 2, false, NW, true, pfd_of(FAMILY)>(c, tile, sb, lane, wave, rs, sbase, nbase, stage, total, rows, nc, ntile, ntotal);
+        else br_tile<1, 2, 2, 4, false, NW, true, pfd_of(FAMILY)>(c, tile, sb, lane, wave, rs, sbase, nbase, stage, total, rows, nc, ntile, ntotal);
     } else if constexpr (FAMILY == 1) {
-        if (shape == 2) br_tile<5, 2, 2, 4, true, NW, false>(c, tile, sb, lane, wave, rs, sbase, nbase, stage, total, rows, nc, ntile, ntotal);
-        else br_tile<5, 2, 3, 4, true, NW, false>(c, tile, sb, lane, wave, rs, sbase, nbase, stage, total, rows, nc, ntile, ntotal);
+        if (shape == 2) br_tile<5, 2, 2, 4, true, NW, false, pfd_of(FAMILY)>(c, tile, sb, lane, wave, rs, sbase, nbase, stage, total, rows, nc, ntile, ntotal);
+        else br_tile<5, 2, 3, 4, true, NW, false, pfd_of(FAMILY)>(c, tile, sb, lane, wave, rs, sbase, nbase, stage, total, rows, nc, ntile, ntotal);
     } else if constexpr (FAMILY == 2) {
-        if (shape == 4) br_tile<9, 4, 4, 8, true, NW, false>(c, tile, sb, lane, wave, rs, sbase, nbase, stage, total, rows, nc, ntile, ntotal);
-        else if (shape == 5) br_tile<9, 4, 6, 8, true, NW, false>(c, tile, sb, lane, wave, rs, sbase, nbase, stage, total, rows, nc, ntile, ntotal);
-        else br_tile<9, 4, 8, 8, true, NW, false>(c, tile, sb, lane, wave, rs, sbase, nbase, stage, total, rows, nc, ntile, ntotal);
+        if (shape == 4) br_tile<9, 4, 4, 8, true, NW, false, pfd_of(FAMILY)>(c, tile, sb, lane, wave, rs, sbase, nbase, stage, total, rows, nc, ntile, ntotal);
+        else if (shape == 5) br_tile<9, 4, 6, 8, true, NW, false, pfd_of(FAMILY)>(c, tile, sb, lane, wave, rs, sbase, nbase, stage, total, rows, nc, ntile, ntotal);
+        else br_tile<9, 4, 8, 8, true, NW, false, pfd_of(FAMILY)>(c, tile, sb, lane, wave, rs, sbase, nbase, stage, total, rows, nc, ntile, ntotal);
     } else {
-        if (shape == 8) br_tile<17, 8, 8, 16, true, NW, false>(c, tile, sb, lane, wave, rs, sbase, nbase, stage, total, rows, nc, ntile, ntotal);
-        else br_tile<17, 8, 16, 32, true, NW, false>(c, tile, sb, lane, wave, rs, sbase, nbase, stage, total, rows, nc, ntile, ntotal);
+        if (shape == 8) br_tile<17, 8, 8, 16, true, NW, false, pfd_of(FAMILY)>(c, tile, sb, lane, wave, rs, sbase, nbase, stage, total, rows, nc, ntile, ntotal);
+        else br_tile<17, 8, 16, 32, true, NW, false, pfd_of(FAMILY)>(c, tile, sb, lane, wave, rs, sbase, nbase, stage, total, rows, nc, ntile, ntotal);
     }
 }
 
 constexpr int BR_NW = 4;
 
 template <int FAMILY>
-__global__ __launch_bounds__(BR_NW * 64, FAMILY == 0 ? 4 : (FAMILY == 1 ? 3 : 2)) void mlp_bf16_reg_kernel(const BfRegMulti mp) {
+__global__ __launch_bounds__(BR_NW * 64, FAMILY == 0 ? 4 : (FAMILY == 1 ? 3 : (FAMILY == 2 ? SAD_BR_F2 : 2))) void mlp_bf16_reg_kernel(const BfRegMulti mp) {
     constexpr int NW = BR_NW;
     constexpr int FPW = RS / NW;
     constexpr bool STATICW = FAMILY == 0;
