@@ -25,6 +25,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 using sad::BfRowsJob;
 
 constexpr int KC = 4;                 // k-steps (of 16) per chunk
+#ifndef SAD_ROWS_DX
+#define SAD_ROWS_DX 2      // row-queue depth of layers with more than two chunks (3: slower on every aggregation, 224 - 256 registers)
+#endif
 
 __device__ __forceinline__ bf16x8 cvt8(const float4 a, const float4 b) {
     bf16x8 v;
@@ -34,7 +37,7 @@ __device__ __forceinline__ bf16x8 cvt8(const float4 a, const float4 b) {
 }
 
 // NT = channel tiles (of 32) per item: 4, or 2 for layers with at most 64 output channels
-template <bool XBF16, int NT>
+template <bool XBF16, int NT, int DX>
 __global__ __launch_bounds__(256) void bf16_rows_kernel(const BfRowsJob jb) {
     constexpr int STAGE_F4 = KC * NT * 64;
     __shared__ __attribute__((aligned(16))) float4 lds[2 * STAGE_F4];
@@ -109,54 +112,130 @@ __global__ __launch_bounds__(256) void bf16_rows_kernel(const BfRowsJob jb) {
             acc[t][4 * q] = bv.x; acc[t][4 * q + 1] = bv.y; acc[t][4 * q + 2] = bv.z; acc[t][4 * q + 3] = bv.w;
         }
     }
-    XRaw xn = load_x(0);
-    {
-        const WRaw w0 = load_w(0);
-        store_w(w0, lds);
-    }
-    __syncthreads();
-#pragma unroll 1
-    for (int c = 0; c < NC; ++c) {
-        const float4 *cur = lds + (c & 1) * STAGE_F4;
-        bf16x8 x[KC];
-#pragma unroll
-        for (int s = 0; s < KC; ++s) x[s] = XBF16 ? __builtin_bit_cast(bf16x8, xn.a[s]) : cvt8(xn.a[s], xn.b[s]);
-        const int cn = c + 1 < NC ? c + 1 : c;
-        xn = load_x(cn);                            // the next chunk's rows and weights are in flight during the MFMAs
-        const WRaw wn = load_w(cn);
-        // A full chunk of a full item (every chunk but possibly the last, every item but those of a ragged last channel block) runs
-        // WITHOUT per-product conditions: with them every MFMA sat behind its own branch, LDS read and lgkmcnt(0) — ~200 cycles per
-        // 32-cycle product, 3 000 cycles per chunk (cluster.agg: 24 chunks, 50 us for 5 us of MFMAs).  The fragments of k-step s + 1
-        // are read while the products of k-step s run.
-        if (nt == NT && (c + 1) * KC <= KS) {
-            float4 wf[2][NT];
-#pragma unroll
-            for (int t = 0; t < NT; ++t) wf[0][t] = cur[t * 64 + lane];
-#pragma unroll
-            for (int s = 0; s < KC; ++s) {
-                if (s + 1 < KC) {
-#pragma unroll
-                    for (int t = 0; t < NT; ++t) wf[(s + 1) & 1][t] = cur[((s + 1) * NT + t) * 64 + lane];
-                }
-                __builtin_amdgcn_sched_barrier(0);      // the next k-step's LDS reads stay AHEAD of this k-step's MFMAs
-#pragma unroll
-                for (int t = 0; t < NT; ++t)
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[s & 1][t]), x[s], acc[t], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        } else {
-#pragma unroll
-            for (int s = 0; s < KC; ++s) {
-                if (c * KC + s < KS) {              // (wave-uniform: the padded k-steps of the last chunk are skipped)
-#pragma unroll
+    if constexpr (DX == 0) {
+        // layers of one or two chunks (sa1.agg: K = 128, 1 024 workgroups): the next chunk in flight during the current one, nothing
+        // else — the queued loop below costs such a layer 26 -> 32 us (six unrolled chunk bodies, two weight sets)
+        XRaw xn = load_x(0);
+        {
+            const WRaw w0 = load_w(0);
+            store_w(w0, lds);
+        }
+        __syncthreads();
+    #pragma unroll 1
+        for (int c = 0; c < NC; ++c) {
+            const float4 *cur = lds + (c & 1) * STAGE_F4;
+            bf16x8 x[KC];
+    #pragma unroll
+            for (int s = 0; s < KC; ++s) x[s] = XBF16 ? __builtin_bit_cast(bf16x8, xn.a[s]) : cvt8(xn.a[s], xn.b[s]);
+            const int cn = c + 1 < NC ? c + 1 : c;
+            xn = load_x(cn);                            // the next chunk's rows and weights are in flight during the MFMAs
+            const WRaw wn = load_w(cn);
+            // A full chunk of a full item (every chunk but possibly the last, every item but those of a ragged last channel block) runs
+            // WITHOUT per-product conditions: with them every MFMA sat behind its own branch, LDS read and lgkmcnt(0) — ~200 cycles per
+            // 32-cycle product, 3 000 cycles per chunk (cluster.agg: 24 chunks, 50 us for 5 us of MFMAs).  The fragments of k-step s + 1
+            // are read while the products of k-step s run.
+            if (nt == NT && (c + 1) * KC <= KS) {
+                float4 wf[2][NT];
+    #pragma unroll
+                for (int t = 0; t < NT; ++t) wf[0][t] = cur[t * 64 + lane];
+    #pragma unroll
+                for (int s = 0; s < KC; ++s) {
+                    if (s + 1 < KC) {
+    #pragma unroll
+                        for (int t = 0; t < NT; ++t) wf[(s + 1) & 1][t] = cur[((s + 1) * NT + t) * 64 + lane];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);      // the next k-step's LDS reads stay AHEAD of this k-step's MFMAs
+    #pragma unroll
                     for (int t = 0; t < NT; ++t)
-                        if (t < nt)
-                            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, cur[(s * NT + t) * 64 + lane]), x[s], acc[t], 0, 0, 0);
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[s & 1][t]), x[s], acc[t], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else {
+    #pragma unroll
+                for (int s = 0; s < KC; ++s) {
+                    if (c * KC + s < KS) {              // (wave-uniform: the padded k-steps of the last chunk are skipped)
+    #pragma unroll
+                        for (int t = 0; t < NT; ++t)
+                            if (t < nt)
+                                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, cur[(s * NT + t) * 64 + lane]), x[s], acc[t], 0, 0, 0);
+                    }
+                }
+            }
+            if (c + 1 < NC) store_w(wn, lds + ((c + 1) & 1) * STAGE_F4);
+            __syncthreads();
+        }
+    } else {
+        // Queues in registers: the rows of chunks c + 1 .. c + DX and the weight fragments of chunks c + 1, c + 2 are in flight while chunk c
+        // multiplies.  One chunk ahead (the first version) left every chunk waiting for loads issued 512 MFMA cycles earlier: 2 700 cycles
+        // per chunk whatever the rows cost (cluster.agg, 24 chunks: 49 us with the rows, 31 with the rows loaded once).  Static register
+        // names need the chunk loop unrolled by lcm(DX, 2) = 6.
+        static_assert(DX > 0 && 6 % DX == 0, "row queue depth must divide the unroll factor");
+        XRaw xq[DX];
+        WRaw wq[2];
+    #pragma unroll
+        for (int d = 0; d < DX; ++d) xq[d] = load_x(d < NC ? d : NC - 1);
+        {
+            const WRaw w0 = load_w(0);
+            wq[1] = load_w(NC > 1 ? 1 : 0);
+            store_w(w0, lds);
+        }
+        __syncthreads();
+    #pragma unroll 1
+        for (int c0 = 0; c0 < NC; c0 += 6) {
+    #pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                const int c = c0 + i;
+                if (c < NC) {                               // (workgroup-uniform)
+                    const float4 *cur = lds + (i & 1) * STAGE_F4;
+                    bf16x8 x[KC];
+    #pragma unroll
+                    for (int s = 0; s < KC; ++s) x[s] = XBF16 ? __builtin_bit_cast(bf16x8, xq[i % DX].a[s]) : cvt8(xq[i % DX].a[s], xq[i % DX].b[s]);
+                    const int cx = c + DX < NC ? c + DX : NC - 1, cw = c + 2 < NC ? c + 2 : NC - 1;
+    #if defined(SAD_ROWS_ABL) && SAD_ROWS_ABL == 1       // measurement builds: 1 the rows are loaded once, 2 the weights are loaded once (wrong results)
+                    if (c == 0) xq[i % DX] = load_x(cx);
+    #else
+                    xq[i % DX] = load_x(cx);
+    #endif
+    #if defined(SAD_ROWS_ABL) && SAD_ROWS_ABL == 2
+                    wq[i & 1] = load_w(0);
+    #else
+                    wq[i & 1] = load_w(cw);
+    #endif
+                    // A full chunk of a full item (every chunk but possibly the last, every item but those of a ragged last channel block) runs
+                    // WITHOUT per-product conditions: with them every MFMA sat behind its own branch, LDS read and lgkmcnt(0) — ~200 cycles per
+                    // 32-cycle product.  The fragments of k-step s + 1 are read while the products of k-step s run.
+                    if (nt == NT && (c + 1) * KC <= KS) {
+                        float4 wf[2][NT];
+    #pragma unroll
+                        for (int t = 0; t < NT; ++t) wf[0][t] = cur[t * 64 + lane];
+    #pragma unroll
+                        for (int s = 0; s < KC; ++s) {
+                            if (s + 1 < KC) {
+    #pragma unroll
+                                for (int t = 0; t < NT; ++t) wf[(s + 1) & 1][t] = cur[((s + 1) * NT + t) * 64 + lane];
+                            }
+                            __builtin_amdgcn_sched_barrier(0);      // the next k-step's LDS reads stay AHEAD of this k-step's MFMAs
+    #pragma unroll
+                            for (int t = 0; t < NT; ++t)
+                                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[s & 1][t]), x[s], acc[t], 0, 0, 0);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    } else {
+    #pragma unroll
+                        for (int s = 0; s < KC; ++s) {
+                            if (c * KC + s < KS) {              // (wave-uniform: the padded k-steps of the last chunk are skipped)
+    #pragma unroll
+                                for (int t = 0; t < NT; ++t)
+                                    if (t < nt)
+                                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, cur[(s * NT + t) * 64 + lane]), x[s], acc[t], 0, 0, 0);
+                            }
+                        }
+                    }
+                    if (c + 1 < NC) store_w(wq[(i + 1) & 1], lds + ((i + 1) & 1) * STAGE_F4);      // (chunk c + 1: loaded during chunk c - 1)
+                    __syncthreads();
                 }
             }
         }
-        if (c + 1 < NC) store_w(wn, lds + ((c + 1) & 1) * STAGE_F4);
-        __syncthreads();
     }
     // ---- epilogue: lane = row, registers 4q .. 4q+3 = channels 32 t + 8 q + 4 h .. + 3 ----
     if (!live) return;
@@ -210,13 +289,18 @@ int launch_bf16_rows(const BfRowsJob &job, hipStream_t st) {
     jb.ncb = (jb.ct + nt - 1) / nt;
     const long long grid = 8LL * ((jb.nrb + 7) / 8) * jb.ncb;
     if (grid >= (1LL << 31)) return fail(SAD_EINVAL, "sad_mlp_chain_bf16: too many rows");
+    // row-queue depth: a layer of one or two chunks (sa1.agg: K = 128) has nothing to run ahead of and 1 024 workgroups that want four
+    // per CU — the deeper queue's registers cost it 26 -> 34 us; the long-K layers gain (cluster.agg 49 -> 41 us, sa3.agg 29 -> 26)
+    const bool deep = (jb.ks + KC - 1) / KC > 2;
+#define SAD_ROWS_LAUNCH(XB, NTV, DXV) hipLaunchKernelGGL((bf16_rows_kernel<XB, NTV, DXV>), dim3((unsigned)grid), dim3(256), 0, st, jb)
     if (nt == 4) {
-        if (jb.x_bf16) hipLaunchKernelGGL((bf16_rows_kernel<true, 4>), dim3((unsigned)grid), dim3(256), 0, st, jb);
-        else hipLaunchKernelGGL((bf16_rows_kernel<false, 4>), dim3((unsigned)grid), dim3(256), 0, st, jb);
+        if (jb.x_bf16) { if (deep) SAD_ROWS_LAUNCH(true, 4, SAD_ROWS_DX); else SAD_ROWS_LAUNCH(true, 4, 0); }
+        else { if (deep) SAD_ROWS_LAUNCH(false, 4, SAD_ROWS_DX); else SAD_ROWS_LAUNCH(false, 4, 0); }
     } else {
-        if (jb.x_bf16) hipLaunchKernelGGL((bf16_rows_kernel<true, 2>), dim3((unsigned)grid), dim3(256), 0, st, jb);
-        else hipLaunchKernelGGL((bf16_rows_kernel<false, 2>), dim3((unsigned)grid), dim3(256), 0, st, jb);
+        if (jb.x_bf16) { if (deep) SAD_ROWS_LAUNCH(true, 2, SAD_ROWS_DX); else SAD_ROWS_LAUNCH(true, 2, 0); }
+        else { if (deep) SAD_ROWS_LAUNCH(false, 2, SAD_ROWS_DX); else SAD_ROWS_LAUNCH(false, 2, 0); }
     }
+#undef SAD_ROWS_LAUNCH
     return check_launch("sad_mlp_chain_bf16 (plain-row layer)");
 }
 
