@@ -289,9 +289,17 @@ int launch_bf16_rows(const BfRowsJob &job, hipStream_t st) {
     jb.ncb = (jb.ct + nt - 1) / nt;
     const long long grid = 8LL * ((jb.nrb + 7) / 8) * jb.ncb;
     if (grid >= (1LL << 31)) return fail(SAD_EINVAL, "sad_mlp_chain_bf16: too many rows");
-    // row-queue depth: a layer of one or two chunks (sa1.agg: K = 128) has nothing to run ahead of and 1 024 workgroups that want four
-    // per CU — the deeper queue's registers cost it 26 -> 34 us; the long-K layers gain (cluster.agg 49 -> 41 us, sa3.agg 29 -> 26)
-    const bool deep = (jb.ks + KC - 1) / KC > 2;
+    // Which chunk loop.  The queued loop (rows and weights two chunks ahead, ~60 more registers) pays where nothing else hides the load
+    // latency: more than two chunks AND about one workgroup per CU (32 KITTI-shaped scenes: cluster.agg / sa3.agg / sa2.agg launch 256
+    // workgroups: 49 -> 42, 29 -> 27, 19.6 -> 18.9 us).  With many workgroups per CU the resident ones hide it and the registers cost
+    // occupancy instead: sa1.agg (1 024 workgroups, two chunks) 26 -> 32 us, and at 32 nuScenes-shaped scenes (1 024 workgroups per layer)
+    // cluster.agg 160 -> 180, sa3.agg 86 -> 100, sa2.agg 64 -> 69 us.
+    const int cus = sad::device_cus();
+#ifdef SAD_ROWS_DEEP_ALWAYS      // measurement builds: the queued loop for every layer of more than two chunks, whatever the grid
+    const bool deep = (jb.ks + KC - 1) / KC > 2 && cus > 0;
+#else
+    const bool deep = (jb.ks + KC - 1) / KC > 2 && grid <= 2LL * cus;
+#endif
 #define SAD_ROWS_LAUNCH(XB, NTV, DXV) hipLaunchKernelGGL((bf16_rows_kernel<XB, NTV, DXV>), dim3((unsigned)grid), dim3(256), 0, st, jb)
     if (nt == 4) {
         if (jb.x_bf16) { if (deep) SAD_ROWS_LAUNCH(true, 4, SAD_ROWS_DX); else SAD_ROWS_LAUNCH(true, 4, 0); }

@@ -423,12 +423,7 @@ static int launch_coop_family(const RegMulti &mp, size_t lds, hipStream_t st) {
         per_cu.store(pc, std::memory_order_relaxed);
     }
     if (get_option(OPT_MLP_DYN_SLOTS) > 0 && get_option(OPT_MLP_DYN_SLOTS) < pc) pc = get_option(OPT_MLP_DYN_SLOTS);   // A/B knob
-    int dev = 0, cus = 256;
-    if (hipGetDevice(&dev) == hipSuccess) {
-        int v = 0;
-        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
-    }
-    (void)hipGetLastError();
+    const int cus = sad::device_cus();
     long long grid = (long long)cus * pc;
     const long long cap = mp.max_tiles / WAVES + mp.n;          // never more workgroups than items could exist
     if (grid > cap) grid = cap < 1 ? 1 : cap;

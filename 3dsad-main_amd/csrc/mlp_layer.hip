@@ -470,12 +470,7 @@ int launch_layers(const LayerMulti &lm_in, long long max_items, hipStream_t st) 
         per_cu.store(pc, std::memory_order_relaxed);
     }
     if (get_option(OPT_MLP_DYN_SLOTS) > 0 && get_option(OPT_MLP_DYN_SLOTS) < pc) pc = get_option(OPT_MLP_DYN_SLOTS);
-    int dev = 0, cus = 256;
-    if (hipGetDevice(&dev) == hipSuccess) {
-        int v = 0;
-        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
-    }
-    (void)hipGetLastError();
+    const int cus = sad::device_cus();
     long long grid = (long long)cus * pc;
     const long long cap = max_items;
     if (grid > cap) grid = cap < 1 ? 1 : cap;

@@ -423,12 +423,7 @@ int launch_family(const RegMulti &mp, size_t lds, hipStream_t st) {
         pc = nb > 8 ? 8 : nb;
         per_cu.store(pc, std::memory_order_relaxed);
     }
-    int dev = 0, cus = 256;
-    if (hipGetDevice(&dev) == hipSuccess) {
-        int v = 0;
-        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
-    }
-    (void)hipGetLastError();
+    const int cus = sad::device_cus();
     if (sad::get_option(sad::OPT_MLP_DYN_SLOTS) > 0 && sad::get_option(sad::OPT_MLP_DYN_SLOTS) < pc) pc = sad::get_option(sad::OPT_MLP_DYN_SLOTS);   // A/B knob
     long long grid = (long long)cus * pc;
     const long long cap = (mp.max_tiles + WAVES - 1) / WAVES;      // never more waves than tiles could exist
