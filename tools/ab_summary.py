@@ -11,8 +11,14 @@ def row(path):
                 f"MLP {b['mlp_ms_per_step']:.3f}, frac {b['roofline']['frac']:.3f})  | configs4_leg {c['value']:7.0f} ({c['ms_per_step']:.3f} ms, p50 {c['step_ms_p50']:.3f}, "
                 f"MLP {c['mlp_ms_per_step']:.3f}, frac {c['roofline']['frac']:.3f})")
     wl = d["config"]["workload"].split(":")[0]
-    return (f"  {name:10s} standalone {wl} {d['dtype']}: {d['value']:7.0f} scenes/s ({d['ms_per_step']:.3f} ms, p50 {d['step_ms']['p50']:.3f}, max {d['step_ms']['max']:.3f}, "
-            f"MLP {d['roofline']['ms_per_step']:.3f}, frac {d['roofline']['frac']:.3f})")
+    rf = d.get("roofline")          # (absent with --no-launch-timing)
+    tail = f"MLP {rf['ms_per_step']:.3f}, frac {rf['frac']:.3f}" if rf else "no per-launch timing"
+    fps = [k for k in d.get("kernels", []) if "fps" in k.get("kernel", "")]
+    if fps:
+        tail += f", FPS {fps[0].get('cu_ms_per_step')} CU.ms"
+    opts = d["config"].get("opts") or []
+    return (f"  {name:10s} standalone {wl} {d['dtype']}{' ' + ','.join(opts) if opts else ''}: {d['value']:7.0f} scenes/s ({d['ms_per_step']:.3f} ms, p50 {d['step_ms']['p50']:.3f}, "
+            f"max {d['step_ms']['max']:.3f}, steps over 2 x p50: {d['step_ms']['over_2x_p50']}; {tail})")
 for arg in sys.argv[1:]:
     d, _, note = arg.partition(":")
     print(f"{d}  {note}")
