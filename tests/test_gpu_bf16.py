@@ -56,6 +56,38 @@ def test_rows_bf16(orc, sad, dev, rows, dims, mask, in_bf16):
     assert (b[:, :8] == -7).all() and (b[:, 8 + dims[-1]:] == -7).all()
 
 
+# The row-streaming layer has two chunk loops (csrc/mlp_bf16_rows.hip, launch_bf16_rows): rows and weights queued two chunks ahead for layers
+# of more than two chunks on at most two workgroups per CU, the single-ahead loop otherwise.  PLAIN above runs its deep layers on tiny grids
+# (queued loop); 32 nuScenes-shaped scenes put the same layers on ~1 024 workgroups (single-ahead loop).  These cases are the second kind.
+BIG_GRID = [
+    (66_000, [384, 128]),       # 6 chunks, one channel block, ragged last row block
+    (33_000, [768, 256]),       # 12 chunks, two channel blocks
+]
+
+
+@pytest.mark.parametrize("rows,dims", BIG_GRID)
+def test_rows_bf16_deep_layer_on_a_large_grid(orc, sad, dev, rows, dims):
+    import torch
+    from sad_amd import ops, synth
+    # the launcher's grid: 8 * ceil(row blocks / 8) * channel blocks (128 rows and up to 4 x 32 channels per workgroup)
+    ct = (dims[-1] + 31) // 32
+    ncb = (ct + 3) // 4
+    grid = 8 * ((((rows + 127) // 128) + 7) // 8) * ncb
+    cus = torch.cuda.get_device_properties(dev).multi_processor_count
+    assert (dims[0] + 15) // 16 > 8 and grid > 2 * cus, f"this case no longer reaches the single-ahead loop of a deep layer (grid {grid}, {cus} CUs)"
+    rng = np.random.default_rng(rows + sum(dims))
+    layers = synth.make_mlp_weights(dims, rng)
+    x = rng.normal(size=(rows, dims[0])).astype(np.float32)
+    mlp = ops.PackedMLPBf16(layers, False, dev)
+    got = mlp.rows(_t(x, dev)).cpu().numpy()
+    want = orc.mlp_rows_bf16(x, layers)
+    _close(got, want, f"rows {dims} x {rows} (grid {grid} on {cus} CUs)")
+    # the same rows on a small grid take the queued loop: both loops see the same operands in the same k order per chunk
+    few = 1000
+    got_few = mlp.rows(_t(x[:few], dev)).cpu().numpy()
+    _close(got_few, want[:few], f"rows {dims} x {few} (queued loop)")
+
+
 GROUPED = [
     # (B, N, M, S, C, mlp, radius)
     (1, 1024, 256, 32, 0, [64, 64, 128], 0.2),
