@@ -174,6 +174,10 @@ struct Stage {
 
 template <int COUT>
 __device__ __forceinline__ void pool_stage(f32x16 t, const PoolMasks &pm, bool tail, const Stage &sg, int o, int h) {
+#ifdef SAD_REG_NOPOOL       // measurement build (as in pool_store): no pooling, no staging; the comparison keeps the chain alive
+    if (t[0] == 123.f) sg.lds[0] = t[0];
+    return;
+#endif
     t = seg_max16(t, pm);
     if (tail) {
         float *d = sg.lds + sg.slot * COUT + o * 32 + 4 * h;
@@ -185,6 +189,9 @@ __device__ __forceinline__ void pool_stage(f32x16 t, const PoolMasks &pm, bool t
 
 template <int COUT>
 __device__ __forceinline__ void stage_flush(const Stage &sg, int grp, bool whole, int lane, const RegChain &c) {
+#ifdef SAD_REG_NOPOOL
+    return;
+#endif
     unsigned rem = sg.tails;
     for (int s = 0; s < sg.ngroups; ++s) {                 // wave-uniform loop over the groups that end in this tile
         const int p = __builtin_ctz(rem);
