@@ -179,6 +179,15 @@ __device__ __forceinline__ void pool_stage(f32x16 t, const PoolMasks &pm, bool t
     return;
 #endif
     t = seg_max16(t, pm);
+#ifdef SAD_REG_NOSTORE      // measurement build (as in pool_store): the pooling arithmetic only, nothing staged or stored
+    {
+        float s = 0.f;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) s += t[g];
+        if (s == 123.456f) sg.lds[0] = s;
+        return;
+    }
+#endif
     if (tail) {
         float *d = sg.lds + sg.slot * COUT + o * 32 + 4 * h;
 #pragma unroll
@@ -189,7 +198,7 @@ __device__ __forceinline__ void pool_stage(f32x16 t, const PoolMasks &pm, bool t
 
 template <int COUT>
 __device__ __forceinline__ void stage_flush(const Stage &sg, int grp, bool whole, int lane, const RegChain &c) {
-#ifdef SAD_REG_NOPOOL
+#if defined(SAD_REG_NOPOOL) || defined(SAD_REG_NOSTORE)
     return;
 #endif
     unsigned rem = sg.tails;
