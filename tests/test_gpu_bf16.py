@@ -223,6 +223,41 @@ def test_register_chain_bf16_random_group_sizes(orc, sad, dev, seed):
     _close(got, want, f"random groups seed {seed}: S={S} M={M} mode={mode} rows={int(cnt.sum())}")
 
 
+@pytest.mark.parametrize("seed,C,mlp", [(11, 64, [64, 64, 128]), (12, 64, [64, 96, 128]), (13, 256, [256, 256, 512])])
+def test_register_chain_bf16_unaligned_output_slice(sad, dev, seed, C, mlp):
+    """The register-resident chain writing into columns [5, 5 + C_out) of a buffer whose row stride is not a multiple of four: no 16-byte
+    store is possible, whole groups leave through the element-wise path and groups that cross a tile through the per-channel atomic max with its
+    own bounds (csrc/mlp_bf16_reg.hip, flush of a block).  Same arithmetic as the aligned call: identical bits; nothing outside the slice is written."""
+    import torch
+    from sad_amd import ops, synth
+    rng = np.random.default_rng(2000 + seed)
+    B, N = 2, 700
+    S = int(rng.choice([16, 32]))
+    M = int(rng.integers(60, 200))
+    xyz = rng.uniform(0, 1, (B, N, 3)).astype(np.float32)
+    feat = rng.normal(size=(B, N, C)).astype(np.float32)
+    new_xyz = rng.uniform(0, 1, (B, M, 3)).astype(np.float32)
+    idx = rng.integers(0, N, (B, M, S)).astype(np.int32)
+    cnt = rng.choice([1, 2, 3, S // 2, S], size=(B, M)).astype(np.int32)       # tiles of many groups and of few, groups across tiles
+    for b in range(B):
+        for m in range(M):
+            idx[b, m, cnt[b, m]:] = idx[b, m, 0]
+    layers = synth.make_mlp_weights([C + 3] + mlp, rng)
+    net = ops.PackedMLPBf16(layers, True, dev)
+    assert net.preferred_geometry == 2
+    net.default_geometry = 2
+    X, F, Cn, I, K = _t(xyz, dev), _t(feat, dev).bfloat16(), _t(new_xyz, dev), _t(idx, dev), _t(cnt, dev)
+    want = net.grouped(X, F, Cn, I, cnt=K)
+    cout, off = mlp[-1], 5
+    buf = torch.full((B, M, cout + 13), -7.0, device=dev, dtype=torch.float32)
+    buf[:, :, off:off + cout] = 0.0                 # (the slice starts at zero: groups that cross a tile are merged with an atomic max)
+    assert buf.stride(1) % 4 != 0
+    net.grouped(X, F, Cn, I, out=buf, col_off=off, cnt=K)
+    torch.cuda.synchronize()
+    assert torch.equal(buf[:, :, off:off + cout], want), "unaligned slice: different bits from the aligned call"
+    assert bool((buf[:, :, :off] == -7).all()) and bool((buf[:, :, off + cout:] == -7).all()), "written outside the slice"
+
+
 def test_register_chain_bf16_three_chain_dispatch(orc, sad, dev):
     """The three SA3 branches as ONE register-resident dispatch (sad_mlp_chain_multi_bf16) with prescanned tables:
     chains of different shapes follow each other in a workgroup's item list and the weight ring carries over."""
