@@ -272,6 +272,21 @@ __device__ __forceinline__ unsigned bitonic_sort64(unsigned v, int mir63) {
     v = exchange<32>(v, (unsigned)__builtin_amdgcn_ds_bpermute(mir63, (int)v));
     return clean_from<16>(v);
 }
+// The same sort when only lanes 0 .. n-1 hold real keys and every other lane the empty key 0xFFFFFFF0 (which sorts last and is equal to
+// itself): once the blocks of the smallest power of two >= n are sorted, lanes 0 .. n-1 are in their final order and the wider merges could
+// only move empty keys among empty keys — they are skipped (n is wave-uniform: a scalar branch).  n <= 16: 10 of the 21 stages; n <= 32: 15.
+__device__ __forceinline__ unsigned bitonic_sort64n(unsigned v, int mir63, int n) {
+    v = merge_upto32<16>(v);
+    if (n > 16) {
+        v = exchange<16>(v, swz_xor<31>(v));                                    // merge of the 32-lane blocks (as merge_upto32<32>)
+        v = clean_from<8>(v);
+        if (n > 32) {
+            v = exchange<32>(v, (unsigned)__builtin_amdgcn_ds_bpermute(mir63, (int)v));
+            v = clean_from<16>(v);
+        }
+    }
+    return v;
+}
 // 128 keys, two per lane: element e = lane + 64 * register
 __device__ __forceinline__ void bitonic_sort128(unsigned &v0, unsigned &v1, int mir63, int x32) {
     v0 = bitonic_sort64(v0, mir63);
@@ -470,7 +485,7 @@ __global__ __launch_bounds__(GQ_WAVES * 64) __attribute__((amdgpu_waves_per_eu(8
             }
         }
         if (fits) {
-            const unsigned key = bitonic_sort64(packed, mir63);
+            const unsigned key = bitonic_sort64n(packed, mir63, nacc);      // (the kept keys sit in lanes 0 .. nacc-1)
             const int jidx = (int)((key >> 4) & 0x00FFFFFFu);
             const unsigned cl = key >> 28;      // the lane's centroid (15: an empty lane)
             // the lanes of each centroid (contiguous after the sort), and per lane the mask of its own centroid's lanes
@@ -622,7 +637,7 @@ __global__ __launch_bounds__(GQ_WAVES * 64) __attribute__((amdgpu_waves_per_eu(8
             if (T <= 64 && !prm.no_sort) {
                 // ---- sort path, one candidate per lane ----
                 unsigned key = make_key(prc, lane < T);
-                key = bitonic_sort64(key, mir63);
+                key = bitonic_sort64n(key, mir63, T);       // (the T candidates sit in lanes 0 .. T-1)
                 const int jidx = (int)(key >> 4);
 #pragma unroll
                 for (int r = 0; r < NR; ++r) {
