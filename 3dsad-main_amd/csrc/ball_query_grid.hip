@@ -775,6 +775,11 @@ SAD_API int sad_ball_query_grid_f32(const float *xyz, const float *new_xyz, int 
         sad::lds_attr_once(attr_done0, reinterpret_cast<const void *>(&grid_build_kernel<0>), 144 * 1024);
         hipLaunchKernelGGL(grid_build_kernel<0>, dim3(B), dim3(BUILD_T), blds, st, xyz, N, rmax * 1.001f, (char *)workspace);
     }
+#ifdef SAD_GRID_BUILD_TWICE  // measurement build: the grid build launched twice (idempotent: same tables) — what its time costs the pipelined step
+    if (N <= 4 * BUILD_T) hipLaunchKernelGGL(grid_build_kernel<4>, dim3(B), dim3(BUILD_T), blds, st, xyz, N, rmax * 1.001f, (char *)workspace);
+    else if (N <= 16 * BUILD_T) hipLaunchKernelGGL(grid_build_kernel<16>, dim3(B), dim3(BUILD_T), blds, st, xyz, N, rmax * 1.001f, (char *)workspace);
+    else hipLaunchKernelGGL(grid_build_kernel<0>, dim3(B), dim3(BUILD_T), blds, st, xyz, N, rmax * 1.001f, (char *)workspace);
+#endif
     if (int e = sad::check_launch("sad_ball_query_grid_f32 (build)")) return e;
     const char *ws = (const char *)workspace;
     switch (n_radii) {

@@ -193,6 +193,10 @@ int launch_rowscan_multi(const ScanJob *jobs, int n, hipStream_t st) {
     }
     hipLaunchKernelGGL(rowscan_sums_kernel, dim3(blocks), dim3(SCAN_T), 0, st, sm);
     hipLaunchKernelGGL(rowscan_write_kernel, dim3(blocks), dim3(SCAN_T), 0, st, sm);
+#ifdef SAD_SCAN_TWICE       // measurement build: the scan's work doubled (both kernels are idempotent: same tables, same zero fill) — what its time costs the step
+    hipLaunchKernelGGL(rowscan_sums_kernel, dim3(blocks), dim3(SCAN_T), 0, st, sm);
+    hipLaunchKernelGGL(rowscan_write_kernel, dim3(blocks), dim3(SCAN_T), 0, st, sm);
+#endif
     return check_launch("rowscan");
 }
 
