@@ -516,7 +516,9 @@ __global__ __launch_bounds__(GQ_WAVES * 64) __attribute__((amdgpu_waves_per_eu(8
                     const int total = __builtin_popcountll(bc);
                     int first = 0;
                     if (bc) first = __builtin_amdgcn_readlane(jidx, __builtin_ctzll(bc));
+#ifndef SAD_BQ_NOPAD            // (measurement build: the padding stores of the packed path left out — what they cost; consumers that take `cnt` never read them)
                     if (lane >= total && lane < S) out0[c * S + lane] = first;       // (nsample <= 64: one store covers the row)
+#endif
                     tot[c] = total < S ? total : S;
                 }
                 if (prm.cnt[r] && lane < 4 && m0 + lane < M)
