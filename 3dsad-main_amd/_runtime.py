@@ -16,28 +16,42 @@ HW_QUEUES_DEFAULT = 4          # HIP's default when the variable is unset
 HW_QUEUES_WANTED = 16          # every stream of the largest pipeline (2 main + 8 sampling + gather) on its own queue
 
 
-def _hip_initialised() -> bool:
-    """Has this process made a HIP call through torch already?  (torch not imported = certainly not.)"""
+def _hip_initialised():
+    """Has this process made a HIP call already?  False: torch is not imported (certainly not).  True: torch's CUDA
+    state is initialised.  None = UNKNOWN: torch is imported but its flag is still False — ``torch.cuda.is_available()``
+    / ``device_count()`` call hipGetDeviceCount, which brings the HIP runtime up (and makes it read the variable) without
+    setting that flag, and a profiler preload (rocprofv3 --pmc) does the same before Python starts."""
     torch = sys.modules.get("torch")
     if torch is None:
         return False
     try:
-        return bool(torch.cuda.is_initialized())
+        return True if torch.cuda.is_initialized() else None
     except Exception:
-        return False
+        return None
 
 
-def ensure_hw_queues(environ=None, initialised=None) -> str:
+_ASK = object()
+
+
+def ensure_hw_queues(environ=None, initialised=_ASK) -> str:
     """Called at ``import sad_amd``.  Leaves a value the user exported alone; otherwise exports
-    ``GPU_MAX_HW_QUEUES=16`` when the HIP runtime has not initialised yet.  Returns what happened:
-    "user" (already set), "set" (exported here), "late" (unset, and HIP is already up: nothing done)."""
+    ``GPU_MAX_HW_QUEUES=16`` when the HIP runtime cannot have initialised yet.  Returns what happened:
+    "user" (already set), "set" (exported here: torch was not imported, no HIP call can have been made through it),
+    "unknown" (exported here, but torch was imported already and ANY ``torch.cuda`` call — ``is_available()`` included —
+    or a profiler preload may have initialised HIP with the default of 4 queues: the export may be read by nobody),
+    "late" (unset, and torch's CUDA state is up: nothing done).
+
+    The variable must be in the environment before the first HIP call of the process, ``torch.cuda.is_available()``
+    included: export it in the shell (the documented way), or ``import sad_amd`` before ``import torch`` does anything
+    with the GPU.  Note that the export changes ``os.environ`` for every other HIP user of the process."""
     env = os.environ if environ is None else environ
     if env.get(HW_QUEUES_ENV):
         return "user"
-    if _hip_initialised() if initialised is None else initialised:
+    up = _hip_initialised() if initialised is _ASK else initialised       # True / False / None (= unknown)
+    if up:
         return "late"
     env[HW_QUEUES_ENV] = str(HW_QUEUES_WANTED)
-    return "set"
+    return "set" if up is False else "unknown"
 
 
 def hw_queues(environ=None) -> int:
@@ -54,11 +68,24 @@ _warned = set()
 
 def check_stream_budget(n_streams: int, state: str, environ=None) -> bool:
     """Warn (once per kind and process) when a pipeline is about to create more streams than there are hardware queues.
-    ``state`` is what ``ensure_hw_queues`` returned at import.  Returns True when the budget is fine."""
+    ``state`` is what ``ensure_hw_queues`` returned at import.  Returns True when the budget is fine ("unknown": the
+    variable was exported after torch was imported — more than 4 streams get one warning that the export may be unread)."""
     q = hw_queues(environ)
-    if n_streams <= q and state != "late":
+    if n_streams <= q and state not in ("late", "unknown"):
+        return True
+    if state == "unknown" and n_streams > HW_QUEUES_DEFAULT and n_streams <= q:
+        if environ is None:
+            if "unknown" in _warned:
+                return True
+            _warned.add("unknown")
+        warnings.warn(f"sad_amd: {HW_QUEUES_ENV}={q} was exported at `import sad_amd`, after torch was imported: if any torch.cuda call "
+                      f"(is_available() included) or a profiler preload initialised HIP before that, the runtime kept its default of "
+                      f"{HW_QUEUES_DEFAULT} hardware queues and {n_streams} streams will share them.  Export the variable in the shell.",
+                      RuntimeWarning, stacklevel=3)
         return True
     kind = "late" if (state == "late" and n_streams > HW_QUEUES_DEFAULT) else ("over" if n_streams > q else None)
+    if kind is None:             # ("late" with at most 4 streams: the default queues are enough)
+        return True
     if environ is None:          # (explicit environments are the unit tests: always warn there)
         if kind in _warned:
             return False

@@ -110,11 +110,12 @@ __global__ __launch_bounds__(BUILD_T) void grid_build_kernel(const float *__rest
             lo[d] = red[d][w] < lo[d] ? red[d][w] : lo[d];
             hi[d] = red[3 + d][w] > hi[d] ? red[3 + d][w] : hi[d];
         }
-    // 2. grid geometry (identical in every thread): double the cell edge until the grid fits
+    // 2. grid geometry (identical in every thread): grow the cell edge by 2^(1/4) per trial until the grid fits
     // Non-finite coordinates are undefined behaviour for the RESULT (SPEC.md §3), never for memory:
     // an extent that is not a finite non-negative number (Inf / NaN input, or no finite point at all)
     // selects a one-cell grid — every query then tests every point, like the scan kernel — and the
-    // doubling loop is bounded, so the kernel neither spins nor leaves its tables.
+    // growth loop is bounded (128 trials = a factor of 2^32 on the edge: a radius / extent ratio beyond that
+    // also takes the one-cell grid, which is still exact), so the kernel neither spins nor leaves its tables.
     bool sane = true;
 #pragma unroll
     for (int d = 0; d < 3; ++d) {

@@ -297,14 +297,20 @@ __global__ __launch_bounds__(THREADS) void fps_bucket_kernel(const float *__rest
 // per-slot code; the wave's best is a row reduction of the bucket keys.  Few, fat waves (8 x 32
 // slots for 16 384 points) keep the part of the step every wave must execute — test, publish,
 // barrier, NW-key arg-max — short.  Same proof of exactness as above, per bucket.
+// v_writelane_b32 through the LLVM intrinsic (clang has no builtin for it): the compiler then owns m0 — it puts the lane select there
+// (gfx9: one SGPR on the constant bus), merges the m0 writes of consecutive writelanes with the same lane, and keeps them apart from the
+// s_set_gpr_idx / M0 traffic of the register-indexed vectors.  (An asm statement with "s_mov_b32 m0" cannot declare the clobber: m0 is a
+// reserved register and the clobber is ignored with -Winline-asm.)
+extern "C" __device__ unsigned sad_writelane(unsigned val_uniform, unsigned lane_uniform, unsigned old) __asm("llvm.amdgcn.writelane.i32");
 __device__ __forceinline__ unsigned wrl_dyn(unsigned old, unsigned val_uniform, int lane_uniform) {
     // v_writelane_b32 with data and lane select both scalar: the lane select goes through M0
     // (gfx9 allows one SGPR on the constant bus)
     val_uniform = __builtin_amdgcn_readfirstlane(val_uniform);
     lane_uniform = __builtin_amdgcn_readfirstlane(lane_uniform);
-    // (m0 is reserved and not tracked by the compiler; nothing in this kernel keeps a value in it)
-    asm("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(old) : "s"(val_uniform), "s"(lane_uniform));
-    return old;
+    // (the builtin, not an asm statement with "s_mov_b32 m0": m0 is a reserved register, a clobber of it is ignored
+    // (-Winline-asm), and hipcc lowers register-indexed vectors through s_set_gpr_idx / M0 in these kernels — the compiler
+    // has to see every write of m0)
+    return sad_writelane(val_uniform, lane_uniform, old);
 }
 __device__ __forceinline__ float wrl_dyn_f(float old, float val_uniform, int lane_uniform) {
     return __builtin_bit_cast(float, wrl_dyn(__builtin_bit_cast(unsigned, old), __builtin_bit_cast(unsigned, val_uniform), lane_uniform));
@@ -621,8 +627,8 @@ __device__ __forceinline__ void cell2_slow(Cell2<NW, PPT> &s, unsigned act, int 
                 l = __builtin_ctzll(__ballot(mb == hi && n == lo));
             }
             // bucket k's state lane: its new maximum and the lane that holds it (both writes through one m0)
-            asm("s_mov_b32 m0, %4\n\tv_writelane_b32 %0, %2, m0\n\tv_writelane_b32 %1, %3, m0"
-                : "+v"(s.bmax), "+v"(s.blane) : "s"(hi), "s"(l), "s"(k));
+            s.bmax = sad_writelane(hi, k, s.bmax);
+            s.blane = sad_writelane((unsigned)l, k, s.blane);
             top = hi > top ? hi : top;
         } while (act);
         FPS2_T(ts1);
@@ -654,22 +660,24 @@ __device__ __forceinline__ void cell2_slow(Cell2<NW, PPT> &s, unsigned act, int 
     FPS2_T(ts3);
     if (publish) {
         // the owner of the wave's best point (lane wl, register slot kb) publishes it from its own registers: every lane reads
-        // slot kb, lane wl alone writes (exec is all ones here and is restored inside the statement)
+        // slot kb, lane wl alone writes (s_and_saveexec: the statement saves the exec mask it finds and restores it)
         f4v r;
+        unsigned long long sv;
         r.x = s.px[s.kb]; r.y = s.py[s.kb]; r.z = s.pz[s.kb]; r.w = 0.f;
         if (publish & 2u) {
             const unsigned n = s.ni[s.kb];
-            asm volatile("s_mov_b64 exec, %4\n\t"
-                         "v_lshl_or_b32 %0, %2, 4, %3\n\t"            // index order kept (the top four bits fall off: N < 2^28)
-                         "v_mov_b32 %1, %5\n\t"
-                         "ds_write_b128 %6, %7 offset:%8\n\t"
-                         "s_mov_b64 exec, -1"
-                         : "+v"(s.klo), "+v"(s.khi) : "v"(n), "s"(s.wave), "s"(s.wlmask), "s"(s.wk_hi),
-                           "v"(s.a_rec_mine), "v"(r), "n"(BUF * 256) : "memory");
+            asm volatile("s_and_saveexec_b64 %[sv], %[m]\n\t"
+                         "v_lshl_or_b32 %[klo], %[n], 4, %[w]\n\t"    // index order kept (the top four bits fall off: N < 2^28)
+                         "v_mov_b32 %[khi], %[hi]\n\t"
+                         "ds_write_b128 %[a], %[r] offset:%[o]\n\t"
+                         "s_mov_b64 exec, %[sv]"
+                         : [klo] "+v"(s.klo), [khi] "+v"(s.khi), [sv] "=&s"(sv)
+                         : [n] "v"(n), [w] "s"(s.wave), [m] "s"(s.wlmask), [hi] "s"(s.wk_hi),
+                           [a] "v"(s.a_rec_mine), [r] "v"(r), [o] "n"(BUF * 256) : "memory", "scc");
             s.pending = 1u;                   // the other buffer gets the record in the next step
         } else {
-            asm volatile("s_mov_b64 exec, %0\n\tds_write_b128 %1, %2 offset:%3\n\ts_mov_b64 exec, -1"
-                         :: "s"(s.wlmask), "v"(s.a_rec_mine), "v"(r), "n"(BUF * 256) : "memory");
+            asm volatile("s_and_saveexec_b64 %0, %1\n\tds_write_b128 %2, %3 offset:%4\n\ts_mov_b64 exec, %0"
+                         : "=&s"(sv) : "s"(s.wlmask), "v"(s.a_rec_mine), "v"(r), "n"(BUF * 256) : "memory", "scc");
         }
     }
     FPS2_T(ts4);
@@ -698,13 +706,14 @@ __device__ __forceinline__ void cell2_step(Cell2<NW, PPT> &s, int lane, int *__r
     FPS2_T(tc);
     {
         const u64 key = ((u64)s.khi << 32) | s.klo;
-        // (exec is all ones here — whole waves, top level of the loop — and is restored inside the statement)
-        asm volatile("s_mov_b64 exec, %0\n\tds_max_u64 %1, %2 offset:%3\n\ts_mov_b64 exec, -1"
-                     :: "s"(s.wlmask), "v"(s.a_key), "v"(key), "n"(B3 * 8) : "memory");
+        // (the exec mask found on entry is saved and restored inside the statement; scc is declared clobbered)
+        unsigned long long sv;
+        asm volatile("s_and_saveexec_b64 %0, %1\n\tds_max_u64 %2, %3 offset:%4\n\ts_mov_b64 exec, %0"
+                     : "=&s"(sv) : "s"(s.wlmask), "v"(s.a_key), "v"(key), "n"(B3 * 8) : "memory", "scc");
         if (W0) {
             const u64 zero = 0ull;
-            asm volatile("s_mov_b64 exec, 1\n\tds_write_b64 %0, %1 offset:%2\n\ts_mov_b64 exec, -1"
-                         :: "v"(s.a_key), "v"(zero), "n"(B3N * 8) : "memory");
+            asm volatile("s_and_saveexec_b64 %0, 1\n\tds_write_b64 %1, %2 offset:%3\n\ts_mov_b64 exec, %0"
+                         : "=&s"(sv) : "v"(s.a_key), "v"(zero), "n"(B3N * 8) : "memory", "scc");
         }
         // After the barrier: the winning key (one broadcast read), then the winner's record alone (a second broadcast
         // read at an address computed from the key in vector registers: no scalar round trip).  Sixteen waves reading all
@@ -1018,10 +1027,11 @@ __global__ __launch_bounds__(1024) void fps_cellg_kernel(const float4 *__restric
         const unsigned ux = __builtin_amdgcn_readlane(__builtin_bit_cast(unsigned, r.x), l);                          \
         const unsigned uy = __builtin_amdgcn_readlane(__builtin_bit_cast(unsigned, r.y), l);                          \
         const unsigned uz = __builtin_amdgcn_readlane(__builtin_bit_cast(unsigned, r.z), l);                          \
-        asm("s_mov_b32 m0, %10\n\tv_writelane_b32 %0, %5, m0\n\tv_writelane_b32 %1, %6, m0\n\t"                     \
-            "v_writelane_b32 %2, %7, m0\n\tv_writelane_b32 %3, %8, m0\n\tv_writelane_b32 %4, %9, m0"                 \
-            : "+v"(bmax), "+v"(bidx), "+v"(bx), "+v"(by), "+v"(bz)                                                    \
-            : "s"(hi), "s"(bn), "s"(ux), "s"(uy), "s"(uz), "s"(KS));                                                  \
+        bmax = sad_writelane(hi, KS, bmax);                                                              \
+        bidx = sad_writelane(bn, KS, bidx);                                                              \
+        bx = sad_writelane(ux, KS, bx);                                                                  \
+        by = sad_writelane(uy, KS, by);                                                                  \
+        bz = sad_writelane(uz, KS, bz);                                                                  \
         top = hi > top ? hi : top;                                                                                    \
     }
 
@@ -1062,17 +1072,21 @@ __global__ __launch_bounds__(1024) void fps_cellg_kernel(const float4 *__restric
         }                                                                                                             \
         if (publish) {                                                                                                \
             f4v pr;                                                                                                   \
+            unsigned long long sv;      /* (the exec mask the statement finds: saved and restored inside it) */      \
             pr.x = bx; pr.y = by; pr.z = bz; pr.w = 0.f;                                                              \
             if (publish & 2u) {                                                                                       \
                 /* lane kb alone: it holds the bucket's best point; index order kept in the key (N < 2^28) */         \
-                asm volatile("s_lshl_b64 exec, 1, %4\n\tv_lshl_or_b32 %0, %2, 4, %3\n\tv_mov_b32 %1, %5\n\t"         \
-                             "ds_write_b128 %6, %7 offset:%8\n\ts_mov_b64 exec, -1"                                   \
-                             : "+v"(klo), "+v"(khi) : "v"(bidx), "s"(wave), "s"(kb), "v"(bmax),                       \
-                               "v"(a_rec_mine), "v"(pr), "n"((BUF) * 256) : "memory");                                \
+                asm volatile("s_lshl_b64 %[sv], 1, %[kb]\n\ts_and_saveexec_b64 %[sv], %[sv]\n\t"                       \
+                             "v_lshl_or_b32 %[klo], %[n], 4, %[w]\n\tv_mov_b32 %[khi], %[hi]\n\t"                     \
+                             "ds_write_b128 %[a], %[r] offset:%[o]\n\ts_mov_b64 exec, %[sv]"                          \
+                             : [klo] "+v"(klo), [khi] "+v"(khi), [sv] "=&s"(sv)                                        \
+                             : [n] "v"(bidx), [w] "s"(wave), [kb] "s"(kb), [hi] "v"(bmax),                            \
+                               [a] "v"(a_rec_mine), [r] "v"(pr), [o] "n"((BUF) * 256) : "memory", "scc");             \
                 pending = 1u;                                                                                         \
             } else {                                                                                                  \
-                asm volatile("s_lshl_b64 exec, 1, %0\n\tds_write_b128 %1, %2 offset:%3\n\ts_mov_b64 exec, -1"        \
-                             :: "s"(kb), "v"(a_rec_mine), "v"(pr), "n"((BUF) * 256) : "memory");                      \
+                asm volatile("s_lshl_b64 %0, 1, %1\n\ts_and_saveexec_b64 %0, %0\n\tds_write_b128 %2, %3 offset:%4\n\t" \
+                             "s_mov_b64 exec, %0"                                                                     \
+                             : "=&s"(sv) : "s"(kb), "v"(a_rec_mine), "v"(pr), "n"((BUF) * 256) : "memory", "scc");    \
             }                                                                                                         \
         }                                                                                                             \
     }
@@ -1086,12 +1100,14 @@ __global__ __launch_bounds__(1024) void fps_cellg_kernel(const float4 *__restric
                                  (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)act0);        \
         if ((act != 0ull) | (pending != 0u)) CELLG2_SLOW(BUF)                                                         \
         const u64 key = ((u64)khi << 32) | klo;                                                                       \
-        asm volatile("s_lshl_b64 exec, 1, %0\n\tds_max_u64 %1, %2 offset:%3\n\ts_mov_b64 exec, -1"                    \
-                     :: "s"(kb), "v"(a_key), "v"(key), "n"((B3) * 8) : "memory");                                     \
+        unsigned long long sv;                                                                                        \
+        asm volatile("s_lshl_b64 %0, 1, %1\n\ts_and_saveexec_b64 %0, %0\n\tds_max_u64 %2, %3 offset:%4\n\t"            \
+                     "s_mov_b64 exec, %0"                                                                             \
+                     : "=&s"(sv) : "s"(kb), "v"(a_key), "v"(key), "n"((B3) * 8) : "memory", "scc");                   \
         if (W0) {                                                                                                     \
             const u64 zero = 0ull;                                                                                    \
-            asm volatile("s_mov_b64 exec, 1\n\tds_write_b64 %0, %1 offset:%2\n\ts_mov_b64 exec, -1"                   \
-                         :: "v"(a_key), "v"(zero), "n"(((B3) == 2 ? 0 : (B3) + 1) * 8) : "memory");                   \
+            asm volatile("s_and_saveexec_b64 %0, 1\n\tds_write_b64 %1, %2 offset:%3\n\ts_mov_b64 exec, %0"            \
+                         : "=&s"(sv) : "v"(a_key), "v"(zero), "n"(((B3) == 2 ? 0 : (B3) + 1) * 8) : "memory", "scc"); \
         }                                                                                                             \
         unsigned gk, ra;                                                                                              \
         f4v wrec;                                                                                                     \

@@ -21,7 +21,7 @@ from .sa_module import SAModuleMSG
 
 
 class SADDetector(nn.Module):
-    _streams_created = 0          # streams made by every detector of this process (they are never destroyed: torch pools them)
+    _streams_created = {}         # device index -> streams made by every detector of this process there (never destroyed: torch pools them)
 
     def __init__(self, cfg: DetectorConfig, weights: dict, device, overlap_fps: bool = True,
                  n_fps_streams: int = 3, n_main_streams: int = 2, nested_fps_shortcut: bool = True,
@@ -85,8 +85,10 @@ class SADDetector(nn.Module):
         if streams is not None:
             if len(streams[0]) < n_side or len(streams[1]) < n_main:
                 raise ValueError(f"streams: need {n_side} sampling and {n_main} main streams")
-        SADDetector._streams_created += 0 if streams is not None else n_side + n_main
-        _runtime.check_stream_budget(max(n_side + n_main, SADDetector._streams_created) + 1, HW_QUEUES_STATE)
+        dkey = self.device.index if self.device.index is not None else torch.cuda.current_device()   # (hardware queues are per device)
+        made = SADDetector._streams_created.get(dkey, 0) + (0 if streams is not None else n_side + n_main)
+        SADDetector._streams_created[dkey] = made
+        _runtime.check_stream_budget(max(n_side + n_main, made) + 1, HW_QUEUES_STATE)
         self._sides = (list(streams[0][:n_side]) if streams is not None else
                        [torch.cuda.Stream(device=self.device) for _ in range(n_side)])
         self._calls = 0

@@ -41,6 +41,7 @@ sys.path.insert(0, ROOT)
 # another FPS chain) would serialise them (measured: six FPS chains side by side keep their single-stream time,
 # eight on 8 queues take twice as long - tools/fps_concurrency.py).  Must be set before the runtime initialises;
 # `import sad_amd` does the same for any other caller (3dsad-main_amd/_runtime.py).
+HW_QUEUES_AT_START = os.environ.get("GPU_MAX_HW_QUEUES")      # what the process was started with (None: unset; recorded in the line)
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 PEAK_MFMA_F32_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: dense f32 MFMA
@@ -356,16 +357,18 @@ def measure(w: Workload, steps: int, warmup: int, rank: int, world: int, dev, ar
     gc.collect()
     gc.disable()
     out, last = None, 0
-    t0 = time.perf_counter()
-    for i in range(steps):
-        out, last = step()
-        step_marks[i].record(det.last_stream)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
+    try:                                          # (a failure inside must not leave the collector off for the later legs)
+        t0 = time.perf_counter()
+        for i in range(steps):
+            out, last = step()
+            step_marks[i].record(det.last_stream)
         torch.cuda.synchronize()
-    elapsed_local = time.perf_counter() - t0
-    gc.enable()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+        elapsed_local = time.perf_counter() - t0
+    finally:
+        gc.enable()
     assert out.shape == (world * B, cfg.n_cand, 9) and bool(torch.isfinite(out).all())
     got_boxes = out[:B].cpu().numpy()          # rank 0's own scenes come first in the gathered tensor; batch `last`
     points, points_np = batches[last], batches_np[last]
@@ -428,6 +431,7 @@ def measure(w: Workload, steps: int, warmup: int, rank: int, world: int, dev, ar
                    "parallelism": f"batch-sharded x{world}, one all_gather of boxes",
                    "fps_overlap": w.overlap, "fps_streams": w.fps_streams, "main_streams": w.main_streams, "opts": args.opt,
                    "queue_depth": w.queue_depth,
+                   "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"), "gpu_max_hw_queues_at_process_start": HW_QUEUES_AT_START,
                    "mlp_geometry": tuned if tuned else "heuristic", "mlp_geometry_source": geometry_source,
                    "mlp_geometry_hash": geom_hash},
     }

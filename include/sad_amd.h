@@ -46,10 +46,13 @@ typedef void *sad_stream_t; /* hipStream_t */
 int sad_version(void);
 const char *sad_last_error(void);
 /* Tuning / A-B knobs (process-wide; defaults 0 = automatic).  Returns SAD_EINVAL for an unknown key.
- *   fps_variant  1 pair kernel, 2 key kernel, 3 wave buckets, 4 cell buckets, 5 cell buckets over sorted records
+ *   fps_variant  1 pair kernel, 2 key kernel, 3 wave buckets, 4 cell buckets (second form of the kernel: the default for
+ *                N <= 16384), 5 cell buckets over sorted records (default for 16384 < N <= 65536), 6 cell buckets, FIRST form of
+ *                the kernel (lane-elected publish, five writelanes per bucket update: kept as the A/B baseline of round 4)
  *   fps_threads  cell-bucket geometry waves*100 + slots (e.g. 1616, 832); old kernels: 1024/512/256 threads
  *   fps_dpp      1 = DPP reductions in the pair kernel
  *   bq_variant   1 = grid query: always the LDS-bitmap path (no 64-lane sort for centroids with <= 64 candidates);
+ *                2 = grid query: ONE LDS bitmap set per workgroup (round 3's layout) instead of one per two waves;
  *                grid vs scan is the caller's choice: sad_ball_query_grid_f32 / sad_ball_query_multi_f32
  *   group_variant 1 = L2-gather group_points kernel only (no LDS staging)
  *   mlp_rw, mlp_budget_kb, mlp_force, mlp_dedup_f, mlp_nodedup, mlp_static, mlp_dyn_slots, mlp_noxcd: f32 chain geometry overrides

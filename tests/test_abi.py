@@ -210,18 +210,27 @@ def test_package_owns_hw_queue_precondition(monkeypatch):
     assert _runtime.ensure_hw_queues(env, initialised=False) == "user" and env["GPU_MAX_HW_QUEUES"] == "8"
     env = {}
     assert _runtime.ensure_hw_queues(env, initialised=True) == "late" and "GPU_MAX_HW_QUEUES" not in env
+    # torch imported, its CUDA flag still False: is_available() / a profiler preload may have brought HIP up unseen
+    env = {}
+    assert _runtime.ensure_hw_queues(env, initialised=None) == "unknown" and env["GPU_MAX_HW_QUEUES"] == "16"
     assert _runtime.hw_queues({}) == 4 and _runtime.hw_queues({"GPU_MAX_HW_QUEUES": "16"}) == 16
     assert _runtime.hw_queues({"GPU_MAX_HW_QUEUES": "x"}) == 4
     with warnings.catch_warnings():
         warnings.simplefilter("error")
         assert _runtime.check_stream_budget(6, "set", {"GPU_MAX_HW_QUEUES": "16"})        # default detector: 2 + 3 + 1
         assert _runtime.check_stream_budget(4, "late", {})                                # fits HIP's default 4
+        assert _runtime.check_stream_budget(4, "late", {})                                # ... every time (returned False on the second call)
+        assert _runtime.check_stream_budget(4, "unknown", {"GPU_MAX_HW_QUEUES": "16"})
+    with pytest.warns(RuntimeWarning, match="after torch was imported"):                                     # more than 4 streams on an export nobody may have read
+        assert _runtime.check_stream_budget(6, "unknown", {"GPU_MAX_HW_QUEUES": "16"})
+    _runtime._warned.discard(None)
+    assert _runtime.check_stream_budget(3, "late") and _runtime.check_stream_budget(3, "late")   # process-wide path (environ=None), twice
     with pytest.warns(RuntimeWarning, match="hardware queues"):
         assert not _runtime.check_stream_budget(6, "late", {})
     with pytest.warns(RuntimeWarning, match="share a"):
         assert not _runtime.check_stream_budget(9, "user", {"GPU_MAX_HW_QUEUES": "8"})
     # the import itself did it for this process (conftest imports nothing that touches the GPU first)
     import sad_amd
-    assert sad_amd.HW_QUEUES_STATE in ("set", "user")
+    assert sad_amd.HW_QUEUES_STATE in ("set", "user", "unknown")
     import os
     assert os.environ.get("GPU_MAX_HW_QUEUES")
