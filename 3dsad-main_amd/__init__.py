@@ -20,7 +20,7 @@ _LAZY = {
     "group_points": "ops", "gather_points": "ops", "gather_xyz": "ops",
     "mlp_chain": "ops", "PackedMLP": "ops", "nms_bev": "ops",
     "SAModuleMSG": "sa_module", "SAModule": "sa_module", "sa_module": "sa_module",
-    "SADDetector": "detector",
+    "SADDetector": "detector", "IngestPipeline": "pipeline",
     "shard_range": "dist", "all_gather_boxes": "dist", "run_sharded": "dist",
 }
 

@@ -84,6 +84,7 @@ SIGNATURES = {
                                               ctypes.POINTER(vp), ctypes.POINTER(vp),
                                               ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp]),
     "sad_subsample_pad_f32": (ctypes.c_int, [vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_uint, vp, vp]),
+    "sad_copy_rows_u32": (ctypes.c_int, [vp, ctypes.c_longlong, vp, ctypes.c_longlong, ctypes.c_longlong, ctypes.c_longlong, vp]),
     "sad_knn_f32": (ctypes.c_int, [vp, vp] + [ctypes.c_int] * 4 + [vp, vp]),
     "sad_mlp_packed_floats": (ctypes.c_size_t, [ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.c_int]),
     "sad_mlp_pack_f32": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.c_int,
@@ -118,6 +119,25 @@ SIGNATURES = {
 
 _lib = None
 
+# A step plan being recorded on this thread (plan.Recorder, else None): lib() then hands out a stand-in that passes every
+# launch through and appends it to the plan (3dsad-main_amd/plan.py).  Thread-local: another thread's launches are its own.
+import threading
+_tls = threading.local()
+
+
+def recorder():
+    return getattr(_tls, "rec", None)
+
+
+def set_recorder(rec) -> None:
+    _tls.rec = rec
+
+
+def is_launch(name: str) -> bool:
+    """Does this entry point enqueue device work (last argument: the stream)?  Size queries, options and the version do not."""
+    return (name.startswith("sad_") and not name.endswith(("_bytes", "_floats", "_bytes_bf16"))
+            and "preferred_geometry" not in name and name not in ("sad_version", "sad_last_error", "sad_set_option"))
+
 
 def build(force: bool = False) -> str:
     """Compile every HIP source for gfx950 with hipcc (csrc/Makefile).  Works without a GPU."""
@@ -147,7 +167,8 @@ def lib():
             raise RuntimeError(f"{SO_PATH}: ABI version {handle.sad_version()}, this binding needs {ABI_VERSION} "
                                "(stale build: run __graft_entry__.build())")
         _lib = handle
-    return _lib
+    rec = getattr(_tls, "rec", None)
+    return _lib if rec is None else rec.lib
 
 
 def check(code: int, what: str) -> None:

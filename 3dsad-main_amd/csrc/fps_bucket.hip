@@ -1029,9 +1029,9 @@ __global__ __launch_bounds__(1024) void fps_cellg_kernel(const float4 *__restric
         const unsigned uz = __builtin_amdgcn_readlane(__builtin_bit_cast(unsigned, r.z), l);                          \
         bmax = sad_writelane(hi, KS, bmax);                                                              \
         bidx = sad_writelane(bn, KS, bidx);                                                              \
-        bx = sad_writelane(ux, KS, bx);                                                                  \
-        by = sad_writelane(uy, KS, by);                                                                  \
-        bz = sad_writelane(uz, KS, bz);                                                                  \
+        bx = __builtin_bit_cast(float, sad_writelane(ux, KS, __builtin_bit_cast(unsigned, bx)));         \
+        by = __builtin_bit_cast(float, sad_writelane(uy, KS, __builtin_bit_cast(unsigned, by)));         \
+        bz = __builtin_bit_cast(float, sad_writelane(uz, KS, __builtin_bit_cast(unsigned, bz)));         \
         top = hi > top ? hi : top;                                                                                    \
     }
 

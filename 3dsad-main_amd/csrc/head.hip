@@ -140,3 +140,45 @@ SAD_API int sad_subsample_pad_f32(const float *points, const int32_t *offsets, i
                        points, offsets, C, n_points, seed, out);
     return sad::check_launch("sad_subsample_pad_f32");
 }
+
+// ---- strided row copy (the host side's replacement for framework copies on the step) -------------------------
+namespace {
+__global__ __launch_bounds__(256) void copy_rows_kernel(const unsigned *__restrict__ src, long long ss, unsigned *__restrict__ dst, long long ds,
+                                                        long long total, unsigned row_words) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long r = i / row_words;
+        const long long w = i - r * row_words;
+        dst[r * ds + w] = src[r * ss + w];
+    }
+}
+// rows of whole 16-byte chunks, both sides 16-byte aligned (the large copies: centroid prefixes, candidate rows)
+__global__ __launch_bounds__(256) void copy_rows4_kernel(const uint4 *__restrict__ src, long long ss4, uint4 *__restrict__ dst, long long ds4,
+                                                         long long total4, unsigned row4) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long long)gridDim.x * 256) {
+        const long long r = i / row4;
+        const long long w = i - r * row4;
+        dst[r * ds4 + w] = src[r * ss4 + w];
+    }
+}
+}  // namespace
+
+SAD_API int sad_copy_rows_u32(const void *src, long long src_stride_words, void *dst, long long dst_stride_words,
+                              long long n_rows, long long row_words, sad_stream_t stream) {
+    SAD_REQUIRE(src && dst, "sad_copy_rows_u32: NULL pointer");
+    SAD_REQUIRE(n_rows >= 1 && row_words >= 1 && row_words <= 0x7FFFFFFFll && src_stride_words >= 0 && dst_stride_words >= row_words,
+                "sad_copy_rows_u32: need n_rows >= 1, 1 <= row_words < 2^31, dst_stride_words >= row_words");
+    SAD_REQUIRE(((uintptr_t)src & 3) == 0 && ((uintptr_t)dst & 3) == 0, "sad_copy_rows_u32: pointers must be 4-byte aligned");
+    const bool v4 = (row_words % 4 == 0) && (src_stride_words % 4 == 0) && (dst_stride_words % 4 == 0) &&
+                    (((uintptr_t)src | (uintptr_t)dst) & 15) == 0;
+    const long long total = v4 ? n_rows * (row_words / 4) : n_rows * row_words;
+    long long blocks = (total + 255) / 256;
+    const long long cap = (long long)sad::device_cus() * 16;
+    if (blocks > cap) blocks = cap;
+    if (v4)
+        hipLaunchKernelGGL(copy_rows4_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const uint4 *>(src),
+                           src_stride_words / 4, reinterpret_cast<uint4 *>(dst), dst_stride_words / 4, total, (unsigned)(row_words / 4));
+    else
+        hipLaunchKernelGGL(copy_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const unsigned *>(src),
+                           src_stride_words, reinterpret_cast<unsigned *>(dst), dst_stride_words, total, (unsigned)row_words);
+    return sad::check_launch("sad_copy_rows_u32");
+}

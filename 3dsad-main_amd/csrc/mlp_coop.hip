@@ -171,7 +171,11 @@ __device__ __forceinline__ void coop_tile(const RegChain &c, const int tile, con
                 float ops[4];
                 xfix(xq[n % 3], r, ops);
                 t = mma4(t, a[p % 2], ops);
+#ifdef SAD_COOP_NOGATHER     // measurement build (wrong results): the feature rows are gathered for layer 0's FIRST output tile only
+                if (n + 3 < NT0) xq[n % 3] = xload((n + 3) % NT0);
+#else
                 if (n + 3 < NX) xq[n % 3] = xload((n + 3) % NT0);
+#endif
             } else {
                 const int i = r - NT0;
                 acc1[i >> 2] = mma4(acc1[i >> 2], a[p % 2], bt + 4 * (i & 3));

@@ -106,7 +106,13 @@ __device__ __forceinline__ Chunk load_chunk_of(const LayerJob &jb, const unsigne
             const int cc = ch < 0 ? 0 : (ch < jb.cpr ? ch : jb.cpr - 1);
             gb[u] = *reinterpret_cast<const float4 *>(xb + (size_t)(xoff + 16u * (unsigned)cc));
         } else {
+#if defined(SAD_LAYER_WHATIF) && SAD_LAYER_WHATIF >= 3      // measurement build (wrong results): no activation loads at all (a fused chain reads them from LDS)
+            gb[u] = make_float4(0.25f, 0.5f, 0.75f, 1.f);
+#elif defined(SAD_LAYER_WHATIF) && SAD_LAYER_WHATIF == 2    // every activation load hits row 0 (cache hits: the issue cost stays, the bytes go)
+            gb[u] = *reinterpret_cast<const float4 *>((xb + (size_t)g * 32) + (size_t)(16u * (unsigned)h));
+#else
             gb[u] = *reinterpret_cast<const float4 *>((xb + (size_t)g * 32) + (size_t)(xoff + 16u * (unsigned)h));
+#endif
         }
     }
     return Chunk{ga[0], ga[1], ga[KC > 2 ? 2 : 0], ga[KC > 2 ? 3 : 0], gb[0], gb[1], gb[KC > 2 ? 2 : 0], gb[KC > 2 ? 3 : 0]};
@@ -295,7 +301,11 @@ __device__ __forceinline__ Prefetched gemm_item(const LayerMulti &lm, const Laye
         const int j = lane & 31;
         if constexpr (!LAST) {
             // hidden layer: row-major output, 16 bytes per lane (padded channels are exact zeros)
+#if defined(SAD_LAYER_WHATIF) && SAD_LAYER_WHATIF >= 1      // measurement build: the hidden activations are not stored (one sentinel row keeps the code alive)
+            if (ri.live && ri.q == 0x7FFFFFF0) {
+#else
             if (ri.live) {
+#endif
                 float *yrow = jb.y + (long long)ri.q * jb.ldy + (ob * 4 + 2 * wx) * 32 + 4 * h;
 #pragma unroll
                 for (int oc = 0; oc < 2; ++oc)

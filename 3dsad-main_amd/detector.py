@@ -14,7 +14,9 @@ import numpy as np
 import torch
 from torch import nn
 
+from . import _lib as _libmod
 from . import ops
+from . import plan as _plan
 from ._lib import check, lib
 from .config import DetectorConfig
 from .sa_module import SAModuleMSG
@@ -97,32 +99,95 @@ class SADDetector(nn.Module):
         self._mains = (list(streams[1][:n_main]) if streams is not None else
                        [torch.cuda.Stream(device=self.device) for _ in range(n_main)])
         self._submits = 0
+        # Step plans (plan.py): submit() records the launches of a step once per ring slot and replays them afterwards.  The
+        # ring is a multiple of both stream counts, so a slot always meets the same (main, sampling) stream pair, and long
+        # enough (>= 12) that a caller with up to 11 steps in flight never waits for a slot; a slot's buffers (~0.3 GB for 32
+        # KITTI-shaped scenes) live as long as its plan.  ``use_plans=False`` (or any step that cannot be recorded) = the eager path.
+        import os
+        self.use_plans = not os.environ.get("SAD_NO_PLANS")      # (A/B switch for measurements: the eager path)
+        self.plan_refused = None           # why recording was given up, if it was
+        self.plan_replays = 0
+        self._plans = {}
+        import math
+        period = (len(self._mains) * max(1, len(self._sides))) // math.gcd(len(self._mains), max(1, len(self._sides)))
+        self._plan_ring = period * ((12 + period - 1) // period)
 
-    def submit(self, points: torch.Tensor, post=None):
+    def submit(self, points: torch.Tensor, post=None, ready=None):
         """Throughput entry point: enqueue one batch on the next main stream (round-robin) and
         return (result, done_event) without waiting.  ``points`` must already be resident and not
         be written by queued work (same promise as ``input_ready=True``).  ``post(boxes)`` is called
         with that stream current (e.g. the all_gather of a sharded job).  ``done_event`` covers
         everything that produces ``result``: when the hook moves work to a stream of its own and
         exposes its completion as ``post.event`` (``dist.AsyncBoxGather``), that event is returned,
-        otherwise one recorded on the main stream behind the hook."""
+        otherwise one recorded on the main stream behind the hook.  ``ready``: an event behind whatever produces ``points``
+        on another stream (``pipeline.IngestPipeline``: H2D copy + subsample / pad) — the sampling stream and the main stream
+        wait for it instead of for each other."""
         st = self._mains[self._submits % len(self._mains)]
+        slot = self._submits % self._plan_ring
         self._submits += 1
         self.last_stream = st
+        plan = None
+        if self._plannable(points):
+            key = (slot, tuple(points.shape), ready is not None)
+            plan = self._plans.get(key)
+            if plan is not None:
+                # replay: the slot's buffers are free once the step that last used them has completed
+                plan.done.synchronize()
+                self._calls += 1
+                plan.last_input = points                 # (held until the slot's next use: a replay records no stream use for the allocator)
+                out = plan.replay(points.data_ptr(), ready)
+                ev = None
+                if post is not None:
+                    with torch.cuda.stream(st):
+                        out = post(out)
+                    ev = getattr(post, "event", None)
+                plan.done.record(st)
+                self.plan_replays += 1
+                return out, (ev if ev is not None else plan.done)
         with torch.cuda.stream(st):
-            out = self.forward(points, input_ready=True)
+            if plan is None and self._plannable(points):
+                rec = _plan.Recorder()
+                _libmod.set_recorder(rec)
+                try:
+                    out = self.forward(points, input_ready=True, ready=ready)
+                    plan = rec.finish(out, st)
+                    self._plans[key] = plan
+                except _plan.PlanUnsupported as e:            # something on this step cannot be recorded: stay eager for good
+                    _libmod.set_recorder(None)
+                    self.use_plans, self.plan_refused = False, str(e)
+                    out = self.forward(points, input_ready=True, ready=ready)
+                finally:
+                    _libmod.set_recorder(None)
+            else:
+                out = self.forward(points, input_ready=True, ready=ready)
             ev = None
             if post is not None:
                 out = post(out)
                 ev = getattr(post, "event", None)
+            if plan is not None:
+                plan.done.record(st)
+                if ev is None:
+                    ev = plan.done
             if ev is None:
                 ev = torch.cuda.Event()
                 ev.record(st)
         return out, ev
 
+    def _plannable(self, points) -> bool:
+        """May this submit() go through a step plan (plan.py)?  Not while tuning, tracing launches or poisoning buffers, and
+        only for the packed float32 input the recorded launches were made for."""
+        return (self.use_plans and self.overlap_fps and self.query_on_sampling_stream and not ops.AUTOTUNE
+                and ops.LAUNCH_LOG is None and ops.RERUN_LOG is None and not self.poison_buffers
+                and points.is_cuda and points.dtype == torch.float32 and points.dim() == 3 and points.is_contiguous())
+
+    def clear_plans(self) -> None:
+        """Drop every recorded step plan and the buffers they own (geometry changes call this)."""
+        self._plans.clear()
+
     def autotune(self, points: torch.Tensor) -> dict:
         """One synchronous forward pass during which every MLP launch times its workgroup
         geometries on the real shapes and keeps the fastest.  Returns {launch name: geometry}."""
+        self.clear_plans()
         prev, ops.AUTOTUNE = ops.AUTOTUNE, True
         ov, self.overlap_fps = self.overlap_fps, False
         try:
@@ -153,6 +218,7 @@ class SADDetector(nn.Module):
         """Use a saved ``geometry()`` / ``autotune()`` result instead of measuring again (reproducible
         runs: rocprofv3 then sees steady-state launches only).  Codes are validated by the C-ABI at
         launch time (an unusable code raises, it is never silently replaced)."""
+        self.clear_plans()
         for m in self.mlps():
             if m.name in geometry:
                 m._geom.clear()
@@ -170,7 +236,7 @@ class SADDetector(nn.Module):
         point.  By induction fps(cur, M) = (0, 1, ..., M-1), so the centroids are cur[:, :M]."""
         m = self.stages[si]
         if si > 0 and self.nested_fps_shortcut and m.stage.npoint <= cur.shape[1]:
-            return cur[:, :m.stage.npoint].contiguous()
+            return ops.prefix_rows(cur, m.stage.npoint)          # (a library launch, not a framework copy: recordable, plan.py)
         return m.sample(cur)[1]
 
     def _sample_chain(self, xyz):
@@ -183,7 +249,7 @@ class SADDetector(nn.Module):
         return out
 
     def forward(self, points: torch.Tensor, trace: Optional[dict] = None,
-                input_ready: bool = False) -> torch.Tensor:
+                input_ready: bool = False, ready=None) -> torch.Tensor:
         """points [B,N,3+in_feat] f32 on the GPU -> boxes [B,K,9].
 
         ``input_ready=True`` promises that ``points`` is not being produced by work still queued on
@@ -193,32 +259,66 @@ class SADDetector(nn.Module):
         cfg = self.cfg
         if not points.is_cuda:
             raise RuntimeError("points: expected a GPU tensor (sad_amd has no CPU path)")
+        if points.dtype != torch.float32 or points.dim() != 3:
+            raise TypeError("points: expected a float32 [B,N,3+C] tensor")
+        if not points.is_contiguous():
+            ops._unrecordable("points: strided copy")
         points = points.contiguous()
         B, N, D = points.shape
-        feat = points[:, :, 3:] if D > 3 else None   # strided view [B,N,in_feat], no copy
         main = torch.cuda.current_stream()
+        rec = _libmod.recorder()                       # a step plan is being recorded (submit): events and waits go into it too
+        if rec is not None:
+            rec.mark_input(points)
+
+        def new_event(stream):
+            if rec is not None:
+                return rec.event(stream)
+            e = torch.cuda.Event()
+            e.record(stream)
+            return e
+
+        def wait_for(stream, e):
+            if e is None:
+                return
+            if rec is not None:
+                rec.wait(stream, e)
+            else:
+                stream.wait_event(e)
+
+        def wait_ready(stream):                        # `points` is produced on a third stream: everything below waits for it
+            if ready is None:
+                return
+            if rec is not None:
+                rec.wait_ready(stream, ready)
+            else:
+                stream.wait_event(ready)
+
+        wait_ready(main)
         if self.overlap_fps:
             side = self._sides[self._calls % len(self._sides)]
             self._calls += 1
+            wait_ready(side)
             if not input_ready:
+                ops._unrecordable("forward without input_ready")
                 side.wait_stream(main)
             evs = []
             with torch.cuda.stream(side):
-                xyz = points[:, :, :3].contiguous()
-                if feat is not None and self.dtype == "f32" and not ops.PackedMLP.feat_fits_table_kernels(
-                        feat.shape[2], feat.stride(1), feat.data_ptr()):
-                    # e.g. [B,N,7] nuScenes-shaped points: a 4-channel view with row stride 7 cannot be fetched in 16-byte
-                    # chunks; one packed copy (33 MB at 32 x 65 536 points) keeps SA1 on the register-resident kernel
-                    feat = feat.contiguous()
+                # coordinates and features as packed operands (two launches of the library: every device operation of a
+                # step is one, so a step can be recorded and replayed — plan.py; the intensity channel of a [B,N,4] KITTI
+                # batch used to be read in place as a strided view, 2 MB more are written now)
+                xyz, feat = ops.split_points(points)
                 # the pooling buffers of every stage, one allocation.  With the row-packing scans made here (prescan), the scan
                 # zero-fills the few groups the chain kernels combine with an atomic max and the buffers stay uninitialised
                 # (217 MB per 32-scene KITTI step not filled); otherwise one zero fill, covered by ev_xyz
                 prep = self.query_on_sampling_stream and not ops.AUTOTUNE
                 shapes = [(B, m.stage.npoint, m.cat_channels) for m in self.stages]
                 shapes.append((B, cfg.n_cand, self.cluster_cat))
-                zeros = (torch.empty if prep else torch.zeros)((sum(a * b_ * c_ for a, b_, c_ in shapes),), dtype=torch.float32,
-                                                               device=points.device)
+                if not prep:
+                    ops._unrecordable("zero-filled pooling buffers")
+                zeros = (ops._empty if prep else torch.zeros)((sum(a * b_ * c_ for a, b_, c_ in shapes),), dtype=torch.float32,
+                                                              device=points.device)
                 if prep and self.poison_buffers:      # (tests: whatever the kernels do not write must not matter)
+                    ops._unrecordable("poisoned buffers")
                     zeros.fill_(float("nan"))
                 cats, o = [], 0
                 for shp in shapes:
@@ -232,9 +332,9 @@ class SADDetector(nn.Module):
                     fdt = torch.bfloat16 if (self.dtype == "bf16" and self.stages[-1].agg is not None) else torch.float32
                     if not all(mlp.wants_prescan(B, m3, cfg.n_cand, s_, self.cluster_cat, cin, feat_dtype=fdt)
                                for mlp, s_ in zip(self.cluster_branches, cfg.cluster_nsamples)):
+                        ops._unrecordable("zero fill of the cluster pooling buffer")
                         cats[-1].zero_()
-                ev_xyz = torch.cuda.Event()
-                ev_xyz.record(side)
+                ev_xyz = new_event(side)
                 cur = xyz
                 centroids = []
                 queries = []
@@ -249,9 +349,7 @@ class SADDetector(nn.Module):
                                                          feat=feat if si == 0 else None,
                                                          feat_dtype=torch.bfloat16 if (self.dtype == "bf16" and prev_agg) else torch.float32)
                                    if self.query_on_sampling_stream else None)
-                    ev = torch.cuda.Event()
-                    ev.record(side)
-                    evs.append(ev)
+                    evs.append(new_event(side))
             points.record_stream(side)
             for t in centroids + [xyz] + ([feat] if feat is not None else []):
                 t.record_stream(main)
@@ -262,20 +360,16 @@ class SADDetector(nn.Module):
                             if t is not None:          # (a branch whose kernel packs for itself has no prescanned table)
                                 t.record_stream(main)
             zeros.record_stream(main)
-            main.wait_event(ev_xyz)
+            wait_for(main, ev_xyz)
         else:
-            xyz = points[:, :, :3].contiguous()
-            if feat is not None and self.dtype == "f32" and not ops.PackedMLP.feat_fits_table_kernels(
-                    feat.shape[2], feat.stride(1), feat.data_ptr()):
-                feat = feat.contiguous()
+            xyz, feat = ops.split_points(points)
             centroids = self._sample_chain(xyz)
             evs = [None] * len(centroids)
             queries = [None] * len(centroids)
             cats = [None] * (len(centroids) + 1)
         cur_xyz, cur_feat = xyz, feat
         for si, m in enumerate(self.stages):
-            if evs[si] is not None:
-                main.wait_event(evs[si])
+            wait_for(main, evs[si])
             new_xyz = centroids[si]
             cur_feat = m.group_and_pool(cur_xyz, cur_feat, new_xyz, query=queries[si], cat=cats[si],
                                         keep=None if trace is None else trace.setdefault(f"sa{si + 1}", {}))
@@ -285,9 +379,10 @@ class SADDetector(nn.Module):
         # ---- size-adaptive cluster layer (SPEC.md §8) ----------------------------------------
         K = cfg.n_cand
         M3 = cur_xyz.shape[1]
-        c = self.cand_mlp.rows(cur_feat[:, :K, :])                      # [B,K,6]
-        cand = torch.empty((B, K, 3), dtype=torch.float32, device=points.device)
-        rad = torch.empty((B, K), dtype=torch.float32, device=points.device)
+        # (the first K rows of every scene as a packed operand: one library launch, 4 - 8 MB)
+        c = self.cand_mlp.rows(cur_feat if K == M3 else ops.prefix_rows(cur_feat, K))     # [B,K,6]
+        cand = ops._empty((B, K, 3), dtype=torch.float32, device=points.device)
+        rad = ops._empty((B, K), dtype=torch.float32, device=points.device)
         check(lib().sad_candidates_f32(cur_xyz.data_ptr(), c.data_ptr(), B, M3, K, cfg.shift_max,
                                        cfg.r_min, cfg.r_max, self._anchor, cand.data_ptr(),
                                        rad.data_ptr(), main.cuda_stream), "sad_candidates_f32")
@@ -295,6 +390,7 @@ class SADDetector(nn.Module):
                                           return_counts=True)
         cat = cats[-1]
         if cat is None:
+            ops._unrecordable("zero-filled cluster pooling buffer")
             cat = torch.zeros((B, K, self.cluster_cat), dtype=torch.float32, device=points.device)
         calls, off = [], 0
         for mlp, idx, cnt in zip(self.cluster_branches, idxs, cnts):
@@ -308,7 +404,7 @@ class SADDetector(nn.Module):
         else:
             cfeat = self.cluster_agg.rows(cat)
             o = self.head.rows(cfeat)                                    # [B,K,10]
-        boxes = torch.empty((B, K, 9), dtype=torch.float32, device=points.device)
+        boxes = ops._empty((B, K, 9), dtype=torch.float32, device=points.device)
         check(lib().sad_decode_boxes_f32(cand.data_ptr(), o.data_ptr(), B, K, self._anchors,
                                          boxes.data_ptr(), main.cuda_stream), "sad_decode_boxes_f32")
         if trace is not None:

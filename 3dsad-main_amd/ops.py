@@ -23,6 +23,66 @@ def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
+def _empty(*a, **k) -> torch.Tensor:
+    """torch.empty; while a step plan is recorded (plan.py) the plan keeps the buffer, so its address stays valid for replays."""
+    rec = _lib.recorder()
+    return torch.empty(*a, **k) if rec is None else rec.empty(*a, **k)
+
+
+def _unrecordable(what: str) -> None:
+    """In front of any framework kernel on the step path (fill, strided copy): an error while a plan records, nothing otherwise."""
+    if _lib.recorder() is not None:
+        from .plan import PlanUnsupported
+        raise PlanUnsupported(what)
+
+
+def copy_rows(src: torch.Tensor, src_off_words: int, src_stride_words: int, n_rows: int, row_words: int,
+              out: torch.Tensor, dst_stride_words: Optional[int] = None) -> torch.Tensor:
+    """Strided row copy in 4-byte words through the library (``sad_copy_rows_u32``): row r of ``out`` = words
+    [0, row_words) of row r of ``src`` starting at word ``src_off_words``, rows ``src_stride_words`` apart.  ``out`` must be
+    contiguous.  The host side's replacement for framework copies on the step (recordable: plan.py)."""
+    check(lib().sad_copy_rows_u32(src.data_ptr() + 4 * int(src_off_words), int(src_stride_words), out.data_ptr(),
+                                  int(row_words if dst_stride_words is None else dst_stride_words), int(n_rows), int(row_words),
+                                  _stream()), "sad_copy_rows_u32")
+    return out
+
+
+def copy_to_host(src: torch.Tensor, dst_pinned: torch.Tensor) -> None:
+    """Device tensor -> PINNED host tensor of the same byte size, written by a kernel of the library over the bus (pinned
+    memory is device-addressable; visible to the host once the launching stream has reached an event behind this call).
+    For the few hundred KB a step hands back (boxes, NMS order and counts): a copy-engine transfer per tensor shared its
+    queue with the step's H2D transfer and a few steps in a hundred stalled for milliseconds (tools/probe/pipeline_probe.py)."""
+    if not src.is_cuda or not src.is_contiguous() or dst_pinned.is_cuda or not dst_pinned.is_pinned() or not dst_pinned.is_contiguous():
+        raise TypeError("copy_to_host: expected a contiguous GPU source and a contiguous pinned host destination")
+    nbytes = src.numel() * src.element_size()
+    if nbytes != dst_pinned.numel() * dst_pinned.element_size() or nbytes % 4 != 0:
+        raise ValueError("copy_to_host: sizes differ (or are not whole 4-byte words)")
+    check(lib().sad_copy_rows_u32(src.data_ptr(), nbytes // 4, dst_pinned.data_ptr(), nbytes // 4, 1, nbytes // 4, _stream()),
+          "sad_copy_rows_u32")
+
+
+def split_points(points: torch.Tensor):
+    """points [B,N,3+C] f32 contiguous -> (xyz [B,N,3], feat [B,N,C] or None), both packed (two library launches)."""
+    B, N, D = points.shape
+    xyz = _empty((B, N, 3), dtype=torch.float32, device=points.device)
+    copy_rows(points, 0, D, B * N, 3, xyz)
+    feat = None
+    if D > 3:
+        feat = _empty((B, N, D - 3), dtype=torch.float32, device=points.device)
+        copy_rows(points, 3, D, B * N, D - 3, feat)
+    return xyz, feat
+
+
+def prefix_rows(x: torch.Tensor, m: int) -> torch.Tensor:
+    """x [B,M,C] contiguous (C * element size a multiple of 4 bytes) -> packed copy of x[:, :m, :] (one library launch)."""
+    B, M, C = x.shape
+    rb = C * x.element_size()
+    if rb % 4 != 0 or not x.is_contiguous() or not x.is_cuda:
+        raise TypeError("prefix_rows: expected a contiguous GPU tensor whose rows are whole 4-byte words")
+    out = _empty((B, m, C), dtype=x.dtype, device=x.device)
+    return copy_rows(x, 0, M * rb // 4, B, m * rb // 4, out)
+
+
 # Optional per-launch timing for bench.py: when LAUNCH_LOG is a list, every operator brackets its
 # C-ABI call with HIP events recorded on the stream the kernel is launched on and appends
 # (kind, name, start_event, end_event).  None (the default) adds nothing to the launch path.
@@ -79,6 +139,8 @@ def _need(t: torch.Tensor, name: str, dtype, ndim: int) -> torch.Tensor:
         raise TypeError(f"{name}: expected dtype {dtype}, got {t.dtype}")
     if t.dim() != ndim:
         raise ValueError(f"{name}: expected {ndim} dims, got shape {tuple(t.shape)}")
+    if not t.is_contiguous():
+        _unrecordable(f"{name}: strided copy")
     return t.contiguous()
 
 
@@ -90,9 +152,9 @@ def fps(xyz: torch.Tensor, npoint: int) -> torch.Tensor:
         raise ValueError("xyz: last dim must be 3")
     if not 1 <= npoint <= N:
         raise ValueError(f"npoint={npoint} must be in 1..N={N}")
-    idx = torch.empty((B, npoint), dtype=torch.int32, device=xyz.device)
+    idx = _empty((B, npoint), dtype=torch.int32, device=xyz.device)
     ws_bytes = lib().sad_fps_workspace_bytes(B, N)
-    ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=xyz.device) if ws_bytes else None
+    ws = _empty((ws_bytes,), dtype=torch.uint8, device=xyz.device) if ws_bytes else None
     with _timed("fps", f"N{N}"):
         check(lib().sad_fps_f32(xyz.data_ptr(), B, N, npoint, idx.data_ptr(),
                                 ws.data_ptr() if ws is not None else None, _stream()), "sad_fps_f32")
@@ -111,8 +173,8 @@ def ffps(xyz: torch.Tensor, feat_pm: torch.Tensor, npoint: int, w_xyz: float = 1
         feat_pm = feat_pm.contiguous()
     if not 1 <= npoint <= N:
         raise ValueError(f"npoint={npoint} must be in 1..N={N}")
-    idx = torch.empty((B, npoint), dtype=torch.int32, device=xyz.device)
-    ws = torch.empty((lib().sad_ffps_workspace_bytes(B, N),), dtype=torch.uint8, device=xyz.device)
+    idx = _empty((B, npoint), dtype=torch.int32, device=xyz.device)
+    ws = _empty((lib().sad_ffps_workspace_bytes(B, N),), dtype=torch.uint8, device=xyz.device)
     with _timed("fps", f"F{N}"):
         check(lib().sad_ffps_f32(xyz.data_ptr(), feat_pm.data_ptr(), feat_pm.stride(1), B, N,
                                  feat_pm.shape[2], npoint, float(w_xyz), idx.data_ptr(), ws.data_ptr(),
@@ -133,7 +195,7 @@ def gather_xyz(xyz: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
     idx = _need(idx, "idx", torch.int32, 2)
     B, N, _ = xyz.shape
     M = idx.shape[1]
-    out = torch.empty((B, M, 3), dtype=torch.float32, device=xyz.device)
+    out = _empty((B, M, 3), dtype=torch.float32, device=xyz.device)
     check(lib().sad_gather_xyz_f32(xyz.data_ptr(), idx.data_ptr(), B, N, M, out.data_ptr(), _stream()),
           "sad_gather_xyz_f32")
     return out
@@ -148,7 +210,7 @@ def gather_points(features: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
         raise TypeError("features: element size must be 2 or 4 bytes")
     B, C, N = features.shape
     M = idx.shape[1]
-    out = torch.empty((B, C, M), dtype=features.dtype, device=features.device)
+    out = _empty((B, C, M), dtype=features.dtype, device=features.device)
     check(lib().sad_gather_points(features.data_ptr(), idx.data_ptr(), B, C, N, M, esz,
                                   out.data_ptr(), _stream()), "sad_gather_points")
     return out
@@ -163,14 +225,15 @@ def group_points(features: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
         raise TypeError("features: element size must be 2 or 4 bytes")
     B, C, N = features.shape
     _, M, S = idx.shape
-    out = torch.empty((B, C, M, S), dtype=features.dtype, device=features.device)
+    out = _empty((B, C, M, S), dtype=features.dtype, device=features.device)
     with _timed("group_points", f"C{C}N{N}M{M}S{S}"):
         check(lib().sad_group_points(features.data_ptr(), idx.data_ptr(), B, C, N, M, S, esz,
                                      out.data_ptr(), _stream()), "sad_group_points")
     return out
 
 
-def subsample_pad(points: torch.Tensor, offsets: torch.Tensor, n_points: int, seed: int = 0) -> torch.Tensor:
+def subsample_pad(points: torch.Tensor, offsets: torch.Tensor, n_points: int, seed: int = 0,
+                  out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Ragged scenes -> a fixed point count on the GPU (SPEC.md §17; the step before the path).
     points [total, C] f32 (all scenes concatenated), offsets [B+1] int32 on the GPU -> [B, n_points, C]:
     more points than needed = an evenly spread subset in file order, fewer = all points then hashed
@@ -181,7 +244,10 @@ def subsample_pad(points: torch.Tensor, offsets: torch.Tensor, n_points: int, se
     if B < 1:
         raise ValueError("offsets must have B + 1 >= 2 entries")
     C = points.shape[1]
-    out = torch.empty((B, n_points, C), dtype=torch.float32, device=points.device)
+    if out is None:
+        out = _empty((B, n_points, C), dtype=torch.float32, device=points.device)
+    elif tuple(out.shape) != (B, n_points, C) or out.dtype != torch.float32 or not out.is_contiguous() or out.device != points.device:
+        raise ValueError(f"out: expected a contiguous float32 [{B},{n_points},{C}] tensor on {points.device}")
     check(lib().sad_subsample_pad_f32(points.data_ptr(), offsets.data_ptr(), B, C, int(n_points),
                                       int(seed) & 0xFFFFFFFF, out.data_ptr(), _stream()), "sad_subsample_pad_f32")
     return out
@@ -197,7 +263,7 @@ def ball_query(radius: Union[float, torch.Tensor], nsample: int, xyz: torch.Tens
     M = new_xyz.shape[1]
     if new_xyz.shape[0] != B:
         raise ValueError("xyz / new_xyz batch mismatch")
-    idx = torch.empty((B, M, nsample), dtype=torch.int32, device=xyz.device)
+    idx = _empty((B, M, nsample), dtype=torch.int32, device=xyz.device)
     if isinstance(radius, torch.Tensor):
         rad = _need(radius, "radius", torch.float32, 2)
         if tuple(rad.shape) != (B, M):
@@ -226,11 +292,11 @@ def ball_query_multi(radii: Sequence[float], nsamples: Sequence[int], xyz: torch
     n = len(radii)
     if n != len(nsamples) or not 1 <= n <= _lib.MAX_RADII:
         raise ValueError(f"need 1..{_lib.MAX_RADII} radii with matching nsamples")
-    outs = [torch.empty((B, M, s), dtype=torch.int32, device=xyz.device) for s in nsamples]
+    outs = [_empty((B, M, s), dtype=torch.int32, device=xyz.device) for s in nsamples]
     r_arr = (ctypes.c_float * n)(*[float(np.float32(r)) for r in radii])
     s_arr = (ctypes.c_int * n)(*[int(s) for s in nsamples])
     p_arr = (vp * n)(*[o.data_ptr() for o in outs])
-    cnts = [torch.empty((B, M), dtype=torch.int32, device=xyz.device) for _ in nsamples] if return_counts else None
+    cnts = [_empty((B, M), dtype=torch.int32, device=xyz.device) for _ in nsamples] if return_counts else None
     c_arr = (vp * n)(*[c.data_ptr() for c in cnts]) if return_counts else None
     pc = None
     if radius_pc is not None:
@@ -240,7 +306,7 @@ def ball_query_multi(radii: Sequence[float], nsamples: Sequence[int], xyz: torch
         pc = radius_pc.data_ptr()
     if pc is None and N >= GRID_MIN_POINTS and N <= 65536 and min(radii) > 0:
         # grid-pruned kernel: same indices, ~100x fewer pair tests (csrc/ball_query_grid.hip)
-        ws = torch.empty((lib().sad_ball_query_grid_workspace_bytes(B, N),), dtype=torch.uint8,
+        ws = _empty((lib().sad_ball_query_grid_workspace_bytes(B, N),), dtype=torch.uint8,
                          device=xyz.device)
         with _timed("ball_query", f"N{N}M{M}x{n}"):
             check(lib().sad_ball_query_grid_f32(xyz.data_ptr(), new_xyz.data_ptr(), n, r_arr, s_arr, p_arr,
@@ -271,7 +337,7 @@ def rowscan_multi(idxs: Sequence[torch.Tensor], cnts: Sequence[torch.Tensor], N:
         cnt = _need(cnt, "cnt", torch.int32, 2)
         if tuple(idx.shape[:2]) != (B, M) or tuple(cnt.shape) != (B, M):
             raise ValueError("idx / cnt shapes do not match")
-        wss.append(torch.empty((lib().sad_mlp_workspace_bytes(B, M, idx.shape[2]),), dtype=torch.uint8, device=idx.device))
+        wss.append(_empty((lib().sad_mlp_workspace_bytes(B, M, idx.shape[2]),), dtype=torch.uint8, device=idx.device))
     c_arr = (vp * n)(*[c.data_ptr() for c in cnts])
     i_arr = (vp * n)(*[i.data_ptr() for i in idxs])
     s_arr = (ctypes.c_int * n)(*[int(i.shape[2]) for i in idxs])
@@ -324,13 +390,21 @@ def knn_query(k: int, xyz: torch.Tensor, new_xyz: torch.Tensor) -> torch.Tensor:
     new_xyz = _need(new_xyz, "new_xyz", torch.float32, 3)
     B, N, _ = xyz.shape
     M = new_xyz.shape[1]
-    idx = torch.empty((B, M, k), dtype=torch.int32, device=xyz.device)
+    idx = _empty((B, M, k), dtype=torch.int32, device=xyz.device)
     check(lib().sad_knn_f32(xyz.data_ptr(), new_xyz.data_ptr(), B, N, M, k, idx.data_ptr(), _stream()),
           "sad_knn_f32")
     return idx
 
 
-def nms_bev(boxes: torch.Tensor, iou_thr: float, score_thr: float = 0.0, single_kernel: bool = False
+def nms_bev_buffers(B: int, K: int, device) -> tuple:
+    """(keep [B,K], order [B,K], count [B], workspace) for ``nms_bev(..., out=...)``: a caller that runs NMS every step
+    allocates them once (pipeline.py)."""
+    return (torch.empty((B, K), dtype=torch.int32, device=device), torch.empty((B, K), dtype=torch.int32, device=device),
+            torch.empty((B,), dtype=torch.int32, device=device),
+            torch.empty((lib().sad_nms_bev_workspace_bytes(B, K),), dtype=torch.uint8, device=device))
+
+
+def nms_bev(boxes: torch.Tensor, iou_thr: float, score_thr: float = 0.0, single_kernel: bool = False, out: Optional[tuple] = None
             ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
     """Rotated-box NMS in bird's-eye view (SPEC.md §13).  boxes [B,K,9] f32, K <= 512 ->
     (keep [B,K] int32 0/1, order [B,K] int32 kept indices in rank order (-1 padded), count [B]).
@@ -340,16 +414,23 @@ def nms_bev(boxes: torch.Tensor, iou_thr: float, score_thr: float = 0.0, single_
     B, K, nine = boxes.shape
     if nine != 9:
         raise ValueError("boxes: last dim must be 9 (x,y,z,l,w,h,yaw,score,label)")
-    keep = torch.empty((B, K), dtype=torch.int32, device=boxes.device)
-    order = torch.empty((B, K), dtype=torch.int32, device=boxes.device)
-    count = torch.empty((B,), dtype=torch.int32, device=boxes.device)
+    ws = None
+    if out is not None:                 # buffers from nms_bev_buffers(B, K, device)
+        keep, order, count, ws = out
+        if tuple(keep.shape) != (B, K) or tuple(order.shape) != (B, K) or tuple(count.shape) != (B,) or keep.device != boxes.device:
+            raise ValueError("out: buffers of another shape or device (nms_bev_buffers(B, K, device))")
+    else:
+        keep = _empty((B, K), dtype=torch.int32, device=boxes.device)
+        order = _empty((B, K), dtype=torch.int32, device=boxes.device)
+        count = _empty((B,), dtype=torch.int32, device=boxes.device)
     with _timed("nms", f"K{K}"):
         if single_kernel:
             check(lib().sad_nms_bev_f32(boxes.data_ptr(), B, K, float(np.float32(iou_thr)),
                                         float(np.float32(score_thr)), keep.data_ptr(), order.data_ptr(),
                                         count.data_ptr(), _stream()), "sad_nms_bev_f32")
         else:
-            ws = torch.empty((lib().sad_nms_bev_workspace_bytes(B, K),), dtype=torch.uint8, device=boxes.device)
+            if ws is None:
+                ws = _empty((lib().sad_nms_bev_workspace_bytes(B, K),), dtype=torch.uint8, device=boxes.device)
             check(lib().sad_nms_bev_ws_f32(boxes.data_ptr(), B, K, float(np.float32(iou_thr)),
                                            float(np.float32(score_thr)), keep.data_ptr(), order.data_ptr(),
                                            count.data_ptr(), ws.data_ptr(), _stream()), "sad_nms_bev_ws_f32")
@@ -390,7 +471,7 @@ class PackedMLP:
         self.relu_mask = (1 << self.L) - 1 if relu_mask is None else int(relu_mask)
         dims_c = (ctypes.c_int * (self.L + 1))(*self.dims)
         n = lib().sad_mlp_packed_floats(self.L, dims_c, int(self.first_has_xyz))
-        self.packed = torch.empty((n,), dtype=torch.float32, device=self.device)
+        self.packed = _empty((n,), dtype=torch.float32, device=self.device)
         w_arr = (vp * self.L)(*[w.data_ptr() for w in ws])
         b_arr = (vp * self.L)(*[b.data_ptr() for b in bs])
         with torch.cuda.device(self.device):
@@ -544,6 +625,7 @@ class PackedMLP:
             if not feat_pm.is_cuda or feat_pm.dtype != torch.float32 or feat_pm.dim() != 3:
                 raise TypeError("feat_pm: expected a GPU float32 [B,N,C] tensor")
             if feat_pm.stride(2) != 1 or feat_pm.stride(0) != N * feat_pm.stride(1):
+                _unrecordable("feat_pm: strided copy")
                 feat_pm = feat_pm.contiguous()
             C = feat_pm.shape[2]
             a.feat = feat_pm.data_ptr()
@@ -555,6 +637,7 @@ class PackedMLP:
         if self.dims[0] != C + 3:
             raise ValueError(f"MLP expects {self.dims[0] - 3} feature channels, got {C}")
         if out is None:   # the kernel max-combines into the buffer: it must start at zero
+            _unrecordable("grouped: zero-filled output")
             out = torch.zeros((B, M, self.out_channels), dtype=torch.float32, device=xyz.device)
         if self.relu_mask != (1 << self.L) - 1:
             raise RuntimeError("grouped chains need a ReLU after every layer (max-pool combine)")
@@ -566,7 +649,7 @@ class PackedMLP:
                 raise ValueError("cnt must be [B,M]")
             a.cnt = cnt.data_ptr()
             if ws is None:
-                ws = torch.empty((lib().sad_mlp_workspace_bytes(B, M, S),), dtype=torch.uint8, device=xyz.device)
+                ws = _empty((lib().sad_mlp_workspace_bytes(B, M, S),), dtype=torch.uint8, device=xyz.device)
             else:             # table already filled by rowscan_multi (geometries 2 / 3 then launch no scan)
                 if ws.numel() < lib().sad_mlp_workspace_bytes(B, M, S):
                     raise ValueError("ws: too small for this (B, M, S)")
@@ -587,7 +670,7 @@ class PackedMLP:
         if self._layered_ok and cnt is not None and (a.geometry == 3 or AUTOTUNE):
             dims_c = (ctypes.c_int * (self.L + 1))(*self.dims)
             nbytes = lib().sad_mlp_scratch_bytes(B, M, S, self.L, dims_c)
-            sc = torch.empty((nbytes,), dtype=torch.uint8, device=xyz.device)
+            sc = _empty((nbytes,), dtype=torch.uint8, device=xyz.device)
             a.scratch, a.scratch_bytes = sc.data_ptr(), nbytes
             keep.append(sc)
         return a, out, keep
@@ -603,12 +686,14 @@ class PackedMLP:
         C = x.shape[-1]
         if C != self.dims[0]:
             raise ValueError(f"MLP expects {self.dims[0]} channels, got {C}")
+        if not x.is_contiguous():
+            _unrecordable("rows: strided input")
         x2 = x.reshape(-1, C)
         if x2.stride(1) != 1:
             x2 = x2.contiguous()
         R = x2.shape[0]
         if out is None:
-            out = torch.empty(tuple(x.shape[:-1]) + (self.out_channels,), dtype=torch.float32,
+            out = _empty(tuple(x.shape[:-1]) + (self.out_channels,), dtype=torch.float32,
                               device=x.device)
         self._check_out(out, R, col_off)
         a = self._args()
@@ -620,7 +705,7 @@ class PackedMLP:
         if self._layered_ok and self.L > 1 and (geom == 3 or AUTOTUNE):   # activations between the layer launches
             dims_c = (ctypes.c_int * (self.L + 1))(*self.dims)
             nbytes = lib().sad_mlp_scratch_bytes(1, R, 1, self.L, dims_c)
-            sc = torch.empty((nbytes,), dtype=torch.uint8, device=x.device)
+            sc = _empty((nbytes,), dtype=torch.uint8, device=x.device)
             a.scratch, a.scratch_bytes = sc.data_ptr(), nbytes
         self._launch(a, [x2, out, sc])
         return out
@@ -661,6 +746,9 @@ def grouped_multi(calls) -> None:
     bf16 = isinstance(calls[0][0], PackedMLPBf16)
     if any(isinstance(c[0], PackedMLPBf16) != bf16 for c in calls):
         raise TypeError("grouped_multi: all chains must be of the same class (f32 or bf16)")
+    _rec = _lib.recorder()
+    if _rec is not None:             # (a recorded step replays this dispatch: its argument blocks live as long as the plan)
+        _rec.keep.append((args, keep))
     with _timed("mlp", "+".join(c[0].name for c in calls)):
         if bf16:
             arr = (ctypes.POINTER(_lib.MlpBf16Args) * len(args))(*[ctypes.pointer(a) for a in args])
@@ -751,7 +839,7 @@ class PackedMLPBf16:
         self.relu_mask = (1 << self.L) - 1 if relu_mask is None else int(relu_mask)
         dims_c = (ctypes.c_int * (self.L + 1))(*self.dims)
         n = lib().sad_mlp_packed_bytes_bf16(self.L, dims_c, int(self.first_has_xyz))
-        self.packed = torch.empty((n,), dtype=torch.uint8, device=self.device)
+        self.packed = _empty((n,), dtype=torch.uint8, device=self.device)
         self._geom = {}      # (mode, B, N, M, S, ld_out) -> rows per tile picked by the autotuner
         self.default_geometry = 0
         w_arr = (vp * self.L)(*[w.data_ptr() for w in ws])
@@ -831,6 +919,7 @@ class PackedMLPBf16:
             if feat_pm.dim() != 3:
                 raise ValueError("feat_pm: expected [B,N,C]")
             if feat_pm.stride(2) != 1 or feat_pm.stride(0) != N * feat_pm.stride(1):
+                _unrecordable("feat_pm: strided copy")
                 feat_pm = feat_pm.contiguous()
             C = feat_pm.shape[2]
             a.feat, a.ld_feat = feat_pm.data_ptr(), feat_pm.stride(1)
@@ -838,6 +927,7 @@ class PackedMLPBf16:
         if self.dims[0] != C + 3:
             raise ValueError(f"MLP expects {self.dims[0] - 3} feature channels, got {C}")
         if out is None:
+            _unrecordable("grouped: zero-filled output")
             out = torch.zeros((B, M, self.out_channels), dtype=torch.float32, device=xyz.device)
         if out.dtype != torch.float32 or not out.is_contiguous() or col_off + self.out_channels > out.shape[-1]:
             raise ValueError("out: expected a contiguous float32 [B,M,ld_out] buffer wide enough")
@@ -850,7 +940,7 @@ class PackedMLPBf16:
                 raise ValueError("cnt must be [B,M]")
             given = ws is not None
             if not given:
-                ws = torch.empty((lib().sad_mlp_workspace_bytes(B, M, S),), dtype=torch.uint8, device=xyz.device)
+                ws = _empty((lib().sad_mlp_workspace_bytes(B, M, S),), dtype=torch.uint8, device=xyz.device)
             elif ws.numel() < lib().sad_mlp_workspace_bytes(B, M, S):
                 raise ValueError("ws: too small for this (B, M, S)")
             a.cnt, a.workspace = cnt.data_ptr(), ws.data_ptr()
@@ -911,12 +1001,14 @@ class PackedMLPBf16:
         C = x.shape[-1]
         if C != self.dims[0]:
             raise ValueError(f"MLP expects {self.dims[0]} channels, got {C}")
+        if not x.is_contiguous():
+            _unrecordable("rows: strided input")
         x2 = x.reshape(-1, C)
         if x2.stride(1) != 1:
             x2 = x2.contiguous()
         R = x2.shape[0]
         if out is None:
-            out = torch.empty(tuple(x.shape[:-1]) + (self.out_channels,), dtype=out_dtype, device=x.device)
+            out = _empty(tuple(x.shape[:-1]) + (self.out_channels,), dtype=out_dtype, device=x.device)
         if out.dtype not in (torch.float32, torch.bfloat16) or not out.is_contiguous() \
                 or out.numel() // out.shape[-1] != R or col_off + self.out_channels > out.shape[-1]:
             raise ValueError("out: expected a contiguous f32/bf16 [rows, ld_out] buffer wide enough")

@@ -88,6 +88,7 @@ class SAModuleMSG(nn.Module):
                 outs = [(cat, offs[i], self.branches[i].out_channels) for i in pick]
                 for i in range(len(self.branches)):
                     if i not in pick:
+                        ops._unrecordable("query: zero fill of a branch's pooling slice")
                         cat[:, :, offs[i]:offs[i + 1]].zero_()
             if pick:
                 for i, w in zip(pick, ops.rowscan_multi([idxs[i] for i in pick], [cnts[i] for i in pick], N, outs)):
@@ -112,6 +113,7 @@ class SAModuleMSG(nn.Module):
         if keep is not None:
             keep["ball_idx"] = idxs
         if cat is None:      # ``cat``: a caller-provided [B,M,sum C_b] float32 buffer, ZERO or prepared by ``query(prescan=True, cat=cat)``
+            ops._unrecordable("group_and_pool: zero-filled pooling buffer")
             cat = torch.zeros((B, M, self.cat_channels), dtype=torch.float32, device=xyz.device)
         calls, off = [], 0               # all branches in one dispatch (ops.grouped_multi)
         for mlp, idx, cnt, ws in zip(self.branches, idxs, cnts, wss):

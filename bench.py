@@ -111,6 +111,70 @@ def parity_check(got, want):
                        "reference is unpinned (README-only, no implementation)"}
 
 
+def step_tail(gaps) -> dict:
+    """Tail record of a timed region from its per-step completion intervals (ms): how many steps took more than twice the
+    median, and the extremes — so that a run with a few very long steps (three boxes of round 4 read configs4_leg 8 - 17 % low
+    under a NORMAL median) shows up in the line itself."""
+    g = sorted(float(x) for x in gaps)
+    if not g:
+        return {}
+    p50 = g[len(g) // 2]
+    return {"p50": round(p50, 3), "min": round(g[0], 3), "p99": round(g[(len(g) * 99) // 100], 3), "max": round(g[-1], 3),
+            "over_2x_p50": sum(1 for x in g if x > 2 * p50), "mean": round(sum(g) / len(g), 3)}
+
+
+def bf16_quality(boxes_bf16, boxes_f32, idx_bf16, idx_f32) -> dict:
+    """How far the bf16 mode's boxes sit from the f32 detector's on the SAME scenes (numpy arrays: boxes [B,K,9] =
+    x y z l w h yaw score label; idx_* = the adaptive cluster query's index sets, one [B,K,S] array per branch).
+    The bf16 mode is narrower arithmetic than the f32 path north_star specifies: this is its quality figure."""
+    import numpy as np
+    b, f = np.asarray(boxes_bf16, np.float64), np.asarray(boxes_f32, np.float64)
+    n = b.shape[0] * b.shape[1]
+    centre = np.sqrt(((b[..., 0:3] - f[..., 0:3]) ** 2).sum(-1)).ravel()
+    size_abs = np.abs(b[..., 3:6] - f[..., 3:6]).max(-1).ravel()
+    size_rel = (np.abs(b[..., 3:6] - f[..., 3:6]) / np.maximum(np.abs(f[..., 3:6]), 1e-6)).max(-1).ravel()
+    dyaw = np.abs(np.arctan2(np.sin(b[..., 6] - f[..., 6]), np.cos(b[..., 6] - f[..., 6]))).ravel()
+    dscore = np.abs(b[..., 7] - f[..., 7]).ravel()
+
+    def q(v, p):
+        return float(np.sort(v)[min(len(v) - 1, (len(v) * p) // 100)])
+
+    differ = np.zeros(b.shape[:2], bool)
+    per_branch = []
+    for ib, i32 in zip(idx_bf16, idx_f32):
+        d = (np.asarray(ib) != np.asarray(i32)).any(-1)
+        per_branch.append(round(float(d.mean()), 5))
+        differ |= d
+    return {"candidates": int(n), "label_agreement": round(float((b[..., 8] == f[..., 8]).mean()), 5),
+            "centre_delta_m": {"max": round(float(centre.max()), 5), "p99": round(q(centre, 99), 5), "p50": round(q(centre, 50), 6)},
+            "size_delta_m": {"max": round(float(size_abs.max()), 5), "p99": round(q(size_abs, 99), 5), "p50": round(q(size_abs, 50), 6)},
+            "size_delta_rel": {"max": round(float(size_rel.max()), 5), "p99": round(q(size_rel, 99), 5)},
+            "yaw_delta_rad": {"max": round(float(dyaw.max()), 5), "p99": round(q(dyaw, 99), 5)},
+            "score_delta": {"max": round(float(dscore.max()), 5), "p99": round(q(dscore, 99), 5)},
+            "adaptive_index_sets_differ": {"share_of_candidates": round(float(differ.mean()), 5), "per_branch": per_branch},
+            "against": "the f32 detector (same weights, same scenes: the last batch of the leg's timed region), both with trace on; "
+                       "an index set differs when any of its nsample slots differs (a rounding flip of the predicted size moves the "
+                       "adaptive radius)"}
+
+
+def pipeline_parity(got, want_boxes, oracle_nms) -> dict:
+    """Boxes + NMS result of the pipeline's last step vs the oracle chain on the same staged files.  ``got`` = (boxes, order,
+    count) from the device, ``want_boxes`` = oracle boxes [n,K,9], ``oracle_nms(boxes) -> (keep, order, count)``."""
+    import numpy as np
+    boxes, order, count = got
+    n = want_boxes.shape[0]
+    g, w = boxes[:n].astype(np.float64), want_boxes.astype(np.float64)
+    rel = float((np.abs(g - w) / (1.0 + np.abs(w))).max())
+    _, o_same, c_same = oracle_nms(np.ascontiguousarray(boxes[:n]))        # the NMS kernel alone: same input, exact output
+    _, o_e2e, c_e2e = oracle_nms(want_boxes)                               # end to end (boxes differ by <= 1e-4: a flip needs an IoU within that of the threshold)
+    same = bool(np.array_equal(o_same, order[:n]) and np.array_equal(c_same, count[:n]))
+    e2e = bool(np.array_equal(o_e2e, order[:n]) and np.array_equal(c_e2e, count[:n]))
+    return {"scenes": int(n), "boxes_max_rel": float(f"{rel:.3e}"), "tol": PARITY_TOL,
+            "nms_equal_on_device_boxes": same, "nms_equal_end_to_end": e2e, "kept_per_scene_mean": round(float(count[:n].mean()), 2),
+            "ok": bool(rel <= PARITY_TOL and same),
+            "against": "oracle.subsample_pad -> oracle.detector_forward -> oracle.nms_bev on the same staged point files"}
+
+
 def executed_flops(det, points, cfg, dense=False):
     """Flops the MLP kernels execute on this batch: per grouped launch only the leading rows of each
     group up to the last sample that differs from the first (the kernel's own rule); plain launches
@@ -369,9 +433,29 @@ def measure(w: Workload, steps: int, warmup: int, rank: int, world: int, dev, ar
         elapsed_local = time.perf_counter() - t0
     finally:
         gc.enable()
-    assert out.shape == (world * B, cfg.n_cand, 9) and bool(torch.isfinite(out).all())
+    # (SAD_BENCH_WHATIF: measurement builds that skip work on purpose produce garbage boxes; never set for a reported line)
+    assert out.shape == (world * B, cfg.n_cand, 9) and (bool(torch.isfinite(out).all()) or bool(os.environ.get("SAD_BENCH_WHATIF")))
     got_boxes = out[:B].cpu().numpy()          # rank 0's own scenes come first in the gathered tensor; batch `last`
     points, points_np = batches[last], batches_np[last]
+
+    quality = None
+    if w.dtype == "bf16" and rank == 0 and not getattr(args, "no_bf16_quality", False):
+        # the bf16 mode against the f32 detector on the batch the timed region ended with (same weights; serial, traced passes)
+        det32 = SADDetector(cfg, weights, dev, overlap_fps=False, n_main_streams=w.main_streams, dtype="f32", streams=streams)
+        det.overlap_fps, ov = False, det.overlap_fps
+        try:
+            tr_b, tr_f = {}, {}
+            b_bf = det(points, trace=tr_b)
+            b_32 = det32(points, trace=tr_f)
+            torch.cuda.synchronize()
+            quality = bf16_quality(b_bf.cpu().numpy(), b_32.cpu().numpy(),
+                                   [t.cpu().numpy() for t in tr_b["cluster"]["ball_idx"]],
+                                   [t.cpu().numpy() for t in tr_f["cluster"]["ball_idx"]])
+            quality["timed_region_boxes_equal_traced_pass"] = bool(np.array_equal(b_bf.cpu().numpy(), got_boxes))
+        finally:
+            det.overlap_fps = ov
+        del det32, tr_b, tr_f, b_bf, b_32
+        torch.cuda.empty_cache()
 
     log = None if args.no_launch_timing else []
     timed_steps = 0
@@ -436,9 +520,10 @@ def measure(w: Workload, steps: int, warmup: int, rank: int, world: int, dev, ar
                    "mlp_geometry_hash": geom_hash},
     }
     if gaps:
-        res["step_ms"] = {"p50": round(gaps[len(gaps) // 2], 3), "min": round(gaps[0], 3), "p99": round(gaps[(len(gaps) * 99) // 100], 3),
-                          "max": round(gaps[-1], 3), "over_2x_p50": sum(1 for g in gaps if g > 2 * gaps[len(gaps) // 2]), "over_2x_p50_at_steps": slow_at[:8],
-                          "note": f"completion-to-completion over {nm} consecutive steps / {nm} (HIP events on the main streams)"}
+        res["step_ms"] = dict(step_tail(gaps), over_2x_p50_at_steps=slow_at[:8],
+                              note=f"completion-to-completion over {nm} consecutive steps / {nm} (HIP events on the main streams)")
+    if quality is not None:
+        res["bf16_quality"] = quality
     if rank_info is not None:
         res["ranks"] = rank_info
     elif world == 1 and detail:
@@ -697,6 +782,102 @@ def measure(w: Workload, steps: int, warmup: int, rank: int, world: int, dev, ar
     return res, rc, ctx
 
 
+def ragged_scenes(first_scene: int, B: int, n_points: int, lo: float = 0.55, hi: float = 1.75):
+    """B KITTI-shaped scenes with DIFFERENT point counts (uniform in [lo, hi] x n_points, seeded by the scene id): what a
+    loader hands over after reading and range-cropping the files of a batch."""
+    import numpy as np
+    from sad_amd import synth
+    out = []
+    for i in range(B):
+        sid = first_scene + i
+        n = int(np.random.default_rng(777 + sid).integers(int(lo * n_points), int(hi * n_points) + 1))
+        out.append(synth.make_scene(sid, n))
+    return out
+
+
+def pipeline_leg(args, dev, geometry, headline_value: float, rank: int, world: int) -> dict:
+    """SURVEY 8(f) rows 1 + 2 on the step: ragged point files in pinned host memory -> async H2D -> ops.subsample_pad ->
+    SADDetector.submit -> ops.nms_bev -> D2H (boxes, rank order, kept count), `sad_amd.pipeline.IngestPipeline`.  Scenes/s beside
+    the resident-input headline, per-stage ms from a serial pass, and a parity check of the last step against the oracle chain."""
+    import gc
+    import numpy as np
+    import torch
+    import oracle
+    from sad_amd import config, synth
+    from sad_amd.detector import SADDetector
+    from sad_amd.pipeline import IngestPipeline
+
+    cfg, B = config.KITTI, args.batch
+    weights = synth.make_weights(cfg, 0)
+    w = Workload("kitti", "kitti", "f32", B, None, args.main_streams, None, args.batches)
+    streams, _ = shared_streams(dev, w.fps_streams, w.main_streams)
+    ing = _STREAMS[str(dev)].setdefault("ingest", None) or torch.cuda.Stream(device=dev)
+    _STREAMS[str(dev)]["ingest"] = ing
+    det = SADDetector(cfg, weights, dev, n_fps_streams=w.fps_streams, n_main_streams=w.main_streams, dtype="f32", streams=streams)
+    if isinstance(geometry, dict):
+        det.set_geometry(geometry)
+    nb = max(1, args.batches)
+    scenes = [ragged_scenes(batch_first_scene(100 + k, rank, world, B), B, cfg.n_points) for k in range(nb)]
+    pipe = IngestPipeline(det, B, cols=4, max_points_per_scene=int(1.75 * cfg.n_points) + 1, in_slots=nb, out_slots=w.queue_depth,
+                          ingest_stream=ing)
+    staged_bytes = [pipe.stage(k, scenes[k]) for k in range(nb)]
+    steps, warm = args.pipeline_steps, 14
+    kept_total, last = 0, None
+    for i in range(warm):
+        last = pipe.submit(i % nb)
+    torch.cuda.synchronize()
+    gc.collect()
+    gc.disable()
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
+    try:
+        t0 = time.perf_counter()
+        for i in range(steps):
+            last = pipe.submit(i % nb)
+            marks[i].record(det.last_stream)
+            if i >= w.queue_depth - 1:                   # the host consumes a finished step: kept boxes of its scenes
+                _, _, cnt = pipe.result((last + 1) % w.queue_depth)
+                kept_total += int(cnt.sum())
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    finally:
+        gc.enable()
+    last_in = (steps - 1) % nb
+    got = tuple(np.array(a) for a in pipe.result(last))
+    nm = max(1, w.main_streams)
+    gaps = [marks[i].elapsed_time(marks[i + nm]) / nm for i in range(0, steps - nm)]
+    stage_ms = {}
+    for _ in range(5):
+        for k, v in pipe.timed_serial_step(last_in).items():
+            stage_ms.setdefault(k, []).append(v)
+    stage_ms = {k: round(sorted(v)[len(v) // 2], 4) for k, v in stage_ms.items()}
+    # parity: the oracle chain on the same staged files (first n scenes of the last step's batch)
+    oracle.build()
+    n_par = max(1, min(B, args.cpu_scenes)) if not args.no_cpu else min(B, 4)
+    pts, offs = pipe.staged(last_in)
+    padded = oracle.subsample_pad(pts[:offs[n_par]], offs[:n_par + 1], cfg.n_points, 0)
+    want = oracle.detector_forward(padded, cfg, weights, skip_padding=True)
+    par = pipeline_parity(got, want, lambda b: oracle.nms_bev(b, pipe.iou_thr, pipe.score_thr))
+    value = B * steps / dt
+    rec = {"value": round(value, 1), "unit": "scenes/s", "steps": steps, "warmup": warm, "ms_per_step": round(1e3 * dt / steps, 3),
+           "vs_resident_headline": round(value / headline_value, 4) if headline_value else None,
+           "step_ms": step_tail(gaps),
+           "stages_ms_serial": stage_ms,
+           "bytes_per_step": {"h2d": int(sum(staged_bytes) / nb), "d2h": int(B * cfg.n_cand * (9 * 4 + 4) + B * 4)},
+           "h2d_gbps_serial": round(sum(staged_bytes) / nb / (stage_ms["h2d"] * 1e-3) / 1e9, 1) if stage_ms.get("h2d") else None,
+           "points_per_scene": {"min": int(min(s_.shape[0] for b_ in scenes for s_ in b_)), "max": int(max(s_.shape[0] for b_ in scenes for s_ in b_))},
+           "nms": {"iou_thr": pipe.iou_thr, "score_thr": pipe.score_thr, "kept_boxes_consumed": kept_total},
+           "parity_check": par,
+           "workload": (f"{nb} batches of {B} RAGGED KITTI-shaped scenes ({int(0.55 * cfg.n_points)} - {int(1.75 * cfg.n_points)} points each, "
+                        "raw N x 4 float32 file bytes staged in pinned host memory) in rotation -> H2D copy + ops.subsample_pad on an ingest "
+                        "stream -> SADDetector.submit (f32, the headline's geometry and streams) -> ops.nms_bev -> D2H of boxes, rank order and "
+                        f"kept count into pinned slots; {w.queue_depth} steps in flight, the host reads every finished step's counts"),
+           "note": "inputs are NOT resident: this is the PCIe-inclusive rate of the same detector; `value` of the headline stays the "
+                   "resident-input figure (contract)"}
+    del pipe, det
+    torch.cuda.empty_cache()
+    return rec
+
+
 def leg_record(res: dict) -> dict:
     """The part of a measurement that a secondary leg reports inside the headline line."""
     out = {k: res[k] for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype") if k in res}
@@ -705,6 +886,9 @@ def leg_record(res: dict) -> dict:
     out["scenes_per_gpu"] = res["config"]["scenes_per_gpu"]
     if "step_ms" in res:
         out["step_ms_p50"] = res["step_ms"]["p50"]
+        out["step_ms"] = {k: res["step_ms"][k] for k in ("p50", "p99", "max", "over_2x_p50", "over_2x_p50_at_steps") if k in res["step_ms"]}
+    if "bf16_quality" in res:
+        out["bf16_quality"] = res["bf16_quality"]
     if "roofline" in res:
         r = res["roofline"]
         out["roofline"] = {k: r[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "flop_per_step",
@@ -748,7 +932,9 @@ def main():
     ap.add_argument("--cpu-scenes", type=int, default=32)
     ap.add_argument("--no-launch-timing", action="store_true", help="skip the per-launch event passes (roofline / kernels)")
     ap.add_argument("--no-dense-leg", action="store_true")
-    ap.add_argument("--no-legs", action="store_true", help="skip the secondary bf16_leg / configs4_leg of the default run")
+    ap.add_argument("--no-legs", action="store_true", help="skip the secondary bf16_leg / configs4_leg / pipeline_leg of the default run")
+    ap.add_argument("--no-bf16-quality", action="store_true", help="bf16 runs: skip the comparison with the f32 detector on the last batch")
+    ap.add_argument("--pipeline-steps", type=int, default=150, help="timed steps of the pipeline_leg (files -> H2D -> subsample_pad -> detector -> NMS -> D2H)")
     ap.add_argument("--leg-steps", type=int, nargs=2, default=(100, 60), metavar=("BF16", "CONFIGS4"),
                     help="timed steps of the two secondary legs")
     ap.add_argument("--no-autotune", action="store_true", help="use the built-in geometry heuristic")
@@ -837,12 +1023,23 @@ def main():
         import copy
         largs = copy.copy(args)
         largs.geometry_file, largs.save_geometry = None, None
-        bf_note = {"ok": None, "note": "bf16 mode (SPEC 14): verified stage by stage in tests/test_gpu_bf16.py"}
+        bf_note = {"ok": None, "note": "bf16 mode (SPEC 14): verified stage by stage in tests/test_gpu_bf16.py; its distance from the f32 "
+                                       "detector on the leg's last batch is `bf16_quality`"}
+        t_leg = time.perf_counter()
+        try:
+            res["pipeline_leg"] = pipeline_leg(args, dev, res["config"]["mlp_geometry"], res["value"], rank, world)
+            res["pipeline_leg"]["wall_s"] = round(time.perf_counter() - t_leg, 1)
+            if not res["pipeline_leg"]["parity_check"]["ok"]:
+                rc = rc or 1
+        except Exception as e:
+            import traceback
+            res["pipeline_leg"] = {"error": f"{type(e).__name__}: {e}", "trace": traceback.format_exc()[-600:]}
+            rc = rc or 1
         for key, wl, nsteps in (("bf16_leg", Workload("kitti", "kitti", "bf16", args.batch, None, 2, None, args.batches), args.leg_steps[0]),
                                 ("configs4_leg", Workload("nuscenes", "kitti", "bf16", 32, None, 2, None, 2), args.leg_steps[1])):
             t_leg = time.perf_counter()
             try:
-                lres, _, lctx = measure(wl, nsteps, wl.fps_streams + 2, rank, world, dev, largs, detail=False)
+                lres, _, lctx = measure(wl, nsteps, max(wl.fps_streams + 2, 14), rank, world, dev, largs, detail=False)   # (warm-up covers the 12 slots of the step-plan ring)
                 del lctx
                 lres["parity_check"] = bf_note
                 res[key] = leg_record(lres)

@@ -154,6 +154,15 @@ int sad_ball_query_grid_f32(const float *xyz, const float *new_xyz, int n_radii,
 int sad_subsample_pad_f32(const float *points, const int32_t *offsets, int B, int C, int n_points,
                           unsigned seed, float *out, sad_stream_t stream);
 
+/* Strided row copy in 4-byte words (no arithmetic: exact): row r of dst = words [0, row_words) of row r of src, rows
+ * src_stride_words / dst_stride_words apart (dst_stride_words >= row_words; src rows may overlap dst rows never).  What the
+ * host side uses instead of a framework copy wherever a strided view has to become a packed operand on the step — the
+ * coordinates / features of a [B,N,3+C] point array, the centroid prefix of a nested sampling stage, the candidate rows of the
+ * cluster layer — so that every device operation of a step is a launch of this library (and can be recorded and replayed:
+ * 3dsad-main_amd/plan.py).  No reference counterpart (/root/reference/README.md:1-2). */
+int sad_copy_rows_u32(const void *src, long long src_stride_words, void *dst, long long dst_stride_words,
+                      long long n_rows, long long row_words, sad_stream_t stream);
+
 /* SPEC.md §4.  -> idx[B,M,K] sorted by (d2, index); K <= 64, K <= N. */
 int sad_knn_f32(const float *xyz, const float *new_xyz, int B, int N, int M, int K, int32_t *idx,
                 sad_stream_t stream);

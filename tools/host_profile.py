@@ -16,17 +16,25 @@ w = synth.make_weights(cfg, 0)
 pts = torch.from_numpy((synth.make_batch if name == "kitti" else synth.make_nuscenes_batch)(0, B, cfg.n_points)).to(dev)
 det = SADDetector(cfg, w, dev, overlap_fps=True, n_fps_streams=nf, n_main_streams=2, dtype=dtype)
 det.autotune(pts)
-for _ in range(6):
-    det.submit(pts)
-torch.cuda.synchronize()
-ts = []
-for _ in range(30):
-    t0 = time.perf_counter()
-    det.submit(pts)
-    ts.append(time.perf_counter() - t0)
+def idle_submit(label):
+    for _ in range(det._plan_ring + 2):      # (with step plans: every ring slot recorded)
+        det.submit(pts)
     torch.cuda.synchronize()
-ts.sort()
-print(f"{name} {dtype} B={B}: submit with an idle GPU: min {ts[0]*1e3:.3f} median {ts[len(ts)//2]*1e3:.3f} ms")
+    ts = []
+    for _ in range(48):
+        t0 = time.perf_counter()
+        det.submit(pts)
+        ts.append(time.perf_counter() - t0)
+        torch.cuda.synchronize()
+    ts.sort()
+    print(f"{name} {dtype} B={B} [{label}]: submit with an idle GPU: min {ts[0]*1e3:.3f} median {ts[len(ts)//2]*1e3:.3f} ms"
+          f"  (plan replays so far {det.plan_replays}, refused: {det.plan_refused})", flush=True)
+det.use_plans = False
+idle_submit("eager")
+det.use_plans = True
+idle_submit("step plans")
+if len(sys.argv) > 5 and sys.argv[5] == "noprofile":
+    raise SystemExit(0)
 pr = cProfile.Profile()
 for _ in range(30):
     pr.enable()
