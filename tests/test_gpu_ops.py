@@ -356,6 +356,23 @@ def test_nms_bev_parity(orc, sad, dev, B, K, thr, sthr):
         assert (ocount < K).any()                           # suppression actually happened
 
 
+@pytest.mark.parametrize("K,extent,thr", [(512, 10.0, 0.05), (256, 6.0, 0.2), (200, 25.0, 0.0), (130, 3.0, 0.5)])
+def test_nms_bev_crowded_scenes(orc, sad, dev, K, extent, thr):
+    """Crowded scenes: most boxes are suppressed, by boxes of their own 64-rank chunk and of earlier chunks — the chunked walk
+    (round 5) must make the oracle's greedy decisions; thr = 0 keeps a box only if it touches no kept box at all."""
+    from sad_amd import ops
+    from test_oracle import _random_boxes
+    bx = _random_boxes(7 * K, 3, K, extent=extent)
+    keep, order, count = ops.nms_bev(_t(bx, dev), thr, 0.0)
+    okeep, oorder, ocount = orc.nms_bev(bx, thr, 0.0)
+    np.testing.assert_array_equal(count.cpu().numpy(), ocount)
+    np.testing.assert_array_equal(order.cpu().numpy(), oorder)
+    np.testing.assert_array_equal(keep.cpu().numpy(), okeep)
+    assert (ocount < K // 2).all()
+    k1, o1, c1 = ops.nms_bev(_t(bx, dev), thr, 0.0, single_kernel=True)
+    assert bool((order == o1).all()) and bool((count == c1).all())
+
+
 def test_nms_on_detector_boxes(orc, sad, dev):
     """NMS of the boxes the TINY detector produces (the step after the measured path)."""
     import torch
