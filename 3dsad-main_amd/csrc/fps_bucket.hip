@@ -838,6 +838,339 @@ __global__ __launch_bounds__(NW * 64) void fps_cell2_kernel(const float *__restr
 #endif
 }
 
+// ---- cell-bucket kernel, third form ("several samples per round", round 5) ------------------------------------------
+// The first two forms take ONE sample per barrier round: 4 096 dependent rounds of ~1 000 cycles for a 16 384-point scene,
+// whatever the chain inside a round is trimmed to.  This form takes SEVERAL samples per round, exactly:
+//   Let c1 > c2 > ... be the points in descending key order (key = (min-distance, index order): a strict total order).  Plain
+//   FPS samples c1, lowers min-distances within reach of c1, and takes the new maximum.  Min-distances only fall, so if c2's own
+//   min-distance is NOT lowered by c1 (d2(c2, c1) >= mind[c2]) and is positive, c2 is that new maximum: every other point was
+//   below c2 before and cannot have risen, and c1 itself dropped to 0.  By induction c(j+1) is the sample after c1..cj whenever
+//   none of c1..cj lowers it.  So a round may take the longest prefix c1..cP of the global order in which no member is within
+//   reach of an earlier one — provided the prefix is KNOWN to be the global order.
+//   Every wave publishes the two largest keys among its points (k1, k2: exact, see wave top-2 below).  In the merged list of
+//   the 2 NW published keys, an unpublished point of wave w lies below k2(w); so the list's prefix is the global order up to
+//   and including the first k2 it contains (beyond that, the wave that supplied it may hide a larger third point).
+// A round: [apply the round's samples: lane-parallel box tests, bucket updates, the wave's new top-2, published by the lanes
+// that own the two points] barrier [every wave ranks ITS two candidates among the 32 table entries and tests them against
+// the higher-ranked ones: two ballots + one distance evaluation per candidate] barrier [every wave derives the same prefix
+// length P from the 32 results and reads the P sample coordinates out of its table registers].  On KITTI-shaped scenes a
+// round takes 5 samples on average (tools/probe/fps_rounds.py; 16 384 -> 4 096 in ~810 rounds instead of 4 095).
+// Same buckets, same box test, same tie rules as the other forms; indices are bit-exact (tests/test_gpu_ops.py).
+constexpr int MP_KMAX = 8;                    // samples per round (cap)
+#ifdef SAD_FPS_STAMPS3
+// measurement build: s_memtime ticks per phase, per wave of workgroup 0, summed over the rounds of the second half of the run:
+// [0] box tests, [1] bucket updates, [2] top-2 + publish, [3] wait at the first barrier, [4] ranking, [5] wait at the second
+// barrier, [6] prefix + samples, [7] rounds, [8] buckets updated, [9] rounds with a top-2 recompute, [10] samples
+__device__ unsigned long long g_fpst3[16 * 12];
+extern "C" __attribute__((visibility("default"))) int sad_debug_read_fps_stamps3(unsigned long long *dst) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_fpst3), sizeof(unsigned long long) * 16 * 12);
+}
+#define FPS3_T(v) const unsigned long long v = __builtin_amdgcn_s_memtime()
+#define FPS3_ACC(slot, expr) do { if (sample3) acc3[slot] += (expr); } while (0)
+#else
+#define FPS3_T(v)
+#define FPS3_ACC(slot, expr)
+#endif
+
+template <int NW, int PPT>
+__global__ __launch_bounds__(NW * 64) void fps_cell3_kernel(const float *__restrict__ xyz, const int *__restrict__ perm_in,
+                                                            int N, int M, int *__restrict__ idx_out) {
+    static_assert(PPT <= 32 && NW <= 16 && NW >= 1, "bucket state lives in lanes 0..31; two table entries per wave");
+    typedef float fvec __attribute__((ext_vector_type(PPT)));
+    typedef unsigned uvec __attribute__((ext_vector_type(PPT)));
+    constexpr int PSTEPS = PPT > 16 ? 5 : 4;
+    constexpr unsigned long long PMASK = PPT >= 32 ? 0xffffffffull : ((1ull << PPT) - 1ull);
+    // table: entry 2 w + s = wave w's best (s = 0) / second best (s = 1) point: key, coordinates; its rank | bad << 8 (written by
+    // its wave); the round's samples in rank order (x, y, z, ~index), written by the waves whose candidates rank below MP_KMAX
+    __shared__ __attribute__((aligned(16))) u64 s_key[32];
+    __shared__ __attribute__((aligned(16))) float s_rec[32][4];
+    __shared__ __attribute__((aligned(16))) unsigned s_res[32];
+    __shared__ __attribute__((aligned(16))) float s_cen[MP_KMAX][4];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const float *p = xyz + (size_t)blockIdx.x * N * 3;
+    const int *perm = perm_in + (size_t)blockIdx.x * N;
+    int *out = idx_out + (size_t)blockIdx.x * M;
+
+    fvec px, py, pz, md;
+    uvec ni;                                  // ~original index (larger = lower index, for the tie rule)
+    float blo0 = 0.f, blo1 = 0.f, blo2 = 0.f, bhi0 = 0.f, bhi1 = 0.f, bhi2 = 0.f;
+    unsigned bmax = 0u, blane = 0u;           // lane k: bucket k's max min-distance (bits) and the lane that attains it
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+        const int pos = (k * NW + wave) * 64 + lane;
+        const bool real = pos < N;
+        float x = 0.f, y = 0.f, z = 0.f;
+        unsigned n = 0x80000000u;             // padding: distance 0 and the largest index never beat a real point
+        if (real) {
+            const int j = perm[pos];
+            x = p[j * 3 + 0];
+            y = p[j * 3 + 1];
+            z = p[j * 3 + 2];
+            n = ~(unsigned)j;
+        }
+        px[k] = x; py[k] = y; pz[k] = z; ni[k] = n;
+        md[k] = real ? __builtin_inff() : 0.f;
+        float lo[3] = {real ? x : 3.0e38f, real ? y : 3.0e38f, real ? z : 3.0e38f};
+        float hi[3] = {real ? x : -3.0e38f, real ? y : -3.0e38f, real ? z : -3.0e38f};
+#pragma unroll
+        for (int d = 0; d < 3; ++d)
+            for (int off = 32; off >= 1; off >>= 1) {
+                const float a = __shfl_xor(lo[d], off, 64), b = __shfl_xor(hi[d], off, 64);
+                lo[d] = a < lo[d] ? a : lo[d];
+                hi[d] = b > hi[d] ? b : hi[d];
+            }
+        const bool any_real = __ballot(real) != 0ull;
+        if (lane == k) {
+            blo0 = lo[0]; blo1 = lo[1]; blo2 = lo[2];
+            bhi0 = hi[0]; bhi1 = hi[1]; bhi2 = hi[2];
+            bmax = any_real ? 0x7f800000u : 0u;   // +inf: the first round updates every real bucket
+        }
+    }
+    if (tid < 32) {
+        s_key[tid] = 0ull;
+        s_res[tid] = 63u | (1u << 8);
+        s_rec[tid][0] = s_rec[tid][1] = s_rec[tid][2] = s_rec[tid][3] = 0.f;
+    }
+    if (tid < MP_KMAX) { s_cen[tid][0] = p[0]; s_cen[tid][1] = p[1]; s_cen[tid][2] = p[2]; s_cen[tid][3] = __builtin_bit_cast(float, ~0u); }
+    if (tid == 0) out[0] = 0;
+    __syncthreads();
+
+    // the wave's two best points (all wave-uniform): bucket (register slot), min-distance bits, ~index, coordinates
+    int kb = 0, kb2 = 0;
+    unsigned v1 = 0u, n1 = 0u, v2 = 0u, n2 = 0u;
+    float q1x = 0.f, q1y = 0.f, q1z = 0.f, q2x = 0.f, q2y = 0.f, q2z = 0.f;
+    bool fresh = true;                        // nothing published yet
+    // the samples of the current round (wave-uniform: scalar registers, one per vector instruction is free on gfx9); slots >= P
+    // repeat sample 0 (applying a sample twice changes nothing), so nothing below depends on P except the second group of four
+    float cx[MP_KMAX], cy[MP_KMAX], cz[MP_KMAX];
+    {
+        const float p0x = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, p[0])));
+        const float p0y = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, p[1])));
+        const float p0z = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, p[2])));
+#pragma unroll
+        for (int i = 0; i < MP_KMAX; ++i) { cx[i] = p0x; cy[i] = p0y; cz[i] = p0z; }
+    }
+    int P = 1, t = 1;
+#ifdef SAD_FPS_STAMPS3
+    unsigned long long acc3[12];
+    for (int q = 0; q < 12; ++q) acc3[q] = 0;
+#endif
+    while (t < M) {
+#ifdef SAD_FPS_STAMPS3
+        const bool sample3 = blockIdx.x == 0 && t >= M / 2;
+#endif
+        FPS3_T(t0);
+        FPS3_ACC(7, 1);
+        FPS3_ACC(10, P);
+        // ---- apply the round's samples: box tests (lane k tests bucket k), then the disturbed buckets ---------------
+        const float bmf = __builtin_bit_cast(float, bmax);
+        bool any = false;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float dq = sad::d2f(__builtin_amdgcn_fmed3f(cx[i], blo0, bhi0), __builtin_amdgcn_fmed3f(cy[i], blo1, bhi1),
+                                      __builtin_amdgcn_fmed3f(cz[i], blo2, bhi2), cx[i], cy[i], cz[i]);
+            any = any || (dq < bmf);
+        }
+        const bool more = P > 4;              // (wave-uniform)
+        if (more) {
+#pragma unroll
+            for (int i = 4; i < MP_KMAX; ++i) {
+                const float dq = sad::d2f(__builtin_amdgcn_fmed3f(cx[i], blo0, bhi0), __builtin_amdgcn_fmed3f(cy[i], blo1, bhi1),
+                                          __builtin_amdgcn_fmed3f(cz[i], blo2, bhi2), cx[i], cy[i], cz[i]);
+                any = any || (dq < bmf);
+            }
+        }
+        unsigned rest = __builtin_amdgcn_readfirstlane((unsigned)__ballot(any));
+        FPS3_T(t1);
+        FPS3_ACC(0, t1 - t0);
+        if (rest) {
+            const bool hit = fresh || ((((rest >> kb) | (rest >> kb2)) & 1u) != 0u);
+            FPS3_ACC(8, __builtin_popcount(rest));
+            do {
+                // two disturbed buckets per pass (the second repeats the first when only one is left: the update is idempotent),
+                // so that the two dependent chains — distances, minimum, 64-lane maximum, lane of the maximum — interleave
+                const int k0 = __builtin_amdgcn_readfirstlane(__builtin_ctz(rest));
+                rest &= rest - 1;
+                const int k1 = rest ? __builtin_amdgcn_readfirstlane(__builtin_ctz(rest)) : k0;
+                rest &= rest - 1;             // (0 & anything = 0)
+                float x0 = px[k0], y0 = py[k0], z0 = pz[k0], o0 = md[k0];
+                asm volatile("" : "+v"(x0), "+v"(y0), "+v"(z0), "+v"(o0));      // (register-indexed reads kept apart: see fps_cell2)
+                float x1 = px[k1], y1 = py[k1], z1 = pz[k1], o1 = md[k1];
+                asm volatile("" : "+v"(x1), "+v"(y1), "+v"(z1), "+v"(o1));
+                unsigned m0 = __builtin_bit_cast(unsigned, o0), m1 = __builtin_bit_cast(unsigned, o1);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const unsigned d0 = __builtin_bit_cast(unsigned, sad::d2f(x0, y0, z0, cx[i], cy[i], cz[i]));
+                    const unsigned d1 = __builtin_bit_cast(unsigned, sad::d2f(x1, y1, z1, cx[i], cy[i], cz[i]));
+                    m0 = d0 < m0 ? d0 : m0;       // (bit patterns of values >= +0: integer order = float order)
+                    m1 = d1 < m1 ? d1 : m1;
+                }
+                if (more) {
+#pragma unroll
+                    for (int i = 4; i < MP_KMAX; ++i) {
+                        const unsigned d0 = __builtin_bit_cast(unsigned, sad::d2f(x0, y0, z0, cx[i], cy[i], cz[i]));
+                        const unsigned d1 = __builtin_bit_cast(unsigned, sad::d2f(x1, y1, z1, cx[i], cy[i], cz[i]));
+                        m0 = d0 < m0 ? d0 : m0;
+                        m1 = d1 < m1 ? d1 : m1;
+                    }
+                }
+                md[k0] = __builtin_bit_cast(float, m0);
+                md[k1] = __builtin_bit_cast(float, m1);       // (k1 == k0: the same value again)
+                const unsigned h0 = wave_max_u32_b(m0), h1 = wave_max_u32_b(m1);
+                const unsigned long long tie0 = __ballot(m0 == h0), tie1 = __ballot(m1 == h1);
+                int l0 = __builtin_ctzll(tie0), l1 = __builtin_ctzll(tie1);
+                if (__builtin_popcountll(tie0) > 1 || __builtin_popcountll(tie1) > 1) {     // equal maxima: lowest index wins
+                    unsigned nk0 = ni[k0], nk1 = ni[k1];
+                    asm volatile("" : "+v"(nk0), "+v"(nk1));
+                    const unsigned lo0 = wave_max_u32_b(m0 == h0 ? nk0 : 0u), lo1 = wave_max_u32_b(m1 == h1 ? nk1 : 0u);
+                    l0 = __builtin_ctzll(__ballot(m0 == h0 && nk0 == lo0));
+                    l1 = __builtin_ctzll(__ballot(m1 == h1 && nk1 == lo1));
+                }
+                bmax = sad_writelane(h0, k0, bmax);
+                blane = sad_writelane((unsigned)l0, k0, blane);
+                bmax = sad_writelane(h1, k1, bmax);
+                blane = sad_writelane((unsigned)l1, k1, blane);
+            } while (rest);
+            FPS3_T(t2);
+            FPS3_ACC(1, t2 - t1);
+            if (hit) {
+                FPS3_ACC(9, 1);
+                // the wave's best point: best bucket (ties: lowest index), the lane recorded for it
+                auto bucket_of = [&](unsigned top, int excl, int &bk, int &bl, unsigned &bn) {
+                    unsigned long long wt = __ballot(bmax == top && lane != excl) & PMASK;
+                    bk = __builtin_ctzll(wt);
+                    bl = (int)__builtin_amdgcn_readlane(blane, bk);
+                    unsigned nv = ni[bk];
+                    asm volatile("" : "+v"(nv));
+                    bn = __builtin_amdgcn_readlane(nv, bl);
+                    wt &= wt - 1;
+                    while (wt) {                             // equal maxima in several buckets: lowest index wins
+                        const int k2 = __builtin_amdgcn_readfirstlane(__builtin_ctzll(wt));
+                        wt &= wt - 1;
+                        const int l2 = (int)__builtin_amdgcn_readlane(blane, k2);
+                        unsigned nv2 = ni[k2];
+                        asm volatile("" : "+v"(nv2));
+                        const unsigned c2 = __builtin_amdgcn_readlane(nv2, l2);
+                        if (c2 > bn) { bn = c2; bk = k2; bl = l2; }
+                    }
+                };
+                const unsigned nh = __builtin_amdgcn_readlane(half_max_u32<PSTEPS>(bmax), 0);
+                int wl = 0;
+                bucket_of(nh, -1, kb, wl, n1);
+                v1 = nh;
+                // second best: the runner-up inside bucket kb, or the best of the other buckets (both reductions first, ties after)
+                float omk = md[kb], xk = px[kb], yk = py[kb], zk = pz[kb];
+                unsigned nik = ni[kb];
+                asm volatile("" : "+v"(omk), "+v"(nik), "+v"(xk), "+v"(yk), "+v"(zk));
+                const unsigned mbk = lane != wl ? __builtin_bit_cast(unsigned, omk) : 0u;
+                const unsigned bm2 = lane != kb ? bmax : 0u;
+                const unsigned sA = wave_max_u32_b(mbk);
+                const unsigned vB = __builtin_amdgcn_readlane(half_max_u32<PSTEPS>(bm2), 0);
+                q1x = rdl_f(xk, wl); q1y = rdl_f(yk, wl); q1z = rdl_f(zk, wl);
+                const unsigned long long tieA = __ballot(lane != wl && mbk == sA);
+                int lA = __builtin_ctzll(tieA);
+                if (__builtin_popcountll(tieA) > 1) {
+                    const unsigned loA = wave_max_u32_b((lane != wl && mbk == sA) ? nik : 0u);
+                    lA = __builtin_ctzll(__ballot(lane != wl && mbk == sA && nik == loA));
+                }
+                const unsigned nA = __builtin_amdgcn_readlane(nik, lA);
+                int kB = kb, lB = lA;
+                unsigned nB = 0u;
+                if (PPT > 1) bucket_of(vB, kb, kB, lB, nB);
+                if (PPT > 1 && (vB > sA || (vB == sA && nB > nA))) {
+                    kb2 = kB; v2 = vB; n2 = nB;
+                    float xb = px[kB], yb = py[kB], zb = pz[kB];
+                    asm volatile("" : "+v"(xb), "+v"(yb), "+v"(zb));
+                    q2x = rdl_f(xb, lB); q2y = rdl_f(yb, lB); q2z = rdl_f(zb, lB);
+                } else {
+                    kb2 = kb; v2 = sA; n2 = nA;
+                    q2x = rdl_f(xk, lA); q2y = rdl_f(yk, lA); q2z = rdl_f(zk, lA);
+                }
+                fresh = false;
+                // publish both entries (wave-uniform values: one lane writes them)
+                if (lane == 0) {
+                    typedef unsigned u4v __attribute__((ext_vector_type(4)));
+                    *reinterpret_cast<u4v *>(&s_key[2 * wave]) = u4v{n1, v1, n2, v2};
+                    *reinterpret_cast<f4v *>(&s_rec[2 * wave][0]) = f4v{q1x, q1y, q1z, 0.f};
+                    *reinterpret_cast<f4v *>(&s_rec[2 * wave + 1][0]) = f4v{q2x, q2y, q2z, 0.f};
+                }
+                FPS3_T(t3);
+                FPS3_ACC(2, t3 - t2);
+            }
+        }
+        FPS3_T(t4);
+        __syncthreads();
+        FPS3_T(t5);
+        FPS3_ACC(3, t5 - t4);
+        // ---- every wave ranks its two candidates in the table and tests them against the higher-ranked entries ------
+        unsigned tkhi = 0u, tklo = 0u;
+        float tx = 0.f, ty = 0.f, tz = 0.f;
+        if (lane < 2 * NW) {
+            const u64 key = s_key[lane];
+            const f4v r = *reinterpret_cast<const f4v *>(&s_rec[lane][0]);
+            tkhi = (unsigned)(key >> 32); tklo = (unsigned)key;
+            tx = r.x; ty = r.y; tz = r.z;
+        }
+        {
+            // (no branches: the two candidates' chains interleave; everything but the two distance evaluations is scalar)
+            const unsigned long long g1 = __ballot(tkhi > v1 || (tkhi == v1 && tklo > n1));
+            const unsigned long long g2 = __ballot(tkhi > v2 || (tkhi == v2 && tklo > n2));
+            const float d1 = sad::d2f(q1x, q1y, q1z, tx, ty, tz);      // the candidate as the point, entry j as the sample
+            const float d2 = sad::d2f(q2x, q2y, q2z, tx, ty, tz);
+            const unsigned long long w1 = __ballot(d1 < __builtin_bit_cast(float, v1)) & g1;
+            const unsigned long long w2 = __ballot(d2 < __builtin_bit_cast(float, v2)) & g2;
+            unsigned r1 = (unsigned)__builtin_popcountll(g1), r2 = (unsigned)__builtin_popcountll(g2);
+            // bad: lowered by a higher-ranked entry; or at distance 0 (such a point is only ever sampled first); or nothing published
+            unsigned b1 = (w1 != 0ull || (v1 == 0u && r1 > 0u)) ? 1u : 0u;
+            unsigned b2 = (w2 != 0ull || (v2 == 0u && r2 > 0u)) ? 1u : 0u;
+            if (fresh || (v1 == 0u && n1 == 0u)) { r1 = 63u; b1 = 1u; }
+            if (fresh || (v2 == 0u && n2 == 0u)) { r2 = 63u; b2 = 1u; }
+            if (lane == 0) {
+                typedef unsigned u2v __attribute__((ext_vector_type(2)));
+                *reinterpret_cast<u2v *>(&s_res[2 * wave]) = u2v{r1 | (b1 << 8), r2 | (b2 << 8)};
+                if (r1 < (unsigned)MP_KMAX) *reinterpret_cast<f4v *>(&s_cen[r1][0]) = f4v{q1x, q1y, q1z, __builtin_bit_cast(float, n1)};
+                if (r2 < (unsigned)MP_KMAX) *reinterpret_cast<f4v *>(&s_cen[r2][0]) = f4v{q2x, q2y, q2z, __builtin_bit_cast(float, n2)};
+            }
+        }
+        FPS3_T(t6);
+        FPS3_ACC(4, t6 - t5);
+        __syncthreads();
+        FPS3_T(t7);
+        FPS3_ACC(5, t7 - t6);
+        // ---- the prefix: every wave derives the same P; the samples come sorted from the table ---------------------------
+        const unsigned res = lane < 2 * NW ? s_res[lane] : (63u | (1u << 8));
+        const f4v cen = *reinterpret_cast<const f4v *>(&s_cen[lane & (MP_KMAX - 1)][0]);     // lane i (< MP_KMAX): sample i of the round
+        const unsigned rank = res & 0xFFu;
+        const unsigned limit = (res >> 8) ? rank : ((lane & 1) ? rank + 1u : 255u);   // bad: stop before it; a second-best: stop behind it
+        int np = 255 - (int)wave_max_u32_b(255u - limit);
+        np = np < MP_KMAX ? np : MP_KMAX;
+        np = np < M - t ? np : M - t;
+        P = np;                                   // >= 1: the entry of rank 0 is never bad
+#pragma unroll
+        for (int i = 0; i < MP_KMAX; ++i) {
+            const int j = i < P ? i : 0;          // (wave-uniform; slots beyond P repeat sample 0)
+            cx[i] = rdl_f(cen.x, j);
+            cy[i] = rdl_f(cen.y, j);
+            cz[i] = rdl_f(cen.z, j);
+        }
+        const float cenw = cen.w;                 // (hipcc: a bit_cast applied directly to a vector element reads element 0)
+        if (wave == 0 && lane < P) out[t + lane] = (int)(~__builtin_bit_cast(unsigned, cenw));
+        t += P;
+        FPS3_T(t8);
+        FPS3_ACC(6, t8 - t7);
+    }
+#ifdef SAD_FPS_STAMPS3
+    if (blockIdx.x == 0 && lane == 0)
+        for (int q = 0; q < 12; ++q) g_fpst3[wave * 12 + q] = acc3[q];
+#endif
+}
+
+template <int NW, int PPT>
+void launch_cell3(const float *xyz, const int *perm, int B, int N, int M, int *idx, hipStream_t st) {
+    hipLaunchKernelGGL((fps_cell3_kernel<NW, PPT>), dim3(B), dim3(NW * 64), 0, st, xyz, perm, N, M, idx);
+}
+
 template <int NW, int PPT>
 void launch_cell2(const float *xyz, const int *perm, int B, int N, int M, int *idx, hipStream_t st) {
     hipLaunchKernelGGL((fps_cell2_kernel<NW, PPT>), dim3(B), dim3(NW * 64), 0, st, xyz, perm, N, M, idx);
@@ -1258,6 +1591,17 @@ int launch_fps_bucket(const float *xyz, int B, int N, int M, int32_t *idx, void 
         if (nw * ppt < nb || !(nw == 1 || nw == 2 || nw == 4 || nw == 8 || nw == 16) ||
             !(ppt == 4 || ppt == 8 || ppt == 16 || ppt == 32))
             return fail(SAD_EINVAL, "sad_fps_f32: cell geometry %d cannot hold %d buckets", geo, nb);
+        if (get_option(OPT_FPS_VARIANT) == 7) {                 // third form: several samples per round
+#define SAD_CELL3(NW_, PPT_) case NW_ * 100 + PPT_: launch_cell3<NW_, PPT_>(xyz, perm, B, N, M, idx, st); break;
+            switch (geo) {
+                SAD_CELL3(16, 4) SAD_CELL3(16, 8) SAD_CELL3(16, 16)
+                SAD_CELL3(8, 4) SAD_CELL3(8, 8) SAD_CELL3(8, 16) SAD_CELL3(8, 32)
+                SAD_CELL3(4, 4) SAD_CELL3(4, 8) SAD_CELL3(4, 16) SAD_CELL3(4, 32)
+                default: return fail(SAD_EINVAL, "sad_fps_f32: cell geometry %d not built for the third form", geo);
+            }
+#undef SAD_CELL3
+            return check_launch("sad_fps_f32 (cell, several samples per round)");
+        }
         if (get_option(OPT_FPS_VARIANT) != 6 && nw >= 2) {      // second form of the cell kernel (lane-direct publish); 6 = the first form
 #define SAD_CELL2(NW_, PPT_) case NW_ * 100 + PPT_: launch_cell2<NW_, PPT_>(xyz, perm, B, N, M, idx, st); break;
             switch (geo) {

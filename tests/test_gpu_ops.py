@@ -31,12 +31,12 @@ def _rand_xyz(seed, B, N, scale=1.0):
 @pytest.mark.parametrize("B,N,M", [(2, 64, 16), (3, 257, 100), (2, 1024, 256), (2, 2048, 512),
                                    (2, 3000, 700), (2, 4096, 1024), (1, 8192, 512), (2, 16384, 1024),
                                    (1, 5, 5), (1, 1, 1)])
-@pytest.mark.parametrize("variant", ["shfl", "dpp", "key", "bucket", "cell", "records", "cell_v1"])
+@pytest.mark.parametrize("variant", ["shfl", "dpp", "key", "bucket", "cell", "records", "cell_v1", "multi"])
 def test_fps_parity(orc, sad, dev, B, N, M, variant):
     """Every FPS kernel variant (selected with sad_set_option) gives the oracle's indices."""
     from sad_amd import _lib, ops
     _lib.set_option("fps_dpp", 1 if variant == "dpp" else 0)
-    _lib.set_option("fps_variant", {"shfl": 1, "dpp": 1, "key": 2, "bucket": 3, "cell": 4, "records": 5, "cell_v1": 6}[variant])
+    _lib.set_option("fps_variant", {"shfl": 1, "dpp": 1, "key": 2, "bucket": 3, "cell": 4, "records": 5, "cell_v1": 6, "multi": 7}[variant])
     try:
         xyz = _rand_xyz(100 + N, B, N)
         got = ops.fps(_t(xyz, dev), M).cpu().numpy()
@@ -68,7 +68,7 @@ def test_fps_big_n_ties_and_duplicates(orc, sad, dev):
     np.testing.assert_array_equal(ops.fps(_t(flat, dev), 700).cpu().numpy(), orc.fps(flat, 700))
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 6])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 6, 7])
 def test_fps_edge_cases(orc, sad, dev, variant):
     from sad_amd import _lib, ops
     _lib.set_option("fps_variant", variant)
