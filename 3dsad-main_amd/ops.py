@@ -506,7 +506,13 @@ class PackedMLP:
             self._geom[key] = geom
         a.geometry = geom or self.default_geometry or a.geometry      # (a.geometry: the preferred kernel of an un-tuned grouped call)
         with _timed("mlp", self.name):
-            check(lib().sad_mlp_chain_f32(ctypes.byref(a), _stream()), "sad_mlp_chain_f32")
+            rc = lib().sad_mlp_chain_f32(ctypes.byref(a), _stream())
+            if rc == -2 and not geom and not self.default_geometry and a.geometry > 5:
+                # the library's un-tuned pick for the tiled kernel does not fit LDS for this (S, widths): its built-in heuristic
+                self.preferred_geometry = 0
+                a.geometry = 0
+                rc = lib().sad_mlp_chain_f32(ctypes.byref(a), _stream())
+            check(rc, "sad_mlp_chain_f32")
         if RERUN_LOG is not None:
             RERUN_LOG.append((self.name, lambda a=a, keep=keep: check(
                 lib().sad_mlp_chain_f32(ctypes.byref(a), _stream()), "sad_mlp_chain_f32")))
@@ -759,7 +765,14 @@ def grouped_multi(calls) -> None:
                     lib().sad_mlp_chain_multi_bf16(arr, len(args), _stream()), "sad_mlp_chain_multi_bf16")))
         else:
             arr = (ctypes.POINTER(MlpArgs) * len(args))(*[ctypes.pointer(a) for a in args])
-            check(lib().sad_mlp_chain_multi_f32(arr, len(args), _stream()), "sad_mlp_chain_multi_f32")
+            rc = lib().sad_mlp_chain_multi_f32(arr, len(args), _stream())
+            if rc == -2 and any(a.geometry > 5 and not c[0]._geom and not c[0].default_geometry for a, c in zip(args, calls)):
+                for a, c in zip(args, calls):      # an un-tuned tiled pick that does not fit LDS here: the built-in heuristic
+                    if a.geometry > 5 and not c[0]._geom and not c[0].default_geometry:
+                        c[0].preferred_geometry = 0
+                        a.geometry = 0
+                rc = lib().sad_mlp_chain_multi_f32(arr, len(args), _stream())
+            check(rc, "sad_mlp_chain_multi_f32")
             if RERUN_LOG is not None:
                 outs = [c[5] for c in calls]
                 RERUN_LOG.append(("+".join(c[0].name for c in calls), lambda arr=arr, args=args, keep=(keep, outs): check(

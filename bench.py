@@ -203,29 +203,66 @@ def executed_flops(det, points, cfg, dense=False):
 
     dense_rows, exec_rows = 0, 0
     per = {}
+    # algorithmic HBM bytes per chain (what a dispatch must move at least: every executed row's inputs once, every output once,
+    # the weights once): a grouped chain reads per packed row its row-map entry (8 B), the point's coordinates (12 B) and
+    # feature row, per group the centroid (12 B), and writes the pooled row; a plain chain reads and writes its rows
+    bf = getattr(det, "dtype", "f32") == "bf16"
+    per_bytes = {}
+
+    def wbytes(d):
+        return (2 if bf else 4) * sum(a * b for a, b in zip(d[:-1], d[1:]))
+
+    feat_esz = 4                                   # the scene's own feature channels are float32 in both modes
     for si, st in enumerate(cfg.stages):
         name = f"sa{si + 1}"
         for bi, idx in enumerate(tr[name]["ball_idx"]):
             r = rows_of(idx)
-            per[f"{name}.b{bi}"] = r * chain(dims[f"{name}.b{bi}"])
+            d = dims[f"{name}.b{bi}"]
+            per[f"{name}.b{bi}"] = r * chain(d)
+            per_bytes[f"{name}.b{bi}"] = r * (8 + 12 + (d[0] - 3) * feat_esz) + B * st.npoint * (12 + d[-1] * 4) + wbytes(d)
             exec_rows += r
             dense_rows += idx.numel()
         if st.agg:
-            per[f"{name}.agg"] = B * st.npoint * chain(dims[f"{name}.agg"])
+            d = dims[f"{name}.agg"]
+            per[f"{name}.agg"] = B * st.npoint * chain(d)
+            per_bytes[f"{name}.agg"] = B * st.npoint * (d[0] * 4 + d[-1] * (2 if bf else 4)) + wbytes(d)
+            feat_esz = 2 if bf else 4              # a bf16 aggregation layer hands bf16 rows to the next stage (SPEC 14)
     for bi, idx in enumerate(tr["cluster"]["ball_idx"]):
         r = rows_of(idx)
-        per[f"cluster.b{bi}"] = r * chain(dims[f"cluster.b{bi}"])
+        d = dims[f"cluster.b{bi}"]
+        per[f"cluster.b{bi}"] = r * chain(d)
+        per_bytes[f"cluster.b{bi}"] = r * (8 + 12 + (d[0] - 3) * feat_esz) + B * cfg.n_cand * (12 + d[-1] * 4) + wbytes(d)
         exec_rows += r
         dense_rows += idx.numel()
     K = cfg.n_cand
     for n in ("cand", "cluster.agg", "head"):
-        per[n] = B * K * chain(dims[n])
+        d = dims[n]
+        per[n] = B * K * chain(d)
+        per_bytes[n] = B * K * (d[0] * (feat_esz if n == "cand" else 4) + d[-1] * 4) + wbytes(d)
+    executed_flops.last_bytes = per_bytes          # (kept beside the return value: the callers unpack three values)
     return sum(per.values()), exec_rows / max(1, dense_rows), per
 
 
 def flops_of(name, per_flops):
     """A merged dispatch is named "a+b+c" (fused chain: "cluster.agg+head")."""
     return sum(per_flops.get(x, 0) for x in name.split("+"))
+
+
+def bytes_of(name, per_bytes):
+    """Algorithmic bytes of a dispatch = the sum over its chains (a fused chain's intermediate rows are counted: an upper
+    bound on its compulsory traffic, so its `frac_of_bound` is not flattered)."""
+    return sum(per_bytes.get(x, 0) for x in name.split("+"))
+
+
+def dispatch_bound(flops, nbytes, ms, peak_tflops):
+    """Which roofline bounds a dispatch and how close it runs to it: the time its flops need at the dense MFMA peak of the
+    dtype against the time its algorithmic bytes need at the HBM peak — the larger of the two is the bound (four of
+    the bf16 dispatches are byte-bound launches that were graded against 2.5 PFLOP/s)."""
+    t_mfma = flops / (peak_tflops * 1e12) * 1e3
+    t_hbm = nbytes / (PEAK_HBM_GBPS * 1e9) * 1e3
+    bound_ms = max(t_mfma, t_hbm)
+    return {"bound": "mfma" if t_mfma >= t_hbm else "hbm", "mfma_ms": round(t_mfma, 5), "hbm_ms": round(t_hbm, 5),
+            "algorithmic_mb": round(nbytes / 1e6, 2), "frac_of_bound": round(bound_ms / ms, 4) if ms > 0 else None}
 
 
 def launch_command(argv, n, port):
@@ -746,11 +783,22 @@ def measure(w: Workload, steps: int, warmup: int, rank: int, world: int, dev, ar
                          "algorithmic_bytes": g_bytes})
             del gfeat, gidx
         res["kernels"] = kern
+        per_bytes = getattr(executed_flops, "last_bytes", {})
         res["mlp_launches"] = {n: {"ms": round(v, 4), "executed_gflop": round(flops_of(n, per_flops) / 1e9, 2),
                                    "tflops": round(flops_of(n, per_flops) / (v * 1e-3) / 1e12, 1) if v > 0 else None,
                                    "frac": round(flops_of(n, per_flops) / (v * 1e-3) / 1e12 / PEAK, 3) if v > 0 else None,
+                                   **dispatch_bound(flops_of(n, per_flops), bytes_of(n, per_bytes), v, PEAK),
                                    **({"ms_under_overlap": round(per_name.get(("mlp", n), 0.0) / tsteps, 4)} if detail else {})}
                                for (k, n), v in sorted(ser_name.items()) if k == "mlp"}
+        # every dispatch against ITS bound: sum of the bound times / sum of the measured times
+        bt = sum(max(d["mfma_ms"], d["hbm_ms"]) for d in res["mlp_launches"].values())
+        mt = sum(d["ms"] for d in res["mlp_launches"].values())
+        res["roofline"]["per_dispatch_bound"] = {
+            "frac": round(bt / mt, 4) if mt > 0 else None, "bound_ms": round(bt, 4),
+            "hbm_bound_dispatches": sorted(n for n, d in res["mlp_launches"].items() if d["bound"] == "hbm"),
+            "algorithmic_mb_per_step": round(sum(d["algorithmic_mb"] for d in res["mlp_launches"].values()), 1),
+            "note": "each dispatch graded against max(flops / MFMA peak, algorithmic bytes / 8 TB/s); `frac` above keeps the MFMA-only "
+                    "definition of the earlier rounds"}
         if detail:
             res["mlp_launch_order"] = [n for k, n, _, _ in ser_log if k == "mlp"]
 
@@ -906,7 +954,10 @@ def leg_record(res: dict) -> dict:
             out["ball_query_ms_per_step"] = k["ms_per_step"]
             out["ball_query_hbm_frac"] = k["frac"]
     if "mlp_launches" in res:
-        out["mlp_launches"] = {n: {"ms": v["ms"], "frac": v["frac"]} for n, v in res["mlp_launches"].items()}
+        out["mlp_launches"] = {n: {"ms": v["ms"], "frac": v["frac"], "bound": v.get("bound"), "frac_of_bound": v.get("frac_of_bound")}
+                               for n, v in res["mlp_launches"].items()}
+        if "per_dispatch_bound" in res.get("roofline", {}):
+            out["roofline"]["per_dispatch_bound"] = {k: res["roofline"]["per_dispatch_bound"][k] for k in ("frac", "hbm_bound_dispatches", "algorithmic_mb_per_step")}
     out["parity_check"] = res.get("parity_check")
     return out
 

@@ -263,8 +263,10 @@ int sad_mlp_rowscan_init(int n, const int32_t *const *cnt, const int32_t *const 
 size_t sad_mlp_scratch_bytes(int B, int M, int S, int L, const int *dims);
 /* The `geometry` a caller that does not autotune should pass for a GROUPED chain of this shape when it provides
  * cnt + workspace (+ scratch for 3): 4 (cooperative register-resident chain: the SA3 shapes), 2 (register-resident
- * chain: the other compiled shapes), 3 (layer-streamed chain: every padded width a multiple of 128) or 0 (tiled kernel,
- * built-in heuristic).  Matches what the autotuner picks on the KITTI-shaped benchmark. */
+ * chain: the other compiled shapes), 3 (layer-streamed chain: every padded width a multiple of 128), else a code of the tiled
+ * kernel (eight waves, round-robin items, workgroup-local row packing: what the autotuner picks for chains that are not
+ * compiled shapes; a caller retries with 0 = built-in heuristic when it is refused with SAD_EUNSUPPORTED: LDS).  Matches what
+ * the autotuner picks on the KITTI-shaped benchmark; never 0 for a valid chain. */
 int sad_mlp_preferred_geometry(int L, const int *dims);
 int sad_mlp_chain_f32(const sad_mlp_args *args, sad_stream_t stream);
 /* n independent chains (typically the branches of one multi-radius stage, each writing its own

@@ -89,3 +89,13 @@ def test_ragged_scenes_are_ragged_and_seeded():
     assert len({s.shape[0] for s in a}) > 1 and all(s.shape[1] == 4 and s.dtype == np.float32 for s in a)
     assert all(int(0.55 * 2048) <= s.shape[0] <= int(1.75 * 2048) for s in a)
     assert all(np.array_equal(x, y) for x, y in zip(a, b))
+
+
+def test_dispatch_bound_picks_the_larger_roofline():
+    # a byte-bound bf16 aggregation: 10 GFLOP = 4 us at 2.5 PFLOP/s, 50 MB = 6.25 us at 8 TB/s
+    d = bench.dispatch_bound(10e9, 50e6, 0.025, 2500.0)
+    assert d["bound"] == "hbm" and d["frac_of_bound"] == 0.25 and d["algorithmic_mb"] == 50.0
+    # the f32 cluster layer: 76 GFLOP = 0.483 ms at 157.3 TFLOP/s, far above its bytes
+    d = bench.dispatch_bound(76e9, 300e6, 0.86, 157.3)
+    assert d["bound"] == "mfma" and abs(d["frac_of_bound"] - 0.5618) < 1e-3
+    assert bench.bytes_of("a+b", {"a": 3, "b": 4, "c": 9}) == 7

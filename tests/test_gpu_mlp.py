@@ -1032,3 +1032,27 @@ def test_layer_queue_on_two_streams_at_once(orc, sad, dev):
     finally:
         _lib.set_option("mlp_layer_queue", 0)
 
+
+
+@pytest.mark.parametrize("S,C,mlp", [(32, 6, [32, 32, 64]), (32, 32, [64, 96, 128]), (64, 64, [64, 128]), (32, 96, [128, 196, 256]),
+                                     (32, 128, [128, 128, 256, 256]), (32, 256, [256, 384, 512]), (64, 13, [40, 72])])
+def test_uncompiled_chains_untuned_path(orc, sad, dev, S, C, mlp):
+    """Drop-in generality: chains that are not compiled shapes, called with counts and NOT tuned, run on
+    the kernel the library prefers for them — never 0 for a valid chain (round 5: a code of the tiled kernel, or the
+    layer-streamed chain when every width is a multiple of 128) — and give the oracle's pooled features bit for bit."""
+    from sad_amd import ops, synth
+    rng = np.random.default_rng(S + 3 * C + sum(mlp))
+    B, N, M = 2, 1500, 300
+    xyz = rng.uniform(0, 1, (B, N, 3)).astype(np.float32)
+    feat = rng.normal(size=(B, N, C)).astype(np.float32)
+    new_xyz = orc.gather_xyz(xyz, orc.fps(xyz, M))
+    layers = synth.make_mlp_weights([C + 3] + mlp, rng)
+    net = ops.PackedMLP(layers, True, dev)
+    assert net.preferred_geometry != 0
+    X, F, NX = _t(xyz, dev), _t(feat, dev), _t(new_xyz, dev)
+    (idx,), (cnt,) = ops.ball_query_multi([0.17], [S], X, NX, return_counts=True)
+    want = orc.sa_group_mlp_max(xyz, feat, new_xyz, idx.cpu().numpy(), layers, skip_padding=True)
+    import torch
+    out = torch.zeros((B, M, mlp[-1]), device=dev)
+    got = net.grouped(X, F, NX, idx, out=out, cnt=cnt).cpu().numpy()
+    assert np.array_equal(got, want), f"C={C} {mlp}: un-tuned geometry {net.preferred_geometry} differs from the oracle"
