@@ -50,9 +50,9 @@ PEAK_HBM_GBPS = 8000.0         # HBM3E spec
 PARITY_TOL = 1e-4              # BASELINE.json north_star: fp32 boxes within 1e-4
 # profiles/: HBM bytes of the MLP dispatches of one step (rocprofv3 --pmc passes, tools/pmc_traffic.py), per workload;
 # the first file that exists is used
-TRAFFIC_FILES = {("kitti", "f32"): ("r04_pmc_traffic.json", "r03_pmc_traffic.json"),
-                 ("kitti", "bf16"): ("r04_bf16_pmc_traffic.json",),
-                 ("nuscenes", "bf16"): ("r04_nuscenes_bf16_pmc_traffic.json",)}
+TRAFFIC_FILES = {("kitti", "f32"): ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json"),
+                 ("kitti", "bf16"): ("r05_bf16_pmc_traffic.json", "r04_bf16_pmc_traffic.json"),
+                 ("nuscenes", "bf16"): ("r05_nuscenes_bf16_pmc_traffic.json", "r04_nuscenes_bf16_pmc_traffic.json")}
 
 
 def usable_cores() -> int:
