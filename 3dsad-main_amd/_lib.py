@@ -15,7 +15,7 @@ SO_PATH = os.environ.get("SAD_AMD_LIB") or os.path.join(CSRC, "libsad_amd.so")
 
 MAX_LAYERS = 4
 MAX_RADII = 4
-ABI_VERSION = 2            # SAD_ABI_VERSION of include/sad_amd.h this binding was written against
+ABI_VERSION = 3            # SAD_ABI_VERSION of include/sad_amd.h this binding was written against
 # instrumentation ints of a row-packing table (include/sad_amd.h, SAD_WS_*)
 WS_REFILLS, WS_INUSE, WS_CONFLICT = 5, 6, 7
 
@@ -38,6 +38,7 @@ class MlpArgs(ctypes.Structure):
         ("geometry", ctypes.c_int),
         ("scratch", vp), ("scratch_bytes", ctypes.c_size_t),
         ("prescanned", ctypes.c_int),
+        ("c_out", ctypes.c_int),           # ABI 3: != 0 = a chain packed zero-padded onto wider dims (in the ABI-2 struct's tail padding)
     ]
 
 
@@ -96,6 +97,7 @@ SIGNATURES = {
                                             ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(vp), ctypes.POINTER(vp),
                                             ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), vp]),
     "sad_mlp_preferred_geometry": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(ctypes.c_int)]),
+    "sad_mlp_padded_dims": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
     "sad_mlp_scratch_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                                ctypes.POINTER(ctypes.c_int)]),
     "sad_mlp_chain_f32": (ctypes.c_int, [ctypes.POINTER(MlpArgs), vp]),
@@ -136,7 +138,7 @@ def set_recorder(rec) -> None:
 def is_launch(name: str) -> bool:
     """Does this entry point enqueue device work (last argument: the stream)?  Size queries, options and the version do not."""
     return (name.startswith("sad_") and not name.endswith(("_bytes", "_floats", "_bytes_bf16"))
-            and "preferred_geometry" not in name and name not in ("sad_version", "sad_last_error", "sad_set_option"))
+            and "preferred_geometry" not in name and name not in ("sad_version", "sad_last_error", "sad_set_option", "sad_mlp_padded_dims"))
 
 
 def build(force: bool = False) -> str:

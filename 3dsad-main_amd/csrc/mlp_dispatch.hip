@@ -60,7 +60,11 @@ static int prepare_chain(const sad_mlp_args *a, sad_stream_t stream, Prepared &q
     if (grouped) {
         SAD_REQUIRE(a->xyz && a->new_xyz, "sad_mlp_chain_f32: grouped mode needs xyz and new_xyz");
         SAD_REQUIRE(a->N >= 1 && a->S >= 1 && a->S <= 64, "sad_mlp_chain_f32: need N>=1, 1<=S<=64 (S=%d)", a->S);
-        SAD_REQUIRE(a->dims[0] == a->C + 3, "sad_mlp_chain_f32: dims[0]=%d != C+3=%d", a->dims[0], a->C + 3);
+        if (a->c_out)       // a chain packed zero-padded onto wider dims (sad_mlp_padded_dims): fewer feature channels than dims[0] - 3
+            SAD_REQUIRE(a->C + 3 <= a->dims[0] && a->c_out >= 1 && a->c_out <= a->dims[a->L],
+                        "sad_mlp_chain_f32: zero-padded chain needs C+3=%d <= dims[0]=%d and 1 <= c_out=%d <= dims[L]=%d", a->C + 3, a->dims[0], a->c_out, a->dims[a->L]);
+        else
+            SAD_REQUIRE(a->dims[0] == a->C + 3, "sad_mlp_chain_f32: dims[0]=%d != C+3=%d", a->dims[0], a->C + 3);
         SAD_REQUIRE((long long)a->B * a->N < (1LL << 31), "sad_mlp_chain_f32: B*N too large");
         SAD_REQUIRE((long long)a->B * a->M * a->S < (1LL << 31), "sad_mlp_chain_f32: B*M*S too large (row numbers are 32-bit)");
         // straddling groups are merged with an unsigned atomic max into a zero-initialised buffer:
@@ -69,10 +73,11 @@ static int prepare_chain(const sad_mlp_args *a, sad_stream_t stream, Prepared &q
                     "sad_mlp_chain_f32: grouped chains need a ReLU after every layer (relu_mask=0x%x, L=%d)", a->relu_mask, a->L);
     } else {
         SAD_REQUIRE(a->S == 1, "sad_mlp_chain_f32: plain mode needs S == 1");
+        SAD_REQUIRE(a->c_out == 0, "sad_mlp_chain_f32: c_out (zero-padded chain) is a grouped-mode field");
         SAD_REQUIRE(a->C >= 1 && a->dims[0] == a->C, "sad_mlp_chain_f32: dims[0]=%d != C=%d", a->dims[0], a->C);
         SAD_REQUIRE((long long)a->B * a->M < (1LL << 31), "sad_mlp_chain_f32: too many rows");
     }
-    const int cout = a->dims[a->L];
+    const int cout = a->c_out ? a->c_out : a->dims[a->L];
     SAD_REQUIRE(a->ld_out >= a->col_off + cout && a->col_off >= 0, "sad_mlp_chain_f32: ld_out=%d too small for col_off=%d + C_out=%d", a->ld_out, a->col_off, cout);
 
     MlpParams p{};
@@ -111,6 +116,8 @@ static int prepare_chain(const sad_mlp_args *a, sad_stream_t stream, Prepared &q
     } else {
         p.cpr = 0; p.cshift = 0;
     }
+    if (a->c_out && geom_wg != 2 && geom_wg != 4)
+        return sad::fail(SAD_EUNSUPPORTED, "sad_mlp_chain_f32: a zero-padded chain (c_out != 0) runs on geometries 2 / 4 only (geometry %d asked)", geom_wg);
     // ---- geometry 2: register-resident chain (one wave per 32-row tile, no LDS round trips, no barriers) ----
     if (geom_wg == 2 || geom_wg == 4) {
         const int shape = grouped ? sad::reg_shape_id(a->L, g.kp, g.np) : -1;
@@ -128,7 +135,7 @@ static int prepare_chain(const sad_mlp_args *a, sad_stream_t stream, Prepared &q
         q.scan = sad::make_scan_job(a->cnt, (int)p.total_groups, a->S, 32, tab, sad::get_option(sad::OPT_MLP_NODEDUP), a->idx, a->N, a->M);
         q.scan.zout = a->out + a->col_off;         // (a scan launched by the dispatch itself zero-fills the groups that need it)
         q.scan.zld = a->ld_out;
-        q.scan.zcols = a->dims[a->L];
+        q.scan.zcols = cout;                       // (a zero-padded chain: its own output channels only)
         sad::RegChain &rc = q.rc;
         rc.xyz = a->xyz; rc.new_xyz = a->new_xyz; rc.feat = a->feat; rc.packed = a->packed; rc.out = a->out;
         rc.rowtab = tab;
@@ -216,7 +223,7 @@ static int prepare_chain(const sad_mlp_args *a, sad_stream_t stream, Prepared &q
         q.scan = sad::make_scan_job(a->cnt, (int)p.total_groups, a->S, 32, tab, sad::get_option(sad::OPT_MLP_NODEDUP), a->idx, a->N, a->M);
         q.scan.zout = a->out + a->col_off;         // (a scan launched by the dispatch itself zero-fills the groups that need it)
         q.scan.zld = a->ld_out;
-        q.scan.zcols = a->dims[a->L];
+        q.scan.zcols = cout;                       // (a zero-padded chain: its own output channels only)
         const long long rows_max = (p.total_groups * a->S + 31) / 32 * 32;
         int wa = 0, wb = 0;                         // widths of the two ping-pong activation buffers
         for (int l = 0; l + 1 < a->L; ++l) {

@@ -189,3 +189,35 @@ SAD_API int sad_mlp_preferred_geometry(int L, const int *dims) {
     const int n = tiles >= 8 ? 3 : (tiles >= 4 ? 2 : (tiles >= 2 ? 1 : 0));
     return 100000 + 20000 + 5000 + 800 + 10 * n + 1;
 }
+
+// A compiled shape of the register-resident kernels that dominates the chain (include/sad_amd.h)
+SAD_API int sad_mlp_padded_dims(int L, const int *dims, int *padded) {
+    if (L != 3 || !dims || !padded) return 0;
+    for (int l = 0; l <= L; ++l)
+        if (dims[l] < 1 || dims[l] > 4096) return 0;
+    if (dims[0] < 3) return 0;
+    const int C = dims[0] - 3;
+    if (!(C == 0 || C == 1 || C % 4 == 0)) return 0;
+    {
+        const Geometry g = geometry(L, dims, 1);
+        if (sad::reg_shape_id(L, g.kp, g.np) >= 0) return 0;      // already a compiled shape
+    }
+    // logical dims of the compiled shapes (mlp_reg.hip, reg_shape_id): C + 3, C1, C2, C3
+    static const int tab[8][4] = {{7, 16, 16, 32}, {7, 32, 32, 64}, {67, 64, 64, 128}, {67, 64, 96, 128},
+                                  {131, 128, 128, 256}, {131, 128, 192, 256}, {131, 128, 256, 256}, {7, 64, 64, 128}};
+    auto flops = [](const int *d) { return (double)d[0] * d[1] + (double)d[1] * d[2] + (double)d[2] * d[3]; };
+    const double own = flops(dims);
+    int best = -1;
+    double best_f = 0.0;
+    for (int i = 0; i < 8; ++i) {
+        const int *t = tab[i];
+        // the narrow shapes (7 -> ...) take C <= 4 as 0 / 1 strided channels or one 16-byte chunk; the others 16-byte chunks
+        const bool feat_ok = t[0] == 7 ? (C == 0 || C == 1 || C == 4) : (C >= 4 && C % 4 == 0);
+        if (!feat_ok || dims[0] > t[0] || dims[1] > t[1] || dims[2] > t[2] || dims[3] > t[3]) continue;
+        const double f = flops(t);
+        if (best < 0 || f < best_f) { best = i; best_f = f; }
+    }
+    if (best < 0 || best_f > 1.6 * own) return 0;
+    for (int l = 0; l <= L; ++l) padded[l] = tab[best][l];
+    return 1;
+}

@@ -469,7 +469,22 @@ class PackedMLP:
         self.L = len(ws)
         self.first_has_xyz = bool(first_has_xyz)
         self.relu_mask = (1 << self.L) - 1 if relu_mask is None else int(relu_mask)
-        dims_c = (ctypes.c_int * (self.L + 1))(*self.dims)
+        # A grouped 3-layer chain that is not a compiled shape of the register-resident kernels but is DOMINATED by one (every
+        # width <= the shape's, at most 1.6 x the flops) is packed zero-padded onto that shape and runs there: `pack_dims` are the
+        # dims the library sees, `dims` stay the chain's own (sad_mlp_args.c_out, ABI 3; DESIGN.md 6, generality table)
+        self.pack_dims = list(self.dims)
+        if self.first_has_xyz and self.L == 3 and self.relu_mask == (1 << self.L) - 1:
+            pad_c = (ctypes.c_int * (self.L + 1))()
+            if lib().sad_mlp_padded_dims(self.L, (ctypes.c_int * (self.L + 1))(*self.dims), pad_c):
+                self.pack_dims = [int(v) for v in pad_c]
+                for l in range(self.L):
+                    w2 = torch.zeros((self.pack_dims[l + 1], self.pack_dims[l]), dtype=torch.float32, device=self.device)
+                    w2[:ws[l].shape[0], :ws[l].shape[1]] = ws[l]
+                    b2 = torch.zeros((self.pack_dims[l + 1],), dtype=torch.float32, device=self.device)
+                    b2[:bs[l].shape[0]] = bs[l]
+                    ws[l], bs[l] = w2.contiguous(), b2
+        self.padded = self.pack_dims != self.dims
+        dims_c = (ctypes.c_int * (self.L + 1))(*self.pack_dims)
         n = lib().sad_mlp_packed_floats(self.L, dims_c, int(self.first_has_xyz))
         self.packed = _empty((n,), dtype=torch.float32, device=self.device)
         w_arr = (vp * self.L)(*[w.data_ptr() for w in ws])
@@ -485,7 +500,7 @@ class PackedMLP:
         # multiple of 128 channels; it needs scratch for the activations between layers
         # (plain rows: also C % 8 == 0 and an unpadded C_out, whole 128-channel blocks are stored)
         wide = all(((d + 31) // 32 * 32) % 128 == 0 for d in self.dims[1:])
-        self._layered_ok = wide and (self.first_has_xyz or (self.dims[0] % 8 == 0 and self.dims[-1] % 128 == 0))
+        self._layered_ok = (not self.padded) and wide and (self.first_has_xyz or (self.dims[0] % 8 == 0 and self.dims[-1] % 128 == 0))
 
     # Geometries tried by the autotuner: W*100 + log2(WN)*10 + RW (include/sad_amd.h, sad_mlp_args).
     _CANDIDATES = [w * 100 + n * 10 + r for w in (8, 4) for n in range(4) if (1 << n) <= w
@@ -570,8 +585,9 @@ class PackedMLP:
         a = MlpArgs()
         a.struct_size = ctypes.sizeof(MlpArgs)
         a.L = self.L
-        for i, d in enumerate(self.dims):
+        for i, d in enumerate(self.pack_dims):
             a.dims[i] = d
+        a.c_out = self.dims[-1] if self.padded else 0       # (a zero-padded chain stores only its own output channels)
         a.packed = self.packed.data_ptr()
         a.relu_mask = self.relu_mask
         return a
@@ -642,6 +658,18 @@ class PackedMLP:
             feat_ok16 = self.feat_fits_table_kernels(C, a.ld_feat, feat_pm.data_ptr())
         if self.dims[0] != C + 3:
             raise ValueError(f"MLP expects {self.dims[0] - 3} feature channels, got {C}")
+        if self.padded:
+            # a zero-padded chain runs on the register-resident kernels only: they take counts and 16-byte feature rows
+            if cnt is None:
+                _unrecordable("padded chain: counts derived from idx")
+                pos = torch.arange(1, S + 1, device=idx.device, dtype=torch.int32)
+                cnt = torch.clamp(((idx != idx[..., :1]).to(torch.int32) * pos).amax(-1), min=1).to(torch.int32).contiguous()
+            if feat_pm is not None and not feat_ok16:
+                _unrecordable("padded chain: packed copy of the features")
+                feat_pm = feat_pm.contiguous()
+                a.feat, a.ld_feat = feat_pm.data_ptr(), feat_pm.stride(1)
+                keep.append(feat_pm)
+                feat_ok16 = self.feat_fits_table_kernels(C, a.ld_feat, feat_pm.data_ptr())
         if out is None:   # the kernel max-combines into the buffer: it must start at zero
             _unrecordable("grouped: zero-filled output")
             out = torch.zeros((B, M, self.out_channels), dtype=torch.float32, device=xyz.device)
@@ -674,7 +702,7 @@ class PackedMLP:
             raise RuntimeError(f"{self.name or 'PackedMLP'}: a row-packing table (ws) was passed but geometry {a.geometry} packs for "
                                "itself; ask wants_prescan(..., feat=<the feature tensor>) before making the table")
         if self._layered_ok and cnt is not None and (a.geometry == 3 or AUTOTUNE):
-            dims_c = (ctypes.c_int * (self.L + 1))(*self.dims)
+            dims_c = (ctypes.c_int * (self.L + 1))(*self.pack_dims)
             nbytes = lib().sad_mlp_scratch_bytes(B, M, S, self.L, dims_c)
             sc = _empty((nbytes,), dtype=torch.uint8, device=xyz.device)
             a.scratch, a.scratch_bytes = sc.data_ptr(), nbytes

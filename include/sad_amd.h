@@ -40,9 +40,9 @@ extern "C" {
 typedef void *sad_stream_t; /* hipStream_t */
 
 /* ABI version: bumped whenever a public struct layout or a signature changes (2 = sad_mlp_args / sad_mlp_bf16_args
- * start with struct_size).  The structs additionally carry their own size: a caller built against another header is
+ * start with struct_size; 3 = sad_mlp_args.c_out in the former tail padding, sad_mlp_padded_dims, sad_copy_rows_u32).  The structs additionally carry their own size: a caller built against another header is
  * refused with SAD_EINVAL instead of being read past its end. */
-#define SAD_ABI_VERSION 2
+#define SAD_ABI_VERSION 3
 int sad_version(void);
 const char *sad_last_error(void);
 /* Tuning / A-B knobs (process-wide; defaults 0 = automatic).  Returns SAD_EINVAL for an unknown key.
@@ -243,6 +243,13 @@ typedef struct sad_mlp_args {
      * 3 and 4 only): the chain launches no scan of its own.  The scan needs coordinates-side data only, so a
      * caller can run it right behind the ball query on another stream, off the MLP stream's critical path. */
     int prescanned;
+    /* ABI 3 (occupies what was tail padding of the ABI-2 struct: sizeof is unchanged, a zeroed ABI-2 struct means 0).
+     * != 0: the chain was packed ZERO-PADDED onto wider dims (sad_mlp_padded_dims): `dims` are the padded ones, C + 3 <= dims[0]
+     * feature channels exist per row and only the first c_out <= dims[L] output channels are stored.  The padded weights
+     * and biases are zeros, so every fmaf chain gains only exact +0 terms behind its real ones: same results.  Grouped mode,
+     * geometries 2 and 4 (register-resident / cooperative chain) only — that is what it is for: a chain that is not a
+     * compiled shape runs on the compiled shape that dominates it. */
+    int c_out;
 } sad_mlp_args;
 size_t sad_mlp_workspace_bytes(int B, int M, int S);
 /* Row-packing tables of n (<= SAD_MAX_RADII) chains over the same (B, N, M): cnt[i] [B,M] and idx[i] [B,M,S[i]] from the
@@ -268,6 +275,12 @@ size_t sad_mlp_scratch_bytes(int B, int M, int S, int L, const int *dims);
  * compiled shapes; a caller retries with 0 = built-in heuristic when it is refused with SAD_EUNSUPPORTED: LDS).  Matches what
  * the autotuner picks on the KITTI-shaped benchmark; never 0 for a valid chain. */
 int sad_mlp_preferred_geometry(int L, const int *dims);
+/* Is there a compiled shape of the register-resident chain kernels that DOMINATES this grouped 3-layer chain (every padded
+ * width >= the chain's) at no more than 1.6 x its flops?  Returns 1 and the dims to pack for in padded[0..L] (pack the chain's
+ * weights zero-padded to them, call with sad_mlp_args.dims = padded, C = the true feature channels, c_out = the true output
+ * width), else 0.  C must be 0, 1 or a multiple of 4 (the kernels' feature-row layouts).  A chain that IS a compiled shape
+ * returns 0 (nothing to pad). */
+int sad_mlp_padded_dims(int L, const int *dims, int *padded);
 int sad_mlp_chain_f32(const sad_mlp_args *args, sad_stream_t stream);
 /* n independent chains (typically the branches of one multi-radius stage, each writing its own
  * column slice) in one dispatch when they share a wave count: the light chains fill the tail of the

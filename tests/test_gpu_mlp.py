@@ -1056,3 +1056,36 @@ def test_uncompiled_chains_untuned_path(orc, sad, dev, S, C, mlp):
     out = torch.zeros((B, M, mlp[-1]), device=dev)
     got = net.grouped(X, F, NX, idx, out=out, cnt=cnt).cpu().numpy()
     assert np.array_equal(got, want), f"C={C} {mlp}: un-tuned geometry {net.preferred_geometry} differs from the oracle"
+
+
+@pytest.mark.parametrize("S,C,mlp", [(32, 32, [64, 96, 128]), (32, 128, [100, 100, 200]), (32, 96, [128, 196, 256]), (64, 60, [64, 64, 120])])
+def test_zero_padded_chain_runs_on_the_dominating_compiled_shape(orc, sad, dev, S, C, mlp):
+    """A chain that is not a compiled shape but is dominated by one is packed zero-padded onto it (sad_mlp_padded_dims,
+    sad_mlp_args.c_out: ABI 3) and runs on the register-resident / cooperative kernels: the oracle's pooled features bit for
+    bit, with and without counts, into a slice of a wider buffer whose other columns stay untouched."""
+    import torch
+    from sad_amd import ops, synth
+    rng = np.random.default_rng(S + 5 * C + sum(mlp))
+    B, N, M = 2, 1500, 300
+    xyz = rng.uniform(0, 1, (B, N, 3)).astype(np.float32)
+    feat = rng.normal(size=(B, N, C)).astype(np.float32)
+    new_xyz = orc.gather_xyz(xyz, orc.fps(xyz, M))
+    layers = synth.make_mlp_weights([C + 3] + mlp, rng)
+    net = ops.PackedMLP(layers, True, dev)
+    assert net.padded and net.pack_dims != net.dims and net.preferred_geometry in (2, 4), (net.pack_dims, net.preferred_geometry)
+    X, F, NX = _t(xyz, dev), _t(feat, dev), _t(new_xyz, dev)
+    (idx,), (cnt,) = ops.ball_query_multi([0.2], [S], X, NX, return_counts=True)
+    want = orc.sa_group_mlp_max(xyz, feat, new_xyz, idx.cpu().numpy(), layers, skip_padding=True)
+    co = mlp[-1]
+    buf = torch.full((B, M, co + 24), -3.0, device=dev)
+    buf[:, :, 8:8 + co] = 0.0
+    got = net.grouped(X, F, NX, idx, out=buf, col_off=8, cnt=cnt).cpu().numpy()
+    assert np.array_equal(got[:, :, 8:8 + co], want), f"{mlp}: padded chain differs from the oracle"
+    assert (got[:, :, :8] == -3).all() and (got[:, :, 8 + co:] == -3).all(), "columns outside the slice were written"
+    got2 = net.grouped(X, F, NX, idx).cpu().numpy()               # no counts: derived from idx on the host side
+    assert np.array_equal(got2, want)
+    for g in (2,) + ((4,) if net.preferred_geometry == 4 else ()):   # both kernels where the shape has both
+        net.default_geometry = g
+        out = torch.zeros((B, M, co), device=dev)
+        assert np.array_equal(net.grouped(X, F, NX, idx, out=out, cnt=cnt).cpu().numpy(), want), f"geometry {g}"
+    net.default_geometry = 0

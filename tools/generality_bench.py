@@ -68,7 +68,7 @@ for name, src, cen, r, S, C, mlp in cases:
         ms = timeit(lambda: net.grouped(src, feat, cen, idx, out=out, cnt=cnt))
         code = (list(net._geom.values())[-1] if net._geom else 0) if label == "autotuned" else pref
         res[label] = (ms, code)
-    line = {"chain": name, "dims": dims, "rows": rows, "row_fraction": round(rows / (B * M * S), 3), "gflop": round(gf, 2), "preferred_geometry": pref}
+    line = {"chain": name, "dims": dims, "packed_as": net.pack_dims if getattr(net, "padded", False) else None, "rows": rows, "row_fraction": round(rows / (B * M * S), 3), "gflop": round(gf, 2), "preferred_geometry": pref}
     for label, (ms, code) in res.items():
         line[label] = {"ms": round(ms, 4), "tflops": round(gf / ms, 1), "frac": round(gf / ms / PEAK, 3), "geometry": int(code)}
     rows_out.append(line)
