@@ -132,7 +132,10 @@ class SADDetector(nn.Module):
             plan = self._plans.get(key)
             if plan is not None:
                 # replay: the slot's buffers are free once the step that last used them has completed
-                plan.done.synchronize()
+                if plan.done is not None:
+                    plan.done.synchronize()
+                else:
+                    plan.done = torch.cuda.Event()
                 self._calls += 1
                 plan.last_input = points                 # (held until the slot's next use: a replay records no stream use for the allocator)
                 out = plan.replay(points.data_ptr(), ready)
@@ -165,6 +168,8 @@ class SADDetector(nn.Module):
                 out = post(out)
                 ev = getattr(post, "event", None)
             if plan is not None:
+                if plan.done is None:
+                    plan.done = torch.cuda.Event()
                 plan.done.record(st)
                 if ev is None:
                     ev = plan.done

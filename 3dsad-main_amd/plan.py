@@ -66,11 +66,11 @@ class _RecLib:
 
 
 class Recorder:
-    def __init__(self):
+    def __init__(self, real_lib=None):
         self.ops: List[list] = []
         self.keep: List[torch.Tensor] = []        # every buffer the step allocated
         self.inputs = []                          # (base pointer, bytes) of the caller's input tensors
-        self.lib = _RecLib(_lib.lib(), self)
+        self.lib = _RecLib(_lib.lib() if real_lib is None else real_lib, self)
 
     # -- called from the host code of the step while it records --------------------------------------------
     def empty(self, *a, **k) -> torch.Tensor:
@@ -123,7 +123,7 @@ class StepPlan:
 
     def __init__(self, ops, keep, patches, out, stream):
         self.ops, self.keep, self.patches, self.out, self.stream = ops, keep, patches, out, stream
-        self.done = torch.cuda.Event()            # completion of the slot's most recent step (recorded by the detector)
+        self.done = None                          # completion of the slot's most recent step (event made and recorded by the detector)
         self.n_calls = sum(1 for o in ops if o[0] == OP_CALL)
         self.last_input = None                    # the input tensor of the slot's most recent step (kept alive until the next one)
 
