@@ -185,6 +185,20 @@ class SADDetector(nn.Module):
                 and ops.LAUNCH_LOG is None and ops.RERUN_LOG is None and not self.poison_buffers
                 and points.is_cuda and points.dtype == torch.float32 and points.dim() == 3 and points.is_contiguous())
 
+    def prime_plans(self, points: torch.Tensor) -> int:
+        """Record every slot of the step-plan ring now (one eager step each, synchronised at the end) instead of during the
+        first steps of serving: a recording step allocates the ~0.3 GB of buffers its slot keeps, fresh from the driver —
+        tens of milliseconds that do not belong into a latency-sensitive or timed region (bench.py calls the same steps its
+        setup).  Returns the number of steps run (0 when plans are off or ``points`` is not plannable)."""
+        if not self._plannable(points):
+            return 0
+        n = 0
+        for _ in range(self._plan_ring):
+            self.submit(points)
+            n += 1
+        torch.cuda.synchronize(self.device)
+        return n
+
     def clear_plans(self) -> None:
         """Drop every recorded step plan and the buffers they own (geometry changes call this)."""
         self._plans.clear()

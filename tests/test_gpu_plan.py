@@ -89,6 +89,7 @@ def test_plan_falls_back_when_a_step_cannot_be_recorded(sad, dev):
     ref, ev = det.submit(b)
     ev.synchronize()
     assert torch.equal(out, ref) and len(det._plans) == 1
+    assert det.prime_plans(b) == det._plan_ring and len(det._plans) == det._plan_ring and det.plan_replays == 1     # (one slot was recorded already)
     # a strided input view is refused by the recorder, the step runs eagerly and gives the same boxes
     det2 = SADDetector(cfg, w, dev, streams=(det._sides, det._mains))
     wide = torch.zeros((2, cfg.n_points, 6), device=dev)
