@@ -22,14 +22,14 @@ pb() { python3 -c "import json,sys; print(json.load(open(sys.argv[1]))['config']
 serial() {  # serial <name> <bench json whose parity batch is traced> <bench args...>: one stream, nothing overlapped, ONE batch
   n=$1; src=$2; shift 2
   rm -rf $out/$n
-  timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/$n -- python3 bench.py --no-cpu --no-dense-leg --no-legs --no-launch-timing --main-streams 1 --no-overlap --batches 1 --first-batch $(pb $src) --steps 20 --warmup 2 "$@" > $out/$n.log 2>&1 || { tail -3 $out/$n.log; return 1; }
+  timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/$n -- python3 bench.py --no-cpu --no-dense-leg --no-legs --no-launch-timing --no-bf16-quality --main-streams 1 --no-overlap --batches 1 --first-batch $(pb $src) --steps 20 --warmup 2 "$@" > $out/$n.log 2>&1 || { tail -3 $out/$n.log; return 1; }
   trim $out/$n $out/${n}_kernel_trace.csv
   cp $(ls $out/$n/*/*kernel_stats.csv | head -1) $out/${n}_kernel_stats.csv
 }
 pmc() {  # pmc <name> <counters...> -- <bench args...>: counters in their own pass (kernel-trace only, as gpurun requires)
   n=$1; shift; ctr=""; while [ "$1" != "--" ]; do ctr="$ctr $1"; shift; done; shift
   rm -rf $out/pmc_$n
-  timeout -k 10 300 rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d $out/pmc_$n -- python3 bench.py --no-cpu --no-dense-leg --no-legs --no-launch-timing --main-streams 1 --batches 1 --steps 3 --warmup 1 "$@" > $out/pmc_$n.log 2>&1 || { echo "pass $n failed"; tail -5 $out/pmc_$n.log; return 1; }
+  timeout -k 10 300 rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d $out/pmc_$n -- python3 bench.py --no-cpu --no-dense-leg --no-legs --no-launch-timing --no-bf16-quality --main-streams 1 --batches 1 --steps 3 --warmup 1 "$@" > $out/pmc_$n.log 2>&1 || { echo "pass $n failed"; tail -5 $out/pmc_$n.log; return 1; }
 }
 SQ="SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES"
 for part in $parts; do case $part in
@@ -61,7 +61,7 @@ nus)
   python3 bench.py --config nuscenes --dtype bf16 --batch 32 --batches 2 --no-cpu --no-legs --steps 80 --warmup 8 --save-geometry $out/nus_geometry.json > $out/nus_bench.log 2>&1 || { tail -3 $out/nus_bench.log; exit 1; }
   grep -E '^\{' $out/nus_bench.log > $out/nuscenes_bf16_bench.json
   rm -rf $out/nus_serial
-  timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/nus_serial -- python3 bench.py --config nuscenes --dtype bf16 --batch 32 --no-cpu --no-dense-leg --no-legs --no-launch-timing --main-streams 1 --no-overlap --batches 1 --first-batch $(pb $out/nuscenes_bf16_bench.json) --steps 4 --warmup 2 --geometry-file $out/nus_geometry.json > $out/nus_serial.log 2>&1 || { tail -3 $out/nus_serial.log; exit 1; }
+  timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/nus_serial -- python3 bench.py --config nuscenes --dtype bf16 --batch 32 --no-cpu --no-dense-leg --no-legs --no-launch-timing --no-bf16-quality --main-streams 1 --no-overlap --batches 1 --first-batch $(pb $out/nuscenes_bf16_bench.json) --steps 4 --warmup 2 --geometry-file $out/nus_geometry.json > $out/nus_serial.log 2>&1 || { tail -3 $out/nus_serial.log; exit 1; }
   trim $out/nus_serial $out/nus_serial_kernel_trace.csv
   cp $(ls $out/nus_serial/*/*kernel_stats.csv | head -1) $out/nus_serial_kernel_stats.csv
   python3 tools/roofline_from_profiles.py $out/nus_serial_kernel_trace.csv $out/nuscenes_bf16_bench.json 4 | tee $out/nuscenes_bf16_roofline_from_profiles.txt
