@@ -618,6 +618,23 @@ __device__ __forceinline__ void cell2_slow(Cell2<NW, PPT> &s, unsigned act, int 
 #if defined(SAD_FPS_DUP) && SAD_FPS_DUP == 2      // measurement: the 64-lane reduction a second time
             { unsigned t = mb ^ 1u; asm volatile("" : "+v"(t)); unsigned r = wave_max_u32_b(t); asm volatile("" :: "s"(r)); }
 #endif
+#ifdef SAD_FPS_KEEP      // (measurement build; NOT the default: see the comment)
+            {   // Round 5: two thirds of the bucket updates leave the bucket's maximum where it was (the sample lowers a few
+                // points near it, not the farthest one).  Min-distances only fall, so if the recorded lane still holds the
+                // recorded value, maximum and lane are unchanged (a lane that ties now tied before, and the recorded lane was
+                // the lowest index among those): three lane reads instead of the 64-lane reduction, ballot and writelanes.
+                // Exact (all FPS tests) and SLOWER here: 2.195 against 2.094 ms per 32 scenes — the wave that holds the sampled
+                // point never takes the shortcut for that point's bucket and pays the three dependent lane reads on the step's
+                // critical chain.  The record-streaming kernel below keeps its version (11.96 against 12.08 ms: its updates
+                // carry four more lane reads and five writelanes, and wait for L2 anyway).
+                const unsigned obm = __builtin_amdgcn_readlane(s.bmax, k);
+                const int obl = (int)__builtin_amdgcn_readlane(s.blane, k);
+                if (__builtin_amdgcn_readlane(mb, obl) == obm) {
+                    top = obm > top ? obm : top;
+                    continue;
+                }
+            }
+#endif
             const unsigned hi = wave_max_u32_b(mb);
             const unsigned long long tie = __ballot(mb == hi);
             int l = __builtin_ctzll(tie);
@@ -1339,6 +1356,11 @@ __global__ __launch_bounds__(1024) void fps_cellg_kernel(const float4 *__restric
 // loops, each touching one 32-wide vector only: with "if (k < 32) md0[k] ... else md1[k - 32] ..." around the read and
 // again around the write, hipcc copied a whole 32-register vector into a temporary and back on every update
 // (32 v_mov_b64: the first form of this kernel paid that too)
+#ifdef SAD_FPS_NOKEEP
+#define SAD_FPS_KEEP_ON false
+#else
+#define SAD_FPS_KEEP_ON true
+#endif
 #define CELLG2_UPD(MD, KI, KS)                                                                                        \
     {                                                                                                                 \
         const float4 r = rec[(KS) * 1024];                                                                            \
@@ -1349,6 +1371,15 @@ __global__ __launch_bounds__(1024) void fps_cellg_kernel(const float4 *__restric
         const unsigned db = __builtin_bit_cast(unsigned, d), ob = __builtin_bit_cast(unsigned, om);                   \
         const unsigned mb = db < ob ? db : ob;                                                                        \
         MD[KI] = __builtin_bit_cast(float, mb);                                                                       \
+        /* round 5: the bucket's best point (recorded by its ~index) still holds the recorded value: nothing to redo */ \
+        const unsigned obm = __builtin_amdgcn_readlane(bmax, KS);                                                     \
+        const unsigned obn = __builtin_amdgcn_readlane(bidx, KS);                                                     \
+        const unsigned long long own = __ballot(n == obn);                                                            \
+        const bool keep = SAD_FPS_KEEP_ON && own != 0ull &&                                                           \
+                          __builtin_amdgcn_readlane(mb, (int)__builtin_ctzll(own | (1ull << 63))) == obm;             \
+        if (keep) {                                                                                                   \
+            top = obm > top ? obm : top;                                                                              \
+        } else {                                                                                                      \
         const unsigned hi = wave_max_u32_b(mb);                                                                       \
         const unsigned long long tie = __ballot(mb == hi);                                                            \
         int l = __builtin_ctzll(tie);                                                                                 \
@@ -1366,6 +1397,7 @@ __global__ __launch_bounds__(1024) void fps_cellg_kernel(const float4 *__restric
         by = __builtin_bit_cast(float, sad_writelane(uy, KS, __builtin_bit_cast(unsigned, by)));         \
         bz = __builtin_bit_cast(float, sad_writelane(uz, KS, __builtin_bit_cast(unsigned, bz)));         \
         top = hi > top ? hi : top;                                                                                    \
+        }                                                                                                             \
     }
 
 #define CELLG2_SLOW(BUF)                                                                                              \
