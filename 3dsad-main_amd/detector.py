@@ -64,9 +64,11 @@ class SADDetector(nn.Module):
         # no HBM round trip of the cluster features); used when no trace is requested
         n_fused = len(weights["cluster.agg"]) + len(weights["head"])
         self.agg_head = None
-        if dtype == "f32" and n_fused <= 4:
-            self.agg_head = ops.PackedMLP(list(weights["cluster.agg"]) + list(weights["head"]), False, self.device,
-                                          relu_mask=(1 << (n_fused - 1)) - 1, name="cluster.agg+head")
+        import os
+        if n_fused <= 4 and (dtype == "f32" or os.environ.get("SAD_BF16_FUSE_HEAD")):
+            # (bf16: a measurement switch — the fused chain runs the round-1 tiled kernel)
+            self.agg_head = mlp_cls(list(weights["cluster.agg"]) + list(weights["head"]), False, self.device,
+                                    relu_mask=(1 << (n_fused - 1)) - 1, name="cluster.agg+head")
         self._anchor = (ctypes.c_float * 3)(*cfg.anchor_car)
         self._anchors = (ctypes.c_float * 9)(*[v for a in cfg.anchors for v in a])
         self.overlap_fps = overlap_fps
