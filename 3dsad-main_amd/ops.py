@@ -1005,7 +1005,7 @@ class PackedMLPBf16:
         if geom is None and AUTOTUNE:
             stream = torch.cuda.current_stream()
             best, best_ms = 0, None
-            for code in (0, 64, 128, 256) + ((2,) if a.cnt and a.workspace and not a.prescanned else ()):
+            for code in (0, 32, 64, 128, 256) + ((2,) if a.cnt and a.workspace and not a.prescanned else ()):
                 a.geometry = code
                 if lib().sad_mlp_chain_bf16(ctypes.byref(a), _stream()) != 0:
                     continue

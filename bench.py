@@ -999,7 +999,7 @@ def main():
     ap.add_argument("--no-legs", action="store_true", help="skip the secondary bf16_leg / configs4_leg / pipeline_leg of the default run")
     ap.add_argument("--no-bf16-quality", action="store_true", help="bf16 runs: skip the comparison with the f32 detector on the last batch")
     ap.add_argument("--pipeline-steps", type=int, default=150, help="timed steps of the pipeline_leg (files -> H2D -> subsample_pad -> detector -> NMS -> D2H)")
-    ap.add_argument("--leg-steps", type=int, nargs=2, default=(100, 60), metavar=("BF16", "CONFIGS4"),
+    ap.add_argument("--leg-steps", type=int, nargs=2, default=(300, 80), metavar=("BF16", "CONFIGS4"),
                     help="timed steps of the two secondary legs")
     ap.add_argument("--no-autotune", action="store_true", help="use the built-in geometry heuristic")
     ap.add_argument("--geometry-file", default=None,
