@@ -943,6 +943,9 @@ def leg_record(res: dict) -> dict:
     """The part of a measurement that a secondary leg reports inside the headline line."""
     out = {k: res[k] for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype") if k in res}
     out["workload"] = res["config"]["workload"]
+    # (which kernels ran and whether the steps were replayed: a tiled pick for one chain turns the plans off and costs 7 - 8 %)
+    out["mlp_geometry"] = res["config"].get("mlp_geometry")
+    out["step_plans"] = res["config"].get("step_plans")
     out["fps_streams"] = res["config"]["fps_streams"]
     out["scenes_per_gpu"] = res["config"]["scenes_per_gpu"]
     if "step_ms" in res:
