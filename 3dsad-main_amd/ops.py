@@ -826,6 +826,25 @@ def grouped_multi(calls) -> None:
                     lib().sad_mlp_chain_multi_f32(arr, len(args), _stream()), "sad_mlp_chain_multi_f32")))
 
 
+def choose_stage_assignment(picked, t_picked, uniform_times, table=(2, 3, 4)):
+    """The stage-level decision of the autotuner as a pure function (CPU-testable).  ``picked`` = per-chain codes with the measured
+    time ``t_picked`` of their merged dispatch; ``uniform_times`` = {table code: time of the dispatch with every chain on it, or
+    None when refused}.  Among the uniform assignments the fastest wins (an earlier code keeps a tie within 2 %).  It replaces
+    per-chain picks that are all table kernels when it is 2 % faster — and picks with a TILED kernel among them unless those are
+    more than 10 % faster: a tiled branch needs its pooling slice zero-filled by a framework kernel (the step can no longer be
+    replayed from a plan), leaves the stage's scan and its merged dispatch, none of which this timing sees."""
+    u_best, u_t = None, None
+    for code in table:
+        t = uniform_times.get(code)
+        if t is not None and (u_t is None or t < u_t * 0.98):
+            u_best, u_t = code, t
+    all_table = all(p in table for p in picked)
+    if u_t is not None:
+        if (all_table and (t_picked is None or u_t < t_picked * 0.98)) or (not all_table and (t_picked is None or u_t <= t_picked * 1.10)):
+            return [u_best] * len(picked), u_t
+    return list(picked), t_picked
+
+
 def _tune_stage(calls) -> None:
     """Stage-level autotune step: the branches of a stage go out as ONE dispatch, and register-resident
     (geometry 2) / layer-streamed (geometry 3) chains share their launches and work lists, so a branch
@@ -866,23 +885,13 @@ def _tune_stage(calls) -> None:
     picked = [c[0]._geom.get(k) or 0 for c, k in zip(calls, keys)]
     table = (2,) if bf16 else (2, 3, 4)          # the kernels whose chains share launches (f32: register-resident, layer-streamed, cooperative)
     all_table = all(p in table for p in picked)
-    best, t_best = picked, run(picked)
-    # uniform assignments of a table kernel: the fastest of them ...
-    u_best, u_t = None, None
+    t_picked = run(picked)
+    uniform = {}
     for code in table:
-        t = t_best if (all_table and all(p == code for p in picked)) else run([code] * len(calls))
-        if t is not None and (u_t is None or t < u_t * 0.98):
-            u_best, u_t = [code] * len(calls), t
-    # ... replaces per-chain picks that are all table kernels when it is faster, and picks with a TILED kernel among them unless
-    # those are more than 10 % faster: a tiled branch needs its pooling slice zero-filled (a framework kernel: the step cannot be
-    # replayed from a plan), leaves the stage's scan and its merged dispatch.  (The small cluster branch is 15 % faster alone on
-    # the tiled kernel, the mixed dispatch within 2 % of the uniform one: a coin flip that cost 6 - 10 % of every KITTI-shaped leg
-    # in a third of the runs — round 5)
-    if u_t is not None:
-        if (all_table and (t_best is None or u_t < t_best * 0.98)) or (not all_table and (t_best is None or u_t <= t_best * 1.10)):
-            best, t_best = u_best, u_t
+        uniform[code] = t_picked if (all_table and all(p == code for p in picked)) else run([code] * len(calls))
+    best, t_best = choose_stage_assignment(picked, t_picked, uniform, table)
     if os.environ.get("SAD_TUNE_DEBUG"):
-        print(f"[tune-stage] {'+'.join(c[0].name for c in calls)}: picked {picked}, uniform {u_best} {u_t}, final {best} {t_best}", file=sys.stderr, flush=True)
+        print(f"[tune-stage] {'+'.join(c[0].name for c in calls)}: picked {picked} {t_picked}, uniform {uniform}, final {best} {t_best}", file=sys.stderr, flush=True)
     for c, k, code in zip(calls, keys, best):
         c[0]._geom[k] = code
 

@@ -111,3 +111,23 @@ def test_unrecordable_only_raises_while_recording(monkeypatch):
         _lib.set_recorder(None)
     assert _lib.is_launch("sad_mlp_chain_f32") and _lib.is_launch("sad_copy_rows_u32")
     assert not _lib.is_launch("sad_mlp_workspace_bytes") and not _lib.is_launch("sad_mlp_padded_dims") and not _lib.is_launch("sad_version")
+
+
+def test_stage_level_tuner_prefers_table_kernels():
+    """The decision that flipped a coin in round 5: the small cluster branch is faster alone on the tiled kernel, the mixed dispatch
+    within 2 % of the uniform one — the uniform table assignment must win unless the mixed pick is more than 10 % faster."""
+    import sad_amd  # noqa: F401
+    from sad_amd.ops import choose_stage_assignment as choose
+    # the measured case: picked [tiled, 3] 0.775 ms against all-3 0.782 ms (and all-2 / all-4 refused for these shapes)
+    assert choose([24831, 3], 0.775, {2: None, 3: 0.782, 4: None}) == ([3, 3], 0.782)
+    assert choose([24831, 3], 0.790, {2: None, 3: 0.782, 4: None}) == ([3, 3], 0.782)
+    # a mixed pick that really is far faster is kept
+    assert choose([24831, 3], 0.600, {2: None, 3: 0.782, 4: None}) == ([24831, 3], 0.600)
+    # picks that are all table kernels: replaced only by a uniform assignment that is 2 % faster
+    assert choose([2, 4, 4], 0.630, {2: 0.650, 3: 0.700, 4: 0.625}) == ([2, 4, 4], 0.630)
+    assert choose([2, 4, 4], 0.630, {2: 0.650, 3: 0.700, 4: 0.600}) == ([4, 4, 4], 0.600)
+    # among uniform assignments an earlier code keeps a tie within 2 %
+    assert choose([0, 0], 1.0, {2: 0.700, 3: 0.695, 4: 0.690})[0] == [2, 2]
+    # nothing uniform fits: the picks stand; the mixed dispatch was refused: the uniform one is taken
+    assert choose([831, 832], 0.5, {2: None, 3: None, 4: None}) == ([831, 832], 0.5)
+    assert choose([831, 3], None, {2: None, 3: 0.9, 4: None}) == ([3, 3], 0.9)
