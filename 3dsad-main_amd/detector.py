@@ -8,6 +8,8 @@ MFMA-MLP kernels of the earlier stages fill the rest of the chip on the main str
 each stage's centroids over.
 """
 import ctypes
+import math
+import os
 from typing import Optional
 
 import numpy as np
@@ -64,7 +66,6 @@ class SADDetector(nn.Module):
         # no HBM round trip of the cluster features); used when no trace is requested
         n_fused = len(weights["cluster.agg"]) + len(weights["head"])
         self.agg_head = None
-        import os
         if n_fused <= 4 and (dtype == "f32" or os.environ.get("SAD_BF16_FUSE_HEAD")):
             # (bf16: a measurement switch — the fused chain runs the round-1 tiled kernel)
             self.agg_head = mlp_cls(list(weights["cluster.agg"]) + list(weights["head"]), False, self.device,
@@ -105,12 +106,10 @@ class SADDetector(nn.Module):
         # ring is a multiple of both stream counts, so a slot always meets the same (main, sampling) stream pair, and long
         # enough (>= 12) that a caller with up to 11 steps in flight never waits for a slot; a slot's buffers (~0.3 GB for 32
         # KITTI-shaped scenes) live as long as its plan.  ``use_plans=False`` (or any step that cannot be recorded) = the eager path.
-        import os
         self.use_plans = not os.environ.get("SAD_NO_PLANS")      # (A/B switch for measurements: the eager path)
         self.plan_refused = None           # why recording was given up, if it was
         self.plan_replays = 0
         self._plans = {}
-        import math
         period = (len(self._mains) * max(1, len(self._sides))) // math.gcd(len(self._mains), max(1, len(self._sides)))
         self._plan_ring = period * ((12 + period - 1) // period)
 
