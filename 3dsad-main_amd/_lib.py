@@ -15,7 +15,7 @@ SO_PATH = os.environ.get("SAD_AMD_LIB") or os.path.join(CSRC, "libsad_amd.so")
 
 MAX_LAYERS = 4
 MAX_RADII = 4
-ABI_VERSION = 3            # SAD_ABI_VERSION of include/sad_amd.h this binding was written against
+ABI_VERSION = 4            # SAD_ABI_VERSION of include/sad_amd.h this binding was written against
 # instrumentation ints of a row-packing table (include/sad_amd.h, SAD_WS_*)
 WS_REFILLS, WS_INUSE, WS_CONFLICT = 5, 6, 7
 
@@ -54,6 +54,10 @@ class MlpBf16Args(ctypes.Structure):
         ("packed", vp), ("relu_mask", ctypes.c_int),
         ("out", vp), ("out_bf16", ctypes.c_int), ("ld_out", ctypes.c_int), ("col_off", ctypes.c_int),
         ("cnt", vp), ("workspace", vp), ("geometry", ctypes.c_int), ("prescanned", ctypes.c_int),
+        # ABI 4, split pooling: continuation rows of a grouped chain / the pooled chains behind a plain layer's input rows
+        ("cont", vp), ("n_pool", ctypes.c_int),
+        ("pool_ws", vp * MAX_RADII), ("pool_cont", vp * MAX_RADII),
+        ("pool_S", ctypes.c_int * MAX_RADII), ("pool_cols", ctypes.c_int * MAX_RADII),
     ]
 
 
@@ -96,6 +100,10 @@ SIGNATURES = {
     "sad_mlp_rowscan_init": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_int),
                                             ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(vp), ctypes.POINTER(vp),
                                             ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), vp]),
+    "sad_mlp_rowscan_split": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_int),
+                                             ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(vp), ctypes.POINTER(vp),
+                                             ctypes.POINTER(ctypes.c_int), vp]),
+    "sad_mlp_cont_bytes": (ctypes.c_size_t, [ctypes.c_int] * 4),
     "sad_mlp_preferred_geometry": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(ctypes.c_int)]),
     "sad_mlp_padded_dims": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
     "sad_mlp_scratch_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,

@@ -24,7 +24,21 @@ struct ScanJob {
     // others are overwritten by plain stores, so the caller need not initialise the buffer at all
     float *zout;
     int zld, zcols;
+    // split pooling (bf16 mode, sad_mlp_rowscan_split): nothing is zero-filled; the scan marks in the row map the rows whose group
+    // began in an EARLIER 32-row tile (CONT_BIT), writes the first packed row of every group (gstart[ngroups + 1], what the layer
+    // that consumes the pooled rows finds a group's continuation rows with) and zeroes row 0 of the chain's continuation buffer
+    int split;
+    int *gstart;
+    void *cont0;
+    int cont_cols;
 };
+// ints of a row-packing table in front of gstart (hdr, row_start, pass_first, block sums, row map: make_scan_job)
+inline long long scan_gstart_off(long long ng, int S) {
+    const long long o = 4 + (ng + 1) + (ng * S / 32 + 2) + (ng / 1024 + 2) + 2 * ng * S;
+    return (o + 3) & ~3LL;
+}
+constexpr int CONT_BIT = 1 << 29;          // row map: this row's group began in an earlier tile (split pooling only)
+constexpr int GID_MASK = CONT_BIT - 1;
 constexpr int SCAN_MAX_CHAINS = SAD_MAX_RADII;     // the branches of one multi-radius stage
 struct ScanMulti { ScanJob j[SCAN_MAX_CHAINS]; int n; };
 ScanJob make_scan_job(const int32_t *cnt, int ngroups, int S, int R, int *tab, int nodedup, const int32_t *idx, int N, int M);
@@ -115,6 +129,10 @@ struct BfRegChain {
     float *out;
     int ld_out, col_off, cout_last;
     const int *rowtab, *row_src, *row_gid;
+    // split pooling: `out` holds bf16 rows; a group's rows in the tile where it begins pool into out[g], its rows in a later tile t
+    // into cont[t] (row stride ld_cont elements) — every pooled row leaves with plain stores, nothing is combined in memory
+    int out_bf16, ld_cont;
+    void *cont;
 };
 struct BfRegMulti {
     BfRegChain c[REG_MAX_CHAINS];
@@ -135,6 +153,13 @@ struct BfRowsJob {
     void *out;                     // rows [rows, ld_out], f32 or bf16 (out_bf16)
     int out_bf16, ld_out, col_off, vec_out;
     int nrb, ncb;                  // (filled by launch_bf16_rows) row blocks of 128, channel blocks of 128
+    // x = split-pooled rows of n_pool chains side by side (columns pool_col0[i] .. pool_col0[i + 1] - 1 from chain i): row g of chain i
+    // is max(x[g], cont_i[t]) over the tiles t after the one its packed rows begin in (pool_gstart[i][g] >> 5)
+    int n_pool;
+    const int *pool_gstart[SAD_MAX_RADII];
+    const void *pool_cont[SAD_MAX_RADII];
+    int pool_col0[SAD_MAX_RADII + 1];
+    int pool_ld[SAD_MAX_RADII];
 };
 int launch_bf16_rows(const BfRowsJob &job, hipStream_t st);
 int bfreg_shape_id(int L, const int *dims);        // dims = {C + 3, C1, C2, C3}; -1: no compiled shape

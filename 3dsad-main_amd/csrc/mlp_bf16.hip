@@ -541,7 +541,9 @@ static int prepare_bf16(const sad_mlp_bf16_args *a, sad_stream_t stream, BfPrepa
         SAD_REQUIRE(a->xyz && a->new_xyz && a->N >= 1 && a->S >= 1, "sad_mlp_chain_bf16: grouped mode needs xyz, new_xyz, N, S");
         SAD_REQUIRE(a->dims[0] == a->C + 3, "sad_mlp_chain_bf16: dims[0]=%d != C+3=%d", a->dims[0], a->C + 3);
         SAD_REQUIRE((a->relu_mask & ((1 << a->L) - 1)) == (1 << a->L) - 1, "sad_mlp_chain_bf16: every grouped layer needs a ReLU");
-        SAD_REQUIRE(!a->out_bf16, "sad_mlp_chain_bf16: grouped output is f32 (atomic max merge)");
+        SAD_REQUIRE(!a->out_bf16 || (a->geometry == 2 && a->cont), "sad_mlp_chain_bf16: grouped output is f32 (atomic max merge), or bf16 with "
+                    "continuation rows (out_bf16 = 1, cont != NULL: split pooling) on the register-resident chain (geometry 2)");
+        SAD_REQUIRE(!a->n_pool, "sad_mlp_chain_bf16: n_pool describes the INPUT rows of a plain layer");
         p.rows = (long long)a->B * a->M * a->S;
     } else {
         SAD_REQUIRE(a->dims[0] == a->C && a->C >= 1 && a->S == 1, "sad_mlp_chain_bf16: plain mode needs dims[0] == C, S == 1");
@@ -559,6 +561,22 @@ static int prepare_bf16(const sad_mlp_bf16_args *a, sad_stream_t stream, BfPrepa
     prep.reg = false;
     prep.rows = false;
     prep.prescanned = a->prescanned != 0;
+    if (!grouped && a->n_pool) {
+        // the input rows are split-pooled outputs (bf16 rows + continuation rows of n_pool chains side by side): one layer, row-streaming kernel only
+        SAD_REQUIRE(a->n_pool >= 1 && a->n_pool <= SAD_MAX_RADII, "sad_mlp_chain_bf16: n_pool must be 0..%d", SAD_MAX_RADII);
+        if (a->L != 1 || (a->geometry != 0 && a->geometry != 3) || !a->feat_bf16)
+            return sad::fail(SAD_EUNSUPPORTED, "sad_mlp_chain_bf16: split-pooled input rows (n_pool > 0) are read by the row-streaming layer only "
+                                               "(one plain layer, geometry 0 or 3, bf16 rows)");
+        int cols = 0;
+        for (int i = 0; i < a->n_pool; ++i) {
+            SAD_REQUIRE(a->pool_ws[i] && a->pool_cont[i] && (uintptr_t)a->pool_ws[i] % 16 == 0 && (uintptr_t)a->pool_cont[i] % 16 == 0,
+                        "sad_mlp_chain_bf16: pool_ws[%d] / pool_cont[%d]: NULL or not 16-byte aligned", i, i);
+            SAD_REQUIRE(a->pool_S[i] >= 1 && a->pool_S[i] <= 64 && a->pool_cols[i] >= 16 && a->pool_cols[i] % 16 == 0,
+                        "sad_mlp_chain_bf16: pool_S[%d] must be 1..64 and pool_cols[%d] a multiple of 16", i, i);
+            cols += a->pool_cols[i];
+        }
+        SAD_REQUIRE(cols == a->C, "sad_mlp_chain_bf16: the pool_cols add up to %d, the layer reads C = %d channels", cols, a->C);
+    }
     if (!grouped && a->L == 1 && (a->geometry == 0 || a->geometry == 3)) {
         // ---- one plain layer: the row-streaming kernel (every input row read once per 128 output channels) ----
         const size_t esz = a->feat_bf16 ? 2 : 4;
@@ -576,9 +594,19 @@ static int prepare_bf16(const sad_mlp_bf16_args *a, sad_stream_t stream, BfPrepa
             const size_t osz = a->out_bf16 ? 2 : 4;
             j.vec_out = ((size_t)a->ld_out * osz) % (4 * osz) == 0 && ((size_t)a->col_off * osz) % (4 * osz) == 0 &&
                         (uintptr_t)a->out % (4 * osz) == 0;
+            j.n_pool = a->n_pool;
+            for (int i = 0, c0 = 0; i < a->n_pool; ++i) {
+                j.pool_gstart[i] = (const int *)a->pool_ws[i] + sad::scan_gstart_off(p.rows, a->pool_S[i]);
+                j.pool_cont[i] = a->pool_cont[i];
+                j.pool_ld[i] = a->pool_cols[i];
+                j.pool_col0[i] = c0;
+                c0 += a->pool_cols[i];
+                for (int k = i + 1; k <= SAD_MAX_RADII; ++k) j.pool_col0[k] = c0;
+            }
             prep.rows = true;
             return SAD_OK;
         }
+        if (a->n_pool) return sad::fail(SAD_EUNSUPPORTED, "sad_mlp_chain_bf16: split-pooled input rows need C %% 8 == 0 and 16-byte aligned rows");
         if (a->geometry == 3) return sad::fail(SAD_EUNSUPPORTED, "sad_mlp_chain_bf16: geometry 3 (row-streaming layer) needs C %% 8 == 0 and 16-byte aligned rows");
     }
     if (a->geometry == 2) {
@@ -590,14 +618,24 @@ static int prepare_bf16(const sad_mlp_bf16_args *a, sad_stream_t stream, BfPrepa
                                                "cnt + workspace and, for more than 13 feature channels, 16-byte bf16 feature rows");
         SAD_REQUIRE((uintptr_t)a->workspace % 16 == 0, "sad_mlp_chain_bf16: workspace must be 16-byte aligned");
         SAD_REQUIRE(!vec || (uintptr_t)a->feat % 16 == 0, "sad_mlp_chain_bf16: feat must be 16-byte aligned");
-        SAD_REQUIRE((long long)a->B * a->M < (1LL << 30), "sad_mlp_chain_bf16: too many groups");
+        SAD_REQUIRE((long long)a->B * a->M < (long long)sad::CONT_BIT, "sad_mlp_chain_bf16: too many groups");
         SAD_REQUIRE((long long)a->B * a->N < (1LL << 31), "sad_mlp_chain_bf16: B*N too large");
         const int ngroups = a->B * a->M;
         int *tab = (int *)a->workspace;
         prep.scan = sad::make_scan_job(a->cnt, ngroups, a->S, 32, tab, 0, a->idx, a->N, a->M);
-        prep.scan.zout = (float *)a->out + a->col_off;     // (a scan launched by the dispatch itself zero-fills the groups that need it)
-        prep.scan.zld = a->ld_out;
-        prep.scan.zcols = a->dims[a->L];
+        if (a->out_bf16) {
+            // split pooling: bf16 rows + continuation rows, plain stores only (nothing to zero; the table must come from a split scan:
+            // this dispatch's own, or sad_mlp_rowscan_split)
+            SAD_REQUIRE(a->dims[3] % 8 == 0 && a->ld_out % 8 == 0 && a->col_off % 8 == 0 && (uintptr_t)a->out % 16 == 0 && (uintptr_t)a->cont % 16 == 0,
+                        "sad_mlp_chain_bf16: split pooling needs cout, ld_out and col_off multiples of 8 and 16-byte aligned out / cont");
+            prep.scan.split = 1;
+            prep.scan.cont0 = a->cont;
+            prep.scan.cont_cols = a->dims[3];
+        } else {
+            prep.scan.zout = (float *)a->out + a->col_off;     // (a scan launched by the dispatch itself zero-fills the groups that need it)
+            prep.scan.zld = a->ld_out;
+            prep.scan.zcols = a->dims[a->L];
+        }
         sad::BfRegChain &rc = prep.rc;
         rc = sad::BfRegChain{};
         rc.xyz = a->xyz; rc.new_xyz = a->new_xyz; rc.feat = a->feat; rc.feat_bf16 = a->feat_bf16; rc.ld_feat = a->ld_feat; rc.C = a->C;
@@ -612,6 +650,7 @@ static int prepare_bf16(const sad_mlp_bf16_args *a, sad_stream_t stream, BfPrepa
         rc.stream = q;
         rc.out = (float *)a->out; rc.ld_out = a->ld_out; rc.col_off = a->col_off; rc.cout_last = a->dims[3];
         rc.rowtab = tab; rc.row_src = prep.scan.row_src; rc.row_gid = prep.scan.row_gid;
+        rc.out_bf16 = a->out_bf16 ? 1 : 0; rc.cont = a->cont; rc.ld_cont = a->dims[3];
         prep.reg = true;
         prep.reg_shape = shape;
         prep.reg_tiles = ((long long)ngroups * a->S + 31) / 32;

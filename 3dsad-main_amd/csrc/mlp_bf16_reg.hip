@@ -26,11 +26,14 @@
 namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 using sad::BfRegChain;
 using sad::BfRegMulti;
 
 constexpr int WHOLE_BIT = 1 << 30;
+using sad::CONT_BIT;            // split pooling (common.h): the row's group began in an earlier tile
+using sad::GID_MASK;
 #ifndef SAD_BR_RS
 #define SAD_BR_RS 8      // (16: sa1 82 vs 72 us, sa2 47 vs 41, cluster 112 vs 108, sa3 112 vs 115 — the smaller ring / image lets more workgroups share a CU)
 #endif
@@ -105,6 +108,7 @@ struct PoolInfo {
     int ngroups;        // groups with live rows in this tile (0: a tile past the end, nothing is stored)
     int g_first;        // group of the tile's first row (groups are consecutive in the packed order)
     bool whole_first, whole_last;   // the first / last group of the tile has no rows in another tile
+    bool cont_first;    // split pooling: the tile's first group began in an earlier tile (its rows here pool into the tile's continuation row)
 };
 
 // Row-map entries of a wave's NEXT tile, fetched while the current one runs: the gather is a chain of dependent round
@@ -127,7 +131,9 @@ __device__ __forceinline__ NextRows fetch_rows(const BfRegChain &c, int tile, in
 
 // STATICW: the chain's whole fragment stream sits in LDS for the lifetime of the workgroup (the narrow first-stage chains:
 // 3 - 22 fragments) — no ring, no barriers, the waves of a workgroup are independent; `rs.ring` then points at that image.
-template <int KS0, int NO0, int NO1, int NO2, bool VEC0, int NW, bool STATICW, int PFD>
+// SPLIT: split pooling (bf16 rows + continuation rows, plain stores: common.h BfRegChain) — its own instantiation, so that the
+// f32 / atomic-max form keeps its registers (with a run-time flag family 2 spilled 33 registers instead of 13)
+template <int KS0, int NO0, int NO1, int NO2, bool VEC0, int NW, bool STATICW, int PFD, bool SPLIT>
 __device__ __forceinline__ void br_tile(const BfRegChain &c, const int tile, const float *__restrict__ sbias, const int lane, const int wave,
                                         Ring &rs, const float4 *__restrict__ sbase, const float4 *__restrict__ nbase, float *stage,
                                         const int total, NextRows &rows, const BfRegChain &nc, const int ntile, const int ntotal) {
@@ -141,7 +147,7 @@ __device__ __forceinline__ void br_tile(const BfRegChain &c, const int tile, con
     SAD_BSTAMP(ts0);
     // ---- rows: lane r carries packed row pi(r) of the tile (its row-map entries were fetched during the previous tile) ----
     const int src = rows.src;
-    const int grp = rows.gvq & (WHOLE_BIT - 1);
+    const int grp = rows.gvq & GID_MASK;
     const int gv_nat = rows.gvn;
     float rel[3];
     {
@@ -185,6 +191,7 @@ __device__ __forceinline__ void br_tile(const BfRegChain &c, const int tile, con
     int ldo = c.ld_out, cout_last = c.cout_last, col_off = c.col_off;
     asm volatile("" : "+v"(ldo), "+v"(cout_last), "+v"(col_off));
     float *const c_out = c.out;
+    __bf16 *const contp = SPLIT ? reinterpret_cast<__bf16 *>(c.cont) : nullptr;     // (wave-uniform, used once per staged block: left in scalar registers)
     const bool vec_out = (c.ld_out % 4 == 0) && (c.col_off % 4 == 0) && ((reinterpret_cast<uintptr_t>(c.out) & 15) == 0);
 
     // ---- the ring ---------------------------------------------------------------------------------------------
@@ -283,7 +290,7 @@ __device__ __forceinline__ void br_tile(const BfRegChain &c, const int tile, con
     {
         const bool live = tile * 32 + r < total;
         const int gv = gv_nat;
-        const int g = gv & (WHOLE_BIT - 1);
+        const int g = gv & GID_MASK;
         const int gprev = __shfl_up(g, 1, 64);
         const bool same_prev = r > 0 && gprev == g;                 // (rows past the end repeat the last row: same group)
         const unsigned startm = ~(unsigned)__ballot(same_prev && lane < 32);      // bit t: row t starts a group (bit 0 set)
@@ -294,6 +301,7 @@ __device__ __forceinline__ void br_tile(const BfRegChain &c, const int tile, con
         const int nlive = __builtin_popcount(livem);
         pi.whole_first = (__builtin_amdgcn_readlane(gv, 0) & WHOLE_BIT) != 0;
         pi.whole_last = (__builtin_amdgcn_readlane(gv, nlive > 0 ? nlive - 1 : 0) & WHOLE_BIT) != 0;
+        pi.cont_first = (__builtin_amdgcn_readlane(gv, 0) & CONT_BIT) != 0;
         constexpr int CBS_MAX = CB == 128 ? 7 : (CB == 64 ? 6 : 5);
         const int want = pi.ngroups <= 8 ? 7 : (pi.ngroups <= 16 ? 6 : 5);
         pi.cbs = want < CBS_MAX ? want : CBS_MAX;
@@ -361,6 +369,27 @@ __device__ __forceinline__ void br_tile(const BfRegChain &c, const int tile, con
                 const int ch0 = (o >> (cbs - 5)) << cbs;
                 const int lpg = 1 << (cbs - 2);                     // lanes per group (16 bytes per lane)
                 const int ch = ch0 + 4 * (lane & (lpg - 1));
+                if constexpr (SPLIT) {
+                    // split pooling: every group of the tile leaves as ONE plain 8-byte store per lane of bf16 (rounding is monotone:
+                    // the rounded maximum is the maximum of the rounded values) — the rows of a group that began in an earlier tile
+                    // into the tile's continuation row, all others into the group's row; the layer that reads the pooled rows takes
+                    // the maximum of the two (mlp_bf16_rows.hip).  (host: cout % 8 == 0, ld_out % 8 == 0, col_off % 8 == 0, 16-byte bases)
+                    __bf16 *const outb = reinterpret_cast<__bf16 *>(c_out);
+                    for (int s0 = 0; s0 < pi.ngroups; s0 += 64 >> (cbs - 2)) {   // (wave-uniform)
+                        const int sidx = s0 + (lane >> (cbs - 2));
+                        float4 *src = reinterpret_cast<float4 *>(stage + (s0 << cbs)) + lane;
+                        if (sidx < pi.ngroups) {
+                            const float4 v = *src;
+                            *src = make_float4(0.f, 0.f, 0.f, 0.f);
+                            __bf16 *orow = (sidx == 0 && pi.cont_first) ? contp + (long long)tile * cout_last + ch
+                                                                         : outb + (long long)(pi.g_first + sidx) * ldo + col_off + ch;
+                            bf16x4 pk;
+                            pk[0] = (__bf16)v.x; pk[1] = (__bf16)v.y; pk[2] = (__bf16)v.z; pk[3] = (__bf16)v.w;
+                            if (ch + 3 < cout_last) *reinterpret_cast<bf16x4 *>(orow) = pk;
+                        }
+                    }
+                    return;
+                }
                 for (int s0 = 0; s0 < pi.ngroups; s0 += 64 >> (cbs - 2)) {       // (wave-uniform)
                     const int sidx = s0 + (lane >> (cbs - 2));
                     float4 *src = reinterpret_cast<float4 *>(stage + (s0 << cbs)) + lane;
@@ -438,30 +467,30 @@ __device__ __forceinline__ void br_tile(const BfRegChain &c, const int tile, con
 //  2: 67 -> 64 -> 64 -> 128 (SA2)            3: 67 -> 64 -> 96 -> 128
 //  4: 131 -> 128 -> 128 -> 256 (SA3)         5: 131 -> 128 -> 192 -> 256             6: 131 -> 128 -> 256 -> 256
 //  8: 259 -> 256 -> 256 -> 512 (cluster)     9: 259 -> 256 -> 512 -> 1024
-template <int FAMILY, int NW>
+template <int FAMILY, int NW, bool SPLIT>
 __device__ __forceinline__ void run_br(const BfRegChain &c, int shape, int tile, const float *sb, int lane, int wave, Ring &rs,
                                        const float4 *sbase, const float4 *nbase, float *stage, int total, NextRows &rows,
                                        const BfRegChain &nc, int ntile, int ntotal) {
     if constexpr (FAMILY == 0) {
-        if (shape == 0) br_tile<1, 1, 1, 1, false, NW, true, pfd_of(FAMILY)>(c, tile, sb, lane, wave, rs, sbase, nbase, stage, total, rows, nc, ntile, ntotal);
-        else if (shape == 1) br_tile<1, 1, 1, 2, false, NW, true, pfd_of(FAMILY)>(c, tile, sb, lane, wave, rs, sbase, nbase, stage, total, rows, nc, ntile, ntotal);
-        else br_tile<1, 2, 2, 4, false, NW, true, pfd_of(FAMILY)>(c, tile, sb, lane, wave, rs, sbase, nbase, stage, total, rows, nc, ntile, ntotal);
+        if (shape == 0) br_tile<1, 1, 1, 1, false, NW, true, pfd_of(FAMILY), SPLIT>(c, tile, sb, lane, wave, rs, sbase, nbase, stage, total, rows, nc, ntile, ntotal);
+        else if (shape == 1) br_tile<1, 1, 1, 2, false, NW, true, pfd_of(FAMILY), SPLIT>(c, tile, sb, lane, wave, rs, sbase, nbase, stage, total, rows, nc, ntile, ntotal);
+        else br_tile<1, 2, 2, 4, false, NW, true, pfd_of(FAMILY), SPLIT>(c, tile, sb, lane, wave, rs, sbase, nbase, stage, total, rows, nc, ntile, ntotal);
     } else if constexpr (FAMILY == 1) {
-        if (shape == 2) br_tile<5, 2, 2, 4, true, NW, false, pfd_of(FAMILY)>(c, tile, sb, lane, wave, rs, sbase, nbase, stage, total, rows, nc, ntile, ntotal);
-        else br_tile<5, 2, 3, 4, true, NW, false, pfd_of(FAMILY)>(c, tile, sb, lane, wave, rs, sbase, nbase, stage, total, rows, nc, ntile, ntotal);
+        if (shape == 2) br_tile<5, 2, 2, 4, true, NW, false, pfd_of(FAMILY), SPLIT>(c, tile, sb, lane, wave, rs, sbase, nbase, stage, total, rows, nc, ntile, ntotal);
+        else br_tile<5, 2, 3, 4, true, NW, false, pfd_of(FAMILY), SPLIT>(c, tile, sb, lane, wave, rs, sbase, nbase, stage, total, rows, nc, ntile, ntotal);
     } else if constexpr (FAMILY == 2) {
-        if (shape == 4) br_tile<9, 4, 4, 8, true, NW, false, pfd_of(FAMILY)>(c, tile, sb, lane, wave, rs, sbase, nbase, stage, total, rows, nc, ntile, ntotal);
-        else if (shape == 5) br_tile<9, 4, 6, 8, true, NW, false, pfd_of(FAMILY)>(c, tile, sb, lane, wave, rs, sbase, nbase, stage, total, rows, nc, ntile, ntotal);
-        else br_tile<9, 4, 8, 8, true, NW, false, pfd_of(FAMILY)>(c, tile, sb, lane, wave, rs, sbase, nbase, stage, total, rows, nc, ntile, ntotal);
+        if (shape == 4) br_tile<9, 4, 4, 8, true, NW, false, pfd_of(FAMILY), SPLIT>(c, tile, sb, lane, wave, rs, sbase, nbase, stage, total, rows, nc, ntile, ntotal);
+        else if (shape == 5) br_tile<9, 4, 6, 8, true, NW, false, pfd_of(FAMILY), SPLIT>(c, tile, sb, lane, wave, rs, sbase, nbase, stage, total, rows, nc, ntile, ntotal);
+        else br_tile<9, 4, 8, 8, true, NW, false, pfd_of(FAMILY), SPLIT>(c, tile, sb, lane, wave, rs, sbase, nbase, stage, total, rows, nc, ntile, ntotal);
     } else {
-        if (shape == 8) br_tile<17, 8, 8, 16, true, NW, false, pfd_of(FAMILY)>(c, tile, sb, lane, wave, rs, sbase, nbase, stage, total, rows, nc, ntile, ntotal);
-        else br_tile<17, 8, 16, 32, true, NW, false, pfd_of(FAMILY)>(c, tile, sb, lane, wave, rs, sbase, nbase, stage, total, rows, nc, ntile, ntotal);
+        if (shape == 8) br_tile<17, 8, 8, 16, true, NW, false, pfd_of(FAMILY), SPLIT>(c, tile, sb, lane, wave, rs, sbase, nbase, stage, total, rows, nc, ntile, ntotal);
+        else br_tile<17, 8, 16, 32, true, NW, false, pfd_of(FAMILY), SPLIT>(c, tile, sb, lane, wave, rs, sbase, nbase, stage, total, rows, nc, ntile, ntotal);
     }
 }
 
 constexpr int BR_NW = 4;
 
-template <int FAMILY>
+template <int FAMILY, bool SPLIT>
 __global__ __launch_bounds__(BR_NW * 64, FAMILY == 0 ? 4 : (FAMILY == 1 ? 3 : (FAMILY == 2 ? SAD_BR_F2 : 2))) void mlp_bf16_reg_kernel(const BfRegMulti mp) {
     constexpr int NW = BR_NW;
     constexpr int FPW = RS / NW;
@@ -535,7 +564,7 @@ __global__ __launch_bounds__(BR_NW * 64, FAMILY == 0 ? 4 : (FAMILY == 1 ? 3 : (F
         const int nci = chain_of(nit);
         // the tile's last two stages fetch the first two of the next item's stream, and the tile the row map of the next tile
         if constexpr (STATICW) rs.ring = ring + (ci == 0 ? 0 : (ci == 1 ? w1 : w2));
-        run_br<FAMILY, NW>(mp.c[ci], mp.shape[ci], tile_of(item, ci), sbias + (ci == 0 ? 0 : (ci == 1 ? b1 : b2)), lane, wave, rs,
+        run_br<FAMILY, NW, SPLIT>(mp.c[ci], mp.shape[ci], tile_of(item, ci), sbias + (ci == 0 ? 0 : (ci == 1 ? b1 : b2)), lane, wave, rs,
                            stream_of(item), stream_of(nit), stage, total_of(ci), rows, mp.c[nci], tile_of(nit, nci), total_of(nci));
     }
 #ifdef SAD_BR_STAMPS
@@ -618,15 +647,15 @@ int bfreg_pack(int shape, const int *dims, int first_has_xyz, const float *const
     return check_launch("sad_mlp_pack_bf16 (stream image)");
 }
 
-template <int FAMILY>
+template <int FAMILY, bool SPLIT>
 static int launch_bfreg_family(const BfRegMulti &mp, size_t lds, hipStream_t st) {
     static std::atomic<uint64_t> attr_done{0};
-    lds_attr_once(attr_done, reinterpret_cast<const void *>(&mlp_bf16_reg_kernel<FAMILY>), 160 * 1024);
+    lds_attr_once(attr_done, reinterpret_cast<const void *>(&mlp_bf16_reg_kernel<FAMILY, SPLIT>), 160 * 1024);
     static std::atomic<int> per_cu{0};
     int pc = per_cu.load(std::memory_order_relaxed);
     if (pc == 0) {
         int nb = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, mlp_bf16_reg_kernel<FAMILY>, BR_NW * 64, lds) != hipSuccess || nb < 1) {
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, mlp_bf16_reg_kernel<FAMILY, SPLIT>, BR_NW * 64, lds) != hipSuccess || nb < 1) {
             (void)hipGetLastError();
             nb = 1;
         }
@@ -638,7 +667,7 @@ static int launch_bfreg_family(const BfRegMulti &mp, size_t lds, hipStream_t st)
     long long grid = (long long)cus * pc;
     const long long cap = mp.max_tiles / BR_NW + mp.n;           // never more workgroups than items could exist
     if (grid > cap) grid = cap < 1 ? 1 : cap;
-    hipLaunchKernelGGL((mlp_bf16_reg_kernel<FAMILY>), dim3((unsigned)grid), dim3(BR_NW * 64), lds, st, mp);
+    hipLaunchKernelGGL((mlp_bf16_reg_kernel<FAMILY, SPLIT>), dim3((unsigned)grid), dim3(BR_NW * 64), lds, st, mp);
     return check_launch("sad_mlp_chain_bf16 (register-resident chain)");
 }
 
@@ -654,11 +683,22 @@ int launch_bfreg(const BfRegMulti &mp, hipStream_t st) {
         mq.static_f4 += mq.c[i].stream_frags * 64;
     }
     lds += sizeof(float4) * (size_t)(fam == 0 ? mq.static_f4 : RING_F4) + sizeof(float) * (size_t)BR_NW * STAGE_F;
+    const bool split = mq.c[0].out_bf16 != 0;
+    for (int i = 1; i < mq.n; ++i)
+        if ((mq.c[i].out_bf16 != 0) != split) return fail(SAD_EINVAL, "launch_bfreg: split-pooled and f32-pooled chains in one dispatch");
+    if (split) {
+        switch (fam) {
+            case 0: return launch_bfreg_family<0, true>(mq, lds, st);
+            case 1: return launch_bfreg_family<1, true>(mq, lds, st);
+            case 2: return launch_bfreg_family<2, true>(mq, lds, st);
+            default: return launch_bfreg_family<3, true>(mq, lds, st);
+        }
+    }
     switch (fam) {
-        case 0: return launch_bfreg_family<0>(mq, lds, st);
-        case 1: return launch_bfreg_family<1>(mq, lds, st);
-        case 2: return launch_bfreg_family<2>(mq, lds, st);
-        default: return launch_bfreg_family<3>(mq, lds, st);
+        case 0: return launch_bfreg_family<0, false>(mq, lds, st);
+        case 1: return launch_bfreg_family<1, false>(mq, lds, st);
+        case 2: return launch_bfreg_family<2, false>(mq, lds, st);
+        default: return launch_bfreg_family<3, false>(mq, lds, st);
     }
 }
 

@@ -22,6 +22,7 @@ namespace {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
 using sad::BfRowsJob;
 
 constexpr int KC = 4;                 // k-steps (of 16) per chunk
@@ -36,9 +37,21 @@ __device__ __forceinline__ bf16x8 cvt8(const float4 a, const float4 b) {
     return v;
 }
 
+// max of two vectors of eight NON-NEGATIVE bf16 (pooled rows: post-ReLU maxima): their order is the order of their bit patterns as
+// unsigned 16-bit integers — four v_pk_max_u16
+__device__ __forceinline__ float4 max_pos_bf16x8(const float4 a, const float4 b) {
+    return __builtin_bit_cast(float4, __builtin_elementwise_max(__builtin_bit_cast(u16x8, a), __builtin_bit_cast(u16x8, b)));
+}
+
 // NT = channel tiles (of 32) per item: 4, or 2 for layers with at most 64 output channels
-template <bool XBF16, int NT, int DX>
+// XCONT (with XBF16): the rows are SPLIT-POOLED (common.h BfRowsJob; mlp_bf16_reg.hip): row g of the chain behind a column range is the
+// maximum of x[g] and of the chain's continuation rows of the one or two tiles after the one the group's packed rows begin in.
+// The lane finds them once (two table reads per chain), loads the first beside every chunk of its row — row 0, all zero, for the
+// seven groups in eight that have none: no branch — and takes the maximum when the chunk is consumed; a second continuation row
+// (a group of more than 32 rows across three tiles) is rare and read behind a branch.
+template <bool XBF16, int NT, int DX, bool XCONT = false>
 __global__ __launch_bounds__(256) void bf16_rows_kernel(const BfRowsJob jb) {
+    static_assert(!XCONT || XBF16, "split-pooled rows are bf16");
     constexpr int STAGE_F4 = KC * NT * 64;
     __shared__ __attribute__((aligned(16))) float4 lds[2 * STAGE_F4];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -61,6 +74,19 @@ __global__ __launch_bounds__(256) void bf16_rows_kernel(const BfRowsJob jb) {
 
     // this lane's x: 8 consecutive k at k = 16 s + 8 h of its row
     const char *xrow = reinterpret_cast<const char *>(jb.x) + (size_t)rowc * jb.ldx * (XBF16 ? 2 : 4);
+    // split-pooled rows: byte offsets of this row's first / second continuation row inside the buffer of chain i (0: the zero row)
+    unsigned co1[SAD_MAX_RADII] = {}, co2[SAD_MAX_RADII] = {};
+    if constexpr (XCONT) {
+#pragma unroll
+        for (int i = 0; i < SAD_MAX_RADII; ++i) {
+            if (i < jb.n_pool) {
+                const int r0 = jb.pool_gstart[i][rowc], r1 = jb.pool_gstart[i][rowc + 1];
+                const int t0 = r0 >> 5, n = ((r1 - 1) >> 5) - t0;
+                co1[i] = n >= 1 ? (unsigned)(t0 + 1) * (unsigned)jb.pool_ld[i] * 2u : 0u;
+                co2[i] = n >= 2 ? (unsigned)(t0 + 2) * (unsigned)jb.pool_ld[i] * 2u : 0u;
+            }
+        }
+    }
     struct XRaw { float4 a[KC], b[KC]; };
     auto load_x = [&](int c) -> XRaw {
         XRaw v;
@@ -75,6 +101,17 @@ __global__ __launch_bounds__(256) void bf16_rows_kernel(const BfRowsJob jb) {
                 v.a[s] = *reinterpret_cast<const float4 *>(xrow + (size_t)kk * 2);
                 v.b[s] = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (!ok) v.a[s] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if constexpr (XCONT) {
+                    // the chain behind this k-step (column ranges are multiples of 16: wave-uniform)
+                    const int k16 = 16 * ks;
+                    const int ci = (k16 >= jb.pool_col0[1]) + (k16 >= jb.pool_col0[2]) + (k16 >= jb.pool_col0[3]);
+                    const char *cb = reinterpret_cast<const char *>(ci == 0 ? jb.pool_cont[0] : (ci == 1 ? jb.pool_cont[1] : (ci == 2 ? jb.pool_cont[2] : jb.pool_cont[3])));
+                    const unsigned o1 = ci == 0 ? co1[0] : (ci == 1 ? co1[1] : (ci == 2 ? co1[2] : co1[3]));
+                    const unsigned o2 = ci == 0 ? co2[0] : (ci == 1 ? co2[1] : (ci == 2 ? co2[2] : co2[3]));
+                    const unsigned kc = ok ? (unsigned)(k - (ci == 0 ? 0 : (ci == 1 ? jb.pool_col0[1] : (ci == 2 ? jb.pool_col0[2] : jb.pool_col0[3])))) * 2u : 0u;
+                    v.b[s] = *reinterpret_cast<const float4 *>(cb + (size_t)(ok ? o1 : 0u) + kc);
+                    if (ok && o2 != 0u) v.b[s] = max_pos_bf16x8(v.b[s], *reinterpret_cast<const float4 *>(cb + (size_t)o2 + kc));
+                }
             } else {
                 v.a[s] = *reinterpret_cast<const float4 *>(xrow + (size_t)kk * 4);
                 v.b[s] = *reinterpret_cast<const float4 *>(xrow + (size_t)kk * 4 + 16);
@@ -126,7 +163,8 @@ __global__ __launch_bounds__(256) void bf16_rows_kernel(const BfRowsJob jb) {
             const float4 *cur = lds + (c & 1) * STAGE_F4;
             bf16x8 x[KC];
     #pragma unroll
-            for (int s = 0; s < KC; ++s) x[s] = XBF16 ? __builtin_bit_cast(bf16x8, xn.a[s]) : cvt8(xn.a[s], xn.b[s]);
+            for (int s = 0; s < KC; ++s)
+                x[s] = XCONT ? __builtin_bit_cast(bf16x8, max_pos_bf16x8(xn.a[s], xn.b[s])) : (XBF16 ? __builtin_bit_cast(bf16x8, xn.a[s]) : cvt8(xn.a[s], xn.b[s]));
             const int cn = c + 1 < NC ? c + 1 : c;
             xn = load_x(cn);                            // the next chunk's rows and weights are in flight during the MFMAs
             const WRaw wn = load_w(cn);
@@ -189,7 +227,9 @@ __global__ __launch_bounds__(256) void bf16_rows_kernel(const BfRowsJob jb) {
                     const float4 *cur = lds + (i & 1) * STAGE_F4;
                     bf16x8 x[KC];
     #pragma unroll
-                    for (int s = 0; s < KC; ++s) x[s] = XBF16 ? __builtin_bit_cast(bf16x8, xq[i % DX].a[s]) : cvt8(xq[i % DX].a[s], xq[i % DX].b[s]);
+                    for (int s = 0; s < KC; ++s)
+                        x[s] = XCONT ? __builtin_bit_cast(bf16x8, max_pos_bf16x8(xq[i % DX].a[s], xq[i % DX].b[s]))
+                                     : (XBF16 ? __builtin_bit_cast(bf16x8, xq[i % DX].a[s]) : cvt8(xq[i % DX].a[s], xq[i % DX].b[s]));
                     const int cx = c + DX < NC ? c + DX : NC - 1, cw = c + 2 < NC ? c + 2 : NC - 1;
     #if defined(SAD_ROWS_ABL) && SAD_ROWS_ABL == 1       // measurement builds: 1 the rows are loaded once, 2 the weights are loaded once (wrong results)
                     if (c == 0) xq[i % DX] = load_x(cx);
@@ -301,6 +341,13 @@ int launch_bf16_rows(const BfRowsJob &job, hipStream_t st) {
     const bool deep = (jb.ks + KC - 1) / KC > 2 && grid <= 2LL * cus;
 #endif
 #define SAD_ROWS_LAUNCH(XB, NTV, DXV) hipLaunchKernelGGL((bf16_rows_kernel<XB, NTV, DXV>), dim3((unsigned)grid), dim3(256), 0, st, jb)
+    if (jb.n_pool) {
+        if (!jb.x_bf16) return fail(SAD_EINVAL, "sad_mlp_chain_bf16: split-pooled rows are bf16");
+#define SAD_ROWS_LAUNCH_C(NTV, DXV) hipLaunchKernelGGL((bf16_rows_kernel<true, NTV, DXV, true>), dim3((unsigned)grid), dim3(256), 0, st, jb)
+        if (nt == 4) { if (deep) SAD_ROWS_LAUNCH_C(4, SAD_ROWS_DX); else SAD_ROWS_LAUNCH_C(4, 0); }
+        else { if (deep) SAD_ROWS_LAUNCH_C(2, SAD_ROWS_DX); else SAD_ROWS_LAUNCH_C(2, 0); }
+#undef SAD_ROWS_LAUNCH_C
+    } else
     if (nt == 4) {
         if (jb.x_bf16) { if (deep) SAD_ROWS_LAUNCH(true, 4, SAD_ROWS_DX); else SAD_ROWS_LAUNCH(true, 4, 0); }
         else { if (deep) SAD_ROWS_LAUNCH(false, 4, SAD_ROWS_DX); else SAD_ROWS_LAUNCH(false, 4, 0); }

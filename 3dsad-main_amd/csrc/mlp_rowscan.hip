@@ -90,6 +90,14 @@ __global__ __launch_bounds__(SCAN_T) void rowscan_write_kernel(const sad::ScanMu
     if (tid == SCAN_T - 1) s_start[SCAN_T] = run + c;
     __syncthreads();
     const int blk_rows = s_start[SCAN_T];
+    if (jb.split) {
+        // split pooling: first packed row of every group (the consumer of the pooled rows derives a group's continuation tiles
+        // from it), and the all-zero row 0 of the continuation buffer (what a group without continuation reads)
+        if (g < jb.ngroups) jb.gstart[g] = base + run;
+        if (g == jb.ngroups - 1) jb.gstart[jb.ngroups] = base + run + c;
+        if (lb == 0)
+            for (int i = tid; i < jb.cont_cols / 2; i += SCAN_T) reinterpret_cast<unsigned *>(jb.cont0)[i] = 0u;
+    }
     if (g == jb.ngroups - 1) {
         const int total = base + run + c;
         jb.tab[0] = total;
@@ -149,9 +157,10 @@ __global__ __launch_bounds__(SCAN_T) void rowscan_write_kernel(const sad::ScanMu
             const int gg = lb * SCAN_T + lo[u];
             const int r0 = base + s_start[lo[u]], cc = s_start[lo[u] + 1] - s_start[lo[u]];
             const int whole = ((r0 >> 5) == ((r0 + cc - 1) >> 5)) ? WHOLE_BIT : 0;
+            const int cont = (jb.split && ((base + q) >> 5) != (r0 >> 5)) ? sad::CONT_BIT : 0;
             const long long b = gg / jb.M;
             src[u] = (int)(b * jb.N + jb.idx[(long long)gg * jb.S + (q - s_start[lo[u]])]);
-            gid[u] = gg | whole;
+            gid[u] = gg | whole | cont;
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -178,6 +187,7 @@ ScanJob make_scan_job(const int32_t *cnt, int ngroups, int S, int R, int *tab, i
         jb.row_src = tab + 4 + (ngroups + 1) + ((long long)ngroups * S / 32 + 2) + (ngroups / 1024 + 2);
         jb.row_gid = jb.row_src + (long long)ngroups * S;
     }
+    jb.gstart = tab + scan_gstart_off(ngroups, S);      // (written by a split-pooling scan only)
     return jb;
 }
 
@@ -242,9 +252,35 @@ SAD_API int sad_mlp_rowscan_init(int n, const int32_t *const *cnt, const int32_t
     return sad::launch_rowscan_multi(jobs, n, (hipStream_t)stream);
 }
 
+SAD_API int sad_mlp_rowscan_split(int n, const int32_t *const *cnt, const int32_t *const *idx, const int *S, int B, int N,
+                                  int M, void *const *workspace, void *const *cont, const int *cout, sad_stream_t stream) {
+    SAD_REQUIRE(n >= 1 && n <= sad::SCAN_MAX_CHAINS && cnt && idx && S && workspace && cont && cout,
+                "sad_mlp_rowscan_split: need 1..%d chains and non-NULL arrays", sad::SCAN_MAX_CHAINS);
+    SAD_REQUIRE(B >= 1 && N >= 1 && M >= 1 && (long long)B * M < (long long)sad::CONT_BIT, "sad_mlp_rowscan_split: bad B/N/M");
+    sad::ScanJob jobs[sad::SCAN_MAX_CHAINS];
+    for (int i = 0; i < n; ++i) {
+        SAD_REQUIRE(cnt[i] && idx[i] && workspace[i] && S[i] >= 1 && S[i] <= 64, "sad_mlp_rowscan_split: chain %d: NULL pointer or bad nsample", i);
+        SAD_REQUIRE((uintptr_t)workspace[i] % 16 == 0, "sad_mlp_rowscan_split: workspace must be 16-byte aligned");
+        SAD_REQUIRE((long long)B * M * S[i] < (1LL << 31), "sad_mlp_rowscan_split: B*M*S too large");
+        SAD_REQUIRE(cont[i] && (uintptr_t)cont[i] % 16 == 0 && cout[i] >= 8 && cout[i] % 8 == 0,
+                    "sad_mlp_rowscan_split: chain %d: need a 16-byte aligned continuation buffer and cout %% 8 == 0", i);
+        jobs[i] = sad::make_scan_job(cnt[i], B * M, S[i], 32, (int *)workspace[i], 0, idx[i], N, M);
+        jobs[i].split = 1;
+        jobs[i].cont0 = cont[i];
+        jobs[i].cont_cols = cout[i];
+    }
+    return sad::launch_rowscan_multi(jobs, n, (hipStream_t)stream);
+}
+
+SAD_API size_t sad_mlp_cont_bytes(int B, int M, int S, int cout) {
+    if (B < 1 || M < 1 || S < 1 || cout < 1) return 0;
+    const size_t tiles = ((size_t)B * M * S + 31) / 32;          // a tile t >= 1 may hold the continuation of one group: row t; row 0 stays zero
+    return (tiles + 1) * (size_t)cout * 2;
+}
+
 SAD_API size_t sad_mlp_workspace_bytes(int B, int M, int S) {
     if (B < 1 || M < 1 || S < 1) return 0;
     const size_t ng = (size_t)B * M;
-    // hdr, row_start, pass_first (R >= 32), block sums of the two-launch scan
-    return sizeof(int) * (4 + (ng + 1) + (ng * S / 32 + 2) + (ng / 1024 + 2) + 2 * ng * S) + 64;   // + row map
+    // hdr, row_start, pass_first (R >= 32), block sums of the two-launch scan, row map, first packed row of every group (split pooling)
+    return sizeof(int) * ((size_t)sad::scan_gstart_off((long long)ng, S) + ng + 1) + 64;
 }

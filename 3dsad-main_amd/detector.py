@@ -331,27 +331,52 @@ class SADDetector(nn.Module):
                 # zero-fills the few groups the chain kernels combine with an atomic max and the buffers stay uninitialised
                 # (217 MB per 32-scene KITTI step not filled); otherwise one zero fill, covered by ev_xyz
                 prep = self.query_on_sampling_stream and not ops.AUTOTUNE
+                # bf16 mode: split pooling per stage where it applies (sa_module.can_split: bf16 pooled rows + continuation rows,
+                # plain stores, nothing to fill; the aggregation layer takes the maximum as it reads) — not when a trace is asked
+                # for (it hands out the pooled buffers) or the buffers are poisoned
+                split_ok = prep and trace is None and not self.poison_buffers and self.dtype == "bf16"
+                n_in = [N] + [m.stage.npoint for m in self.stages[:-1]]
+                splits = []
+                for si, m in enumerate(self.stages):
+                    prev_agg = si > 0 and self.stages[si - 1].agg is not None
+                    splits.append(split_ok and m.can_split(B, n_in[si], m.stage.npoint, feat=feat if si == 0 else None,
+                                                           feat_dtype=torch.bfloat16 if prev_agg else torch.float32))
+                m3, cin = self.stages[-1].stage.npoint, self.stages[-1].out_channels
+                fdt = torch.bfloat16 if (self.dtype == "bf16" and self.stages[-1].agg is not None) else torch.float32
+                cluster_tables = all(mlp.wants_prescan(B, m3, cfg.n_cand, s_, self.cluster_cat, cin, feat_dtype=fdt)
+                                     for mlp, s_ in zip(self.cluster_branches, cfg.cluster_nsamples))
+                splits.append(split_ok and ops.SPLIT_POOL and cluster_tables and self.agg_head is None
+                              and all(mlp.preferred_geometry == 2 and mlp.out_channels % 16 == 0 for mlp in self.cluster_branches)
+                              and self.cluster_agg.takes_pooled(B * cfg.n_cand, self.cluster_agg.out_channels))
                 shapes = [(B, m.stage.npoint, m.cat_channels) for m in self.stages]
                 shapes.append((B, cfg.n_cand, self.cluster_cat))
                 if not prep:
                     ops._unrecordable("zero-filled pooling buffers")
-                zeros = (ops._empty if prep else torch.zeros)((sum(a * b_ * c_ for a, b_, c_ in shapes),), dtype=torch.float32,
-                                                              device=points.device)
+                zeros = (ops._empty if prep else torch.zeros)((sum(a * b_ * c_ for (a, b_, c_), sp in zip(shapes, splits) if not sp),),
+                                                              dtype=torch.float32, device=points.device)
                 if prep and self.poison_buffers:      # (tests: whatever the kernels do not write must not matter)
                     ops._unrecordable("poisoned buffers")
                     zeros.fill_(float("nan"))
-                cats, o = [], 0
-                for shp in shapes:
+                cats, conts, o = [], [], 0
+                for si, (shp, sp) in enumerate(zip(shapes, splits)):
+                    if sp:
+                        if si < len(self.stages):
+                            c_, k_ = self.stages[si].split_buffers(B, shp[1], points.device)
+                        else:
+                            c_ = ops._empty(shp, dtype=torch.bfloat16, device=points.device)
+                            k_ = [ops.cont_buffer(B, shp[1], s_, mlp.out_channels, points.device)
+                                  for mlp, s_ in zip(self.cluster_branches, cfg.cluster_nsamples)]
+                        cats.append(c_)
+                        conts.append(k_)
+                        continue
                     n_el = shp[0] * shp[1] * shp[2]
                     cats.append(zeros[o:o + n_el].view(shp))
+                    conts.append(None)
                     o += n_el
-                if prep:
+                if prep and not splits[-1]:
                     # the cluster dispatch scans for itself (its query needs the candidates): fine when both branches run table
                     # kernels (the dispatch's own scan prepares `out`), else zero the buffer here
-                    m3, cin = self.stages[-1].stage.npoint, self.stages[-1].out_channels
-                    fdt = torch.bfloat16 if (self.dtype == "bf16" and self.stages[-1].agg is not None) else torch.float32
-                    if not all(mlp.wants_prescan(B, m3, cfg.n_cand, s_, self.cluster_cat, cin, feat_dtype=fdt)
-                               for mlp, s_ in zip(self.cluster_branches, cfg.cluster_nsamples)):
+                    if not cluster_tables:
                         ops._unrecordable("zero fill of the cluster pooling buffer")
                         cats[-1].zero_()
                 ev_xyz = new_event(side)
@@ -367,7 +392,8 @@ class SADDetector(nn.Module):
                     prev_agg = si > 0 and self.stages[si - 1].agg is not None
                     queries.append(self.stages[si].query(prev, cur, prescan=not ops.AUTOTUNE, cat=cats[si] if prep else None,
                                                          feat=feat if si == 0 else None,
-                                                         feat_dtype=torch.bfloat16 if (self.dtype == "bf16" and prev_agg) else torch.float32)
+                                                         feat_dtype=torch.bfloat16 if (self.dtype == "bf16" and prev_agg) else torch.float32,
+                                                         conts=conts[si])
                                    if self.query_on_sampling_stream else None)
                     evs.append(new_event(side))
             points.record_stream(side)
@@ -380,6 +406,11 @@ class SADDetector(nn.Module):
                             if t is not None:          # (a branch whose kernel packs for itself has no prescanned table)
                                 t.record_stream(main)
             zeros.record_stream(main)
+            for c_, k_ in zip(cats, conts):
+                if k_ is not None:
+                    c_.record_stream(main)
+                    for t in k_:
+                        t.record_stream(main)
             wait_for(main, ev_xyz)
         else:
             xyz, feat = ops.split_points(points)
@@ -387,11 +418,12 @@ class SADDetector(nn.Module):
             evs = [None] * len(centroids)
             queries = [None] * len(centroids)
             cats = [None] * (len(centroids) + 1)
+            conts = [None] * (len(centroids) + 1)
         cur_xyz, cur_feat = xyz, feat
         for si, m in enumerate(self.stages):
             wait_for(main, evs[si])
             new_xyz = centroids[si]
-            cur_feat = m.group_and_pool(cur_xyz, cur_feat, new_xyz, query=queries[si], cat=cats[si],
+            cur_feat = m.group_and_pool(cur_xyz, cur_feat, new_xyz, query=queries[si], cat=cats[si], conts=conts[si],
                                         keep=None if trace is None else trace.setdefault(f"sa{si + 1}", {}))
             if trace is not None:
                 trace[f"sa{si + 1}"].update(new_xyz=new_xyz, out=cur_feat)
@@ -413,12 +445,25 @@ class SADDetector(nn.Module):
             ops._unrecordable("zero-filled cluster pooling buffer")
             cat = torch.zeros((B, K, self.cluster_cat), dtype=torch.float32, device=points.device)
         calls, off = [], 0
-        for mlp, idx, cnt in zip(self.cluster_branches, idxs, cnts):
-            calls.append((mlp, cur_xyz, cur_feat, cand, idx, cat, off, cnt))
+        ckont = conts[-1]
+        if ckont is not None:
+            # split pooling: the tables come from an explicit scan (the same two launches the dispatch would make itself), the aggregation
+            # layer needs them beside the continuation rows
+            outs, o_ = [], 0
+            for mlp, k_ in zip(self.cluster_branches, ckont):
+                outs.append((cat, o_, mlp.out_channels, k_))
+                o_ += mlp.out_channels
+            cwss = ops.rowscan_multi(idxs, cnts, M3, outs)
+        for bi, (mlp, idx, cnt) in enumerate(zip(self.cluster_branches, idxs, cnts)):
+            calls.append((mlp, cur_xyz, cur_feat, cand, idx, cat, off, cnt) + ((cwss[bi], ckont[bi]) if ckont is not None else ()))
             off += mlp.out_channels
         ops.grouped_multi(calls)
         # ---- head + decode (SPEC.md §9) -------------------------------------------------------
-        if self.agg_head is not None and trace is None:
+        if ckont is not None:
+            pool = [(w_, k_, s_, mlp.out_channels) for w_, k_, s_, mlp in zip(cwss, ckont, cfg.cluster_nsamples, self.cluster_branches)]
+            cfeat = self.cluster_agg.rows(cat, pool=pool)
+            o = self.head.rows(cfeat)                                    # [B,K,10]
+        elif self.agg_head is not None and trace is None:
             cfeat = None
             o = self.agg_head.rows(cat)                                  # [B,K,10]
         else:

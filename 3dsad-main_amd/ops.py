@@ -328,7 +328,10 @@ def rowscan_multi(idxs: Sequence[torch.Tensor], cnts: Sequence[torch.Tensor], N:
     that ran the query (the sampling stream), off the MLP stream's critical path; pass table i as the last
     element of branch i's ``grouped_multi`` call (``PackedMLP.grouped(..., ws=table)``).
     ``outs`` = [(out [B,M,ld_out] float32, col_off, C_out)] per branch: the scan also zero-fills the output slice of the
-    groups the chain kernels combine with an atomic max, so ``out`` may be UNINITIALISED (``sad_mlp_rowscan_init``)."""
+    groups the chain kernels combine with an atomic max, so ``out`` may be UNINITIALISED (``sad_mlp_rowscan_init``).
+    Split pooling (bf16 mode): ``outs`` = [(out [B,M,ld_out] bfloat16, col_off, C_out, cont)] with ``cont`` from
+    ``cont_buffer`` — nothing is filled, the tables carry what a split-pooled chain and the layer that reads its rows need
+    (``sad_mlp_rowscan_split``)."""
     n = len(idxs)
     if n != len(cnts) or not 1 <= n <= _lib.MAX_RADII:
         raise ValueError(f"need 1..{_lib.MAX_RADII} (idx, cnt) pairs")
@@ -349,6 +352,20 @@ def rowscan_multi(idxs: Sequence[torch.Tensor], cnts: Sequence[torch.Tensor], N:
         return wss
     if len(outs) != n:
         raise ValueError("outs: one (out, col_off, C_out) per branch")
+    if any(len(o) > 3 for o in outs):
+        if not all(len(o) == 4 and o[3] is not None and o[0].dtype == torch.bfloat16 for o in outs):
+            raise ValueError("outs: split pooling needs (bfloat16 out, col_off, C_out, cont) for EVERY branch of the scan")
+        for (o, off, co, cont), idx in zip(outs, idxs):
+            if tuple(o.shape[:2]) != (B, M) or not o.is_contiguous() or off < 0 or off + co > o.shape[2]:
+                raise ValueError("outs: need contiguous [B,M,ld_out] buffers with col_off + C_out <= ld_out")
+            if cont.numel() * cont.element_size() < lib().sad_mlp_cont_bytes(B, M, int(idx.shape[2]), int(co)):
+                raise ValueError("outs: continuation buffer too small (ops.cont_buffer)")
+        k_arr = (vp * n)(*[o[3].data_ptr() for o in outs])
+        co_arr = (ctypes.c_int * n)(*[int(o[2]) for o in outs])
+        check(lib().sad_mlp_rowscan_split(n, c_arr, i_arr, s_arr, B, int(N), M, w_arr, k_arr, co_arr, _stream()), "sad_mlp_rowscan_split")
+        for w in wss:
+            w._sad_split = True
+        return wss
     for o, off, co in outs:
         o = _need(o, "out", torch.float32, 3)
         if tuple(o.shape[:2]) != (B, M) or not o.is_contiguous() or off < 0 or off + co > o.shape[2]:
@@ -360,6 +377,11 @@ def rowscan_multi(idxs: Sequence[torch.Tensor], cnts: Sequence[torch.Tensor], N:
     check(lib().sad_mlp_rowscan_init(n, c_arr, i_arr, s_arr, B, int(N), M, w_arr, o_arr, ld_arr, off_arr, co_arr, _stream()),
           "sad_mlp_rowscan_init")
     return wss
+
+
+def cont_buffer(B: int, M: int, S: int, cout: int, device) -> torch.Tensor:
+    """Continuation rows of one split-pooled bf16 chain (``sad_mlp_cont_bytes``; include/sad_amd.h ``sad_mlp_bf16_args.cont``)."""
+    return _empty((lib().sad_mlp_cont_bytes(int(B), int(M), int(S), int(cout)),), dtype=torch.uint8, device=device)
 
 
 _ITEMQ_INTS = 2 + 32 * 8      # csrc/common.h: a table carries the per-XCD item queues (and these ints) only when it has this many row starts
@@ -774,6 +796,8 @@ class PackedMLP:
 
 # bf16 chains: merge the branches of a stage into one dispatch (sad_mlp_chain_multi_bf16)?
 MERGE_BF16: bool = True
+# bf16 stages with an aggregation layer: split pooling (bf16 pooled rows + continuation rows, no atomics, no zero fill; sa_module.can_split)?
+SPLIT_POOL: bool = not os.environ.get("SAD_NO_SPLIT_POOL")
 
 
 def grouped_multi(calls) -> None:
@@ -785,7 +809,10 @@ def grouped_multi(calls) -> None:
     if AUTOTUNE or len(calls) < 2 or (not MERGE_BF16 and isinstance(calls[0][0], PackedMLPBf16)):
         for c in calls:
             mlp, xyz, feat_pm, new_xyz, idx, out, col_off, cnt = c[:8]
-            mlp.grouped(xyz, feat_pm, new_xyz, idx, out=out, col_off=col_off, cnt=cnt)
+            if len(c) > 9 and c[9] is not None:
+                mlp.grouped(xyz, feat_pm, new_xyz, idx, out=out, col_off=col_off, cnt=cnt, ws=c[8], cont=c[9])
+            else:
+                mlp.grouped(xyz, feat_pm, new_xyz, idx, out=out, col_off=col_off, cnt=cnt)
         if AUTOTUNE and len(calls) >= 2:
             _tune_stage([c[:8] for c in calls])
         return
@@ -793,7 +820,10 @@ def grouped_multi(calls) -> None:
     for c in calls:
         mlp, xyz, feat_pm, new_xyz, idx, out, col_off, cnt = c[:8]
         ws = c[8] if len(c) > 8 else None
-        a, _, k = mlp._grouped_args(xyz, feat_pm, new_xyz, idx, out, col_off, cnt, ws)
+        if len(c) > 9 and c[9] is not None:      # (split pooling: bf16 chains only)
+            a, _, k = mlp._grouped_args(xyz, feat_pm, new_xyz, idx, out, col_off, cnt, ws, cont=c[9])
+        else:
+            a, _, k = mlp._grouped_args(xyz, feat_pm, new_xyz, idx, out, col_off, cnt, ws)
         args.append(a)
         keep.append(k)
     bf16 = isinstance(calls[0][0], PackedMLPBf16)
@@ -973,17 +1003,21 @@ class PackedMLPBf16:
 
     def grouped(self, xyz: torch.Tensor, feat_pm: Optional[torch.Tensor], new_xyz: torch.Tensor,
                 idx: torch.Tensor, out: Optional[torch.Tensor] = None, col_off: int = 0,
-                cnt: Optional[torch.Tensor] = None, ws: Optional[torch.Tensor] = None) -> torch.Tensor:
+                cnt: Optional[torch.Tensor] = None, ws: Optional[torch.Tensor] = None,
+                cont: Optional[torch.Tensor] = None) -> torch.Tensor:
         """xyz [B,N,3] f32; feat_pm point-major [B,N,C] bf16/f32 (or None); new_xyz [B,M,3]; idx
         [B,M,S] -> out[:, :, col_off:col_off+C_out] of a ZERO-initialised float32 [B,M,ld] buffer.
         With ``cnt`` ([B,M] int32 from ball_query_multi(return_counts=True)) only the leading cnt
         rows of each group are computed — the ball query's padding rows cannot change the max.
-        ``ws``: the row-packing table of (idx, cnt) from ``rowscan_multi`` (geometry 2 then launches no scan)."""
-        a, out, _keep = self._grouped_args(xyz, feat_pm, new_xyz, idx, out, col_off, cnt, ws)
+        ``ws``: the row-packing table of (idx, cnt) from ``rowscan_multi`` (geometry 2 then launches no scan).
+        Split pooling: ``out`` an UNINITIALISED bfloat16 [B,M,ld] buffer and ``cont`` from ``cont_buffer`` (needs ``cnt`` and the
+        register-resident chain) — the true pooled row is the maximum of out[g] and the group's continuation rows, which
+        ``rows(..., pool=...)`` takes while it reads them (include/sad_amd.h ``sad_mlp_bf16_args.cont``)."""
+        a, out, _keep = self._grouped_args(xyz, feat_pm, new_xyz, idx, out, col_off, cnt, ws, cont)
         self._launch(a, _keep + [out])
         return out
 
-    def _grouped_args(self, xyz, feat_pm, new_xyz, idx, out, col_off, cnt, ws=None):
+    def _grouped_args(self, xyz, feat_pm, new_xyz, idx, out, col_off, cnt, ws=None, cont=None):
         """Validated ``MlpBf16Args`` of a grouped call + the output tensor + tensors to keep alive."""
         if not self.first_has_xyz:
             raise RuntimeError("this PackedMLPBf16 was packed without the xyz prefix")
@@ -1010,11 +1044,23 @@ class PackedMLPBf16:
         if out is None:
             _unrecordable("grouped: zero-filled output")
             out = torch.zeros((B, M, self.out_channels), dtype=torch.float32, device=xyz.device)
-        if out.dtype != torch.float32 or not out.is_contiguous() or col_off + self.out_channels > out.shape[-1]:
-            raise ValueError("out: expected a contiguous float32 [B,M,ld_out] buffer wide enough")
+        split = out.dtype == torch.bfloat16
+        if (not split and out.dtype != torch.float32) or not out.is_contiguous() or col_off + self.out_channels > out.shape[-1]:
+            raise ValueError("out: expected a contiguous float32 (or, split pooling, bfloat16) [B,M,ld_out] buffer wide enough")
+        if split != (cont is not None):
+            raise ValueError("split pooling needs both a bfloat16 out and a continuation buffer (ops.cont_buffer)")
         a.xyz, a.new_xyz, a.idx = xyz.data_ptr(), new_xyz.data_ptr(), idx.data_ptr()
         a.B, a.N, a.M, a.S, a.C = B, N, M, S, C
-        a.out, a.out_bf16, a.ld_out, a.col_off = out.data_ptr(), 0, out.stride(-2), col_off
+        a.out, a.out_bf16, a.ld_out, a.col_off = out.data_ptr(), int(split), out.stride(-2), col_off
+        if split:
+            if cnt is None or self.preferred_geometry != 2 or not self._feat_ok_reg(feat_pm):
+                raise RuntimeError(f"{self.name or 'PackedMLPBf16'}: split pooling runs on the register-resident chain only (cnt, a compiled shape, 16-byte bf16 feature rows)")
+            if cont.numel() * cont.element_size() < lib().sad_mlp_cont_bytes(B, M, S, self.out_channels):
+                raise ValueError("cont: too small (ops.cont_buffer)")
+            if ws is not None and not getattr(ws, "_sad_split", False):
+                raise RuntimeError("split pooling: the row-packing table must come from rowscan_multi with split-pooling outs")
+            a.cont = cont.data_ptr()
+            keep.append(cont)
         if cnt is not None:
             cnt = _need(cnt, "cnt", torch.int32, 2)
             if tuple(cnt.shape) != (B, M):
@@ -1029,6 +1075,8 @@ class PackedMLPBf16:
         a.geometry = self._geom.get((bool(a.idx), a.B, a.N, a.M, a.S, a.ld_out)) or self.default_geometry
         if not a.geometry and cnt is not None and not AUTOTUNE and self._feat_ok_reg(feat_pm):
             a.geometry = self.preferred_geometry
+        if split:
+            a.geometry = 2
         if cnt is not None and given:
             if a.geometry != 2:       # (same backstop as PackedMLP._grouped_args: the tiled kernel needs a ZERO buffer)
                 raise RuntimeError(f"{self.name or 'PackedMLPBf16'}: a row-packing table (ws) was passed but geometry {a.geometry} "
@@ -1042,6 +1090,13 @@ class PackedMLPBf16:
         key = (bool(a.idx), a.B, a.N, a.M, a.S, a.ld_out)
         geom = self._geom.get(key)
         preferred = a.geometry          # the un-tuned choice of _grouped_args (0 while autotuning)
+        if a.idx and a.out_bf16:        # split pooling: the register-resident chain, nothing to tune
+            with _timed("mlp", self.name):
+                check(lib().sad_mlp_chain_bf16(ctypes.byref(a), _stream()), "sad_mlp_chain_bf16")
+            if RERUN_LOG is not None:
+                RERUN_LOG.append((self.name, lambda a=a, keep=keep: check(
+                    lib().sad_mlp_chain_bf16(ctypes.byref(a), _stream()), "sad_mlp_chain_bf16")))
+            return
         if geom is None and AUTOTUNE:
             stream = torch.cuda.current_stream()
             best, best_ms, reg_ms = 0, None, None
@@ -1077,13 +1132,29 @@ class PackedMLPBf16:
             RERUN_LOG.append((self.name, lambda a=a, keep=keep: check(
                 lib().sad_mlp_chain_bf16(ctypes.byref(a), _stream()), "sad_mlp_chain_bf16")))
 
+    def takes_pooled(self, rows: int, ld_out: int) -> bool:
+        """Can ``rows(..., pool=...)`` read split-pooled rows: one layer on the row-streaming kernel (the autotuner may have picked a
+        tiled kernel for this layer: then not)."""
+        geom = self._geom.get((False, 1, 0, rows, 1, ld_out)) or self.default_geometry
+        return self.L == 1 and not self.first_has_xyz and self.dims[0] % 8 == 0 and geom in (0, 3)
+
     def rows(self, x: torch.Tensor, out: Optional[torch.Tensor] = None, col_off: int = 0,
-             out_dtype=torch.float32) -> torch.Tensor:
-        """Plain rows.  x [..., C] bf16/f32 (last-dim stride 1) -> [..., C_out] f32 or bf16."""
+             out_dtype=torch.float32, pool=None) -> torch.Tensor:
+        """Plain rows.  x [..., C] bf16/f32 (last-dim stride 1) -> [..., C_out] f32 or bf16.
+        ``pool`` = [(ws, cont, S, cols)] per chain, in column order: ``x`` holds SPLIT-POOLED rows (``grouped(..., cont=...)``)
+        of these chains side by side; the layer takes the maximum with their continuation rows while it reads them."""
         if self.first_has_xyz:
             raise RuntimeError("this PackedMLPBf16 was packed with the xyz prefix")
         a = self._args()
         a.feat_bf16 = self._feat(x, "x")
+        keep_pool = []
+        if pool:
+            if len(pool) > _lib.MAX_RADII or x.dtype != torch.bfloat16 or not x.is_contiguous():
+                raise ValueError(f"pool: at most {_lib.MAX_RADII} chains behind contiguous bfloat16 rows")
+            a.n_pool = len(pool)
+            for i, (ws, cont, S, cols) in enumerate(pool):
+                a.pool_ws[i], a.pool_cont[i], a.pool_S[i], a.pool_cols[i] = ws.data_ptr(), cont.data_ptr(), int(S), int(cols)
+                keep_pool += [ws, cont]
         C = x.shape[-1]
         if C != self.dims[0]:
             raise ValueError(f"MLP expects {self.dims[0]} channels, got {C}")
@@ -1102,6 +1173,17 @@ class PackedMLPBf16:
         a.B, a.N, a.M, a.S, a.C = 1, 0, R, 1, C
         a.out, a.out_bf16 = out.data_ptr(), int(out.dtype == torch.bfloat16)
         a.ld_out, a.col_off = out.stride(-2), col_off
+        if pool:
+            a.geometry = 0                # (the row-streaming layer: the only reader of split-pooled rows)
+            with _timed("mlp", self.name):
+                check(lib().sad_mlp_chain_bf16(ctypes.byref(a), _stream()), "sad_mlp_chain_bf16")
+            if RERUN_LOG is not None:
+                RERUN_LOG.append((self.name, lambda a=a, keep=[x2, out] + keep_pool: check(
+                    lib().sad_mlp_chain_bf16(ctypes.byref(a), _stream()), "sad_mlp_chain_bf16")))
+            _rec = _lib.recorder()
+            if _rec is not None:
+                _rec.keep.append((a, keep_pool))
+            return out
         self._launch(a, [x2, out])
         return out
 

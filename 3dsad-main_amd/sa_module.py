@@ -56,9 +56,30 @@ class SAModuleMSG(nn.Module):
         fidx = ops.fps(xyz, self.stage.npoint)
         return fidx, ops.gather_xyz(xyz, fidx)
 
+    def can_split(self, B: int, N: int, M: int, feat: Optional[torch.Tensor] = None, feat_dtype=None) -> bool:
+        """Split pooling (include/sad_amd.h ``sad_mlp_bf16_args.cont``: bf16 pooled rows, plain stores, half the bytes between the
+        branches and the aggregation layer) applies: a bf16 stage with an aggregation layer on the row-streaming kernel and every
+        branch on the register-resident chain.  ``feat`` / ``feat_dtype`` as for ``query``."""
+        if self.dtype != "bf16" or self.agg is None or ops.AUTOTUNE or not ops.SPLIT_POOL:
+            return False
+        if self.cat_channels % 8 or any(m.out_channels % 16 for m in self.branches) or len(self.branches) > 4:
+            return False
+        if not self.agg.takes_pooled(B * M, self.agg.out_channels):
+            return False
+        if feat_dtype is None:
+            feat_dtype = torch.bfloat16
+        return all(mlp.preferred_geometry == 2 and mlp.wants_prescan(B, N, M, s, self.cat_channels, self.in_channels, feat=feat, feat_dtype=feat_dtype)
+                   for mlp, s in zip(self.branches, self.stage.nsamples))
+
+    def split_buffers(self, B: int, M: int, device):
+        """(cat [B,M,sum C_b] bfloat16, [continuation rows per branch]) of a split-pooled call, uninitialised."""
+        cat = ops._empty((B, M, self.cat_channels), dtype=torch.bfloat16, device=device)
+        conts = [ops.cont_buffer(B, M, s, mlp.out_channels, device) for mlp, s in zip(self.branches, self.stage.nsamples)]
+        return cat, conts
+
     def query(self, xyz: torch.Tensor, new_xyz: torch.Tensor, radius_pc: Optional[torch.Tensor] = None,
               radii: Optional[Sequence[float]] = None, prescan: bool = False, cat: Optional[torch.Tensor] = None,
-              feat: Optional[torch.Tensor] = None, feat_dtype=None):
+              feat: Optional[torch.Tensor] = None, feat_dtype=None, conts=None):
         """The stage's multi-radius ball query: ([idx_b [B,M,S_b]], [cnt_b [B,M]]) and, with ``prescan``,
         the row-packing tables of the branches as a third element.  ``cat`` (with ``prescan``): the stage's
         UNINITIALISED [B,M,sum C_b] pooling buffer — the scan prepares the slices of the branches that take a table
@@ -66,7 +87,8 @@ class SAModuleMSG(nn.Module):
         ``group_and_pool(cat=...)``.  ``feat``: the feature tensor ``group_and_pool`` will get (its stride and alignment
         decide which kernel runs, hence whether a table is wanted); when it does not exist yet (a caller that queries ahead
         on another stream) leave it None and it is taken to be a fresh contiguous [B,N,C] tensor of ``feat_dtype``
-        (default: float32, or bfloat16 for a bf16 module)."""
+        (default: float32, or bfloat16 for a bf16 module).  ``conts`` (with a bfloat16 ``cat``, both from ``split_buffers``): split
+        pooling — ask ``can_split`` first."""
         st = self.stage
         idxs, cnts = ops.ball_query_multi(radii if radii is not None else st.radii, st.nsamples, xyz, new_xyz,
                                           radius_pc, return_counts=True)
@@ -81,7 +103,14 @@ class SAModuleMSG(nn.Module):
                     if mlp.wants_prescan(B, N, M, s, self.cat_channels, self.in_channels, feat=feat, feat_dtype=feat_dtype)]
             wss = [None] * len(idxs)
             outs = None
-            if cat is not None:
+            if conts is not None:
+                if cat is None or cat.dtype != torch.bfloat16 or len(pick) != len(self.branches):
+                    raise RuntimeError("split pooling needs a bfloat16 cat and every branch on the register-resident chain (can_split)")
+                offs = [0]
+                for mlp in self.branches:
+                    offs.append(offs[-1] + mlp.out_channels)
+                outs = [(cat, offs[i], self.branches[i].out_channels, conts[i]) for i in pick]
+            elif cat is not None:
                 offs = [0]
                 for mlp in self.branches:
                     offs.append(offs[-1] + mlp.out_channels)
@@ -99,15 +128,18 @@ class SAModuleMSG(nn.Module):
     def group_and_pool(self, xyz: torch.Tensor, feat_pm: Optional[torch.Tensor],
                        new_xyz: torch.Tensor, radius_pc: Optional[torch.Tensor] = None,
                        radii: Optional[Sequence[float]] = None, keep: Optional[dict] = None,
-                       query=None, cat: Optional[torch.Tensor] = None) -> torch.Tensor:
+                       query=None, cat: Optional[torch.Tensor] = None, conts=None) -> torch.Tensor:
         """ball query + fused MLP/max for every branch + aggregation -> [B,M,C'] point-major.
         ``query`` = (idxs, cnts) from an earlier ``self.query(...)`` (the ball query needs coordinates
         only, so a caller may run it ahead on another stream)."""
         st = self.stage
         B, M = new_xyz.shape[0], new_xyz.shape[1]
+        if query is None and cat is None and self.can_split(B, xyz.shape[1], M, feat=feat_pm):
+            cat, conts = self.split_buffers(B, M, xyz.device)
         # (own query: with the row-packing scan behind it, as the detector's sampling stream does — the MLP dispatch is
         # then the same launches in every mode)
-        q = query if query is not None else self.query(xyz, new_xyz, radius_pc, radii, prescan=not ops.AUTOTUNE, feat=feat_pm)
+        q = query if query is not None else self.query(xyz, new_xyz, radius_pc, radii, prescan=not ops.AUTOTUNE, feat=feat_pm,
+                                                       cat=cat if conts is not None else None, conts=conts)
         idxs, cnts = q[0], q[1]
         wss = q[2] if len(q) > 2 else [None] * len(idxs)
         if keep is not None:
@@ -116,10 +148,13 @@ class SAModuleMSG(nn.Module):
             ops._unrecordable("group_and_pool: zero-filled pooling buffer")
             cat = torch.zeros((B, M, self.cat_channels), dtype=torch.float32, device=xyz.device)
         calls, off = [], 0               # all branches in one dispatch (ops.grouped_multi)
-        for mlp, idx, cnt, ws in zip(self.branches, idxs, cnts, wss):
-            calls.append((mlp, xyz, feat_pm, new_xyz, idx, cat, off, cnt, ws))
+        for bi, (mlp, idx, cnt, ws) in enumerate(zip(self.branches, idxs, cnts, wss)):
+            calls.append((mlp, xyz, feat_pm, new_xyz, idx, cat, off, cnt, ws) + ((conts[bi],) if conts is not None else ()))
             off += mlp.out_channels
         ops.grouped_multi(calls)
+        if conts is not None:        # split-pooled rows: the aggregation layer takes the maximum with the continuation rows as it reads
+            pool = [(ws, cont, s, mlp.out_channels) for ws, cont, s, mlp in zip(wss, conts, st.nsamples, self.branches)]
+            return self.agg.rows(cat, out_dtype=torch.bfloat16, pool=pool)
         if self.agg is None:
             return cat
         if self.dtype == "bf16":     # a stage output that feeds another stage is stored as bf16 (SPEC §14)

@@ -40,9 +40,10 @@ extern "C" {
 typedef void *sad_stream_t; /* hipStream_t */
 
 /* ABI version: bumped whenever a public struct layout or a signature changes (2 = sad_mlp_args / sad_mlp_bf16_args
- * start with struct_size; 3 = sad_mlp_args.c_out in the former tail padding, sad_mlp_padded_dims, sad_copy_rows_u32).  The structs additionally carry their own size: a caller built against another header is
+ * start with struct_size; 3 = sad_mlp_args.c_out in the former tail padding, sad_mlp_padded_dims, sad_copy_rows_u32;
+ * 4 = split pooling: sad_mlp_bf16_args.cont / n_pool / pool_*, sad_mlp_rowscan_split, sad_mlp_cont_bytes, larger row-packing tables).  The structs additionally carry their own size: a caller built against another header is
  * refused with SAD_EINVAL instead of being read past its end. */
-#define SAD_ABI_VERSION 3
+#define SAD_ABI_VERSION 4
 int sad_version(void);
 const char *sad_last_error(void);
 /* Tuning / A-B knobs (process-wide; defaults 0 = automatic).  Returns SAD_EINVAL for an unknown key.
@@ -329,7 +330,30 @@ typedef struct sad_mlp_bf16_args {
     int geometry;
     /* != 0: `workspace` already holds the row-packing table of (cnt, idx) from sad_mlp_rowscan (geometry 2 only) */
     int prescanned;
+    /* Split pooling (ABI 4; grouped mode, geometry 2, out_bf16 = 1): the pooled rows leave as bf16 with PLAIN stores and nothing
+     * needs a zero fill.  A group whose packed rows lie in several 32-row tiles (about one in eight) is not combined in memory:
+     * its rows in the tile where they begin pool into out[g], its rows in a later tile t into row t of `cont`
+     * (sad_mlp_cont_bytes() bytes, 16-byte aligned, row stride = dims[3] elements; row 0 is all zero).  The true pooled row is
+     * the element-wise maximum of the two or three — taken by the layer that reads them: a plain-mode call with n_pool > 0.
+     * Exact: rounding to bf16 is monotone, so max(bf16(a), bf16(b)) = bf16(max(a, b)), and every consumer of pooled rows
+     * rounds them to bf16 on load.  Needs dims[3], ld_out and col_off multiples of 8, `out` 16-byte aligned, and a table made
+     * by this call's own scan (prescanned = 0) or by sad_mlp_rowscan_split. */
+    void *cont;
+    /* plain mode, one layer (geometry 0 / 3), feat_bf16 = 1: the input rows are the split-pooled outputs of n_pool chains side
+     * by side — columns of width pool_cols[i] (multiples of 16, adding up to C) pooled by the chain with nsample pool_S[i],
+     * row-packing table pool_ws[i] and continuation rows pool_cont[i]; B * M = the chains' groups.  0 = ordinary rows. */
+    int n_pool;
+    const void *pool_ws[SAD_MAX_RADII];
+    const void *pool_cont[SAD_MAX_RADII];
+    int pool_S[SAD_MAX_RADII];
+    int pool_cols[SAD_MAX_RADII];
 } sad_mlp_bf16_args;
+/* bytes of the continuation-row buffer of a split-pooled chain with B * M groups of at most S rows and cout output channels */
+size_t sad_mlp_cont_bytes(int B, int M, int S, int cout);
+/* sad_mlp_rowscan for chains whose pooled output is split (sad_mlp_bf16_args.cont): also marks the continuation rows in the row
+ * map, records the first packed row of every group behind it and zeroes row 0 of cont[i] (cout[i] = the chain's output channels). */
+int sad_mlp_rowscan_split(int n, const int32_t *const *cnt, const int32_t *const *idx, const int *S, int B, int N,
+                          int M, void *const *workspace, void *const *cont, const int *cout, sad_stream_t stream);
 /* 2 when sad_mlp_chain_bf16 has a register-resident kernel for this grouped chain (dims[0] = C + 3), else 0 */
 int sad_mlp_preferred_geometry_bf16(int L, const int *dims);
 int sad_mlp_chain_bf16(const sad_mlp_bf16_args *args, sad_stream_t stream);

@@ -24,7 +24,7 @@ def test_header_symbols_exported(sad):
     for n in names:
         assert hasattr(handle, n), f"{n} declared in include/sad_amd.h but not exported"
     assert set(names) == set(_lib.SIGNATURES), "ctypes signature table out of sync with the header"
-    assert _lib.lib().sad_version() == _lib.ABI_VERSION == 3
+    assert _lib.lib().sad_version() == _lib.ABI_VERSION == 4
 
 
 def test_no_oracle_in_product_path():

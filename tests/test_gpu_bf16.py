@@ -450,3 +450,163 @@ def test_detector_bf16_overlapped_path_with_poisoned_pooling_buffers(sad, dev):
     for o in outs:
         assert torch.equal(o, ref), "overlapped bf16 path with uninitialised pooling buffers differs from the serial path"
 
+
+
+# ---- split pooling (include/sad_amd.h sad_mlp_bf16_args.cont, ABI 4) ------------------------------------------------------------------
+# A split-pooled chain stores bf16 rows with plain stores: a group's rows in the tile where its packed rows begin pool into out[g], its
+# rows in a later 32-row tile t into row t of the continuation buffer.  The same kernel arithmetic as the f32 / atomic-max form, and
+# rounding to bf16 is monotone, so   max(out[g], cont[t] ...) == bf16(f32-pooled[g])   BIT FOR BIT, and a layer that reads the pooled
+# rows (rows(pool=...)) must give the bits it gives on the f32 buffer.
+def _gstart_off(ng, S):
+    o = 4 + (ng + 1) + (ng * S // 32 + 2) + (ng // 1024 + 2) + 2 * ng * S
+    return (o + 3) & ~3
+
+
+SPLIT = [
+    # (B, N, M, S, C, mlp, fill)    fill: share of the nsample a group gets on average (1.0: every group full -> 64-row groups span three tiles)
+    (2, 2048, 512, 32, 1, [16, 16, 32], 0.15),
+    (2, 2048, 512, 64, 1, [32, 32, 64], 0.1),
+    (2, 1024, 256, 64, 64, [64, 96, 128], 1.0),
+    (2, 1024, 256, 32, 64, [64, 64, 128], 0.3),
+    (1, 512, 128, 32, 128, [128, 192, 256], 0.5),
+    (1, 512, 100, 16, 256, [256, 256, 512], 0.6),
+    (1, 512, 64, 32, 256, [256, 512, 1024], 1.0),
+    (1, 512, 37, 64, 0, [64, 64, 128], 0.05),
+]
+
+
+def _split_case(sad, dev, B, N, M, S, C, mlp, fill, seed=0):
+    import torch
+    from sad_amd import ops, synth
+    rng = np.random.default_rng(N + M + S + C + seed)
+    xyz = rng.random((B, N, 3), dtype=np.float32)
+    new_xyz = xyz[:, :M].copy()
+    idx = rng.integers(0, N, size=(B, M, S)).astype(np.int32)
+    cnt = np.clip(rng.poisson(fill * S, size=(B, M)), 1, S).astype(np.int32) if fill < 1.0 else np.full((B, M), S, np.int32)
+    if fill >= 1.0:
+        cnt[:, ::5] = 13                                 # (full groups off the tile grid: 64-row groups then span three tiles)
+    cnt[0, 0] = S
+    cnt[-1, -1] = 1
+    layers = synth.make_mlp_weights([C + 3] + mlp, rng)
+    m = ops.PackedMLPBf16(layers, True, dev)
+    feat = _t(rng.normal(size=(B, N, C)).astype(np.float32), dev).bfloat16() if C else None
+    return m, _t(xyz, dev), feat, _t(new_xyz, dev), _t(idx, dev), _t(cnt, dev), cnt
+
+
+@pytest.mark.parametrize("B,N,M,S,C,mlp,fill", SPLIT)
+def test_split_pooled_rows_are_the_f32_pooled_rows_rounded(sad, dev, B, N, M, S, C, mlp, fill):
+    import torch
+    from sad_amd import ops
+    m, xyz, feat, new_xyz, idx, cnt, cnt_h = _split_case(sad, dev, B, N, M, S, C, mlp, fill)
+    assert m.preferred_geometry == 2
+    co = mlp[-1]
+    ld, off = co + 24, 16                                # a slice of a wider buffer
+    want = torch.zeros((B, M, ld), device=dev)
+    m.grouped(xyz, feat, new_xyz, idx, out=want, col_off=off, cnt=cnt)
+    want = want[:, :, off:off + co].bfloat16().view(torch.int16).cpu().numpy().reshape(B * M, co)
+    out = torch.full((B, M, ld), -3.0, device=dev, dtype=torch.bfloat16)
+    cont = ops.cont_buffer(B, M, S, co, dev)
+    cont.fill_(0x7F)                                     # (poison: whatever is read must have been written)
+    m.grouped(xyz, feat, new_xyz, idx, out=out, col_off=off, cnt=cnt, cont=cont)        # (scans for itself: prescanned = 0)
+    # the same through an explicit split scan
+    out2 = torch.full((B, M, ld), -3.0, device=dev, dtype=torch.bfloat16)
+    cont2 = ops.cont_buffer(B, M, S, co, dev)
+    cont2.fill_(0x7F)
+    (ws2,) = ops.rowscan_multi([idx], [cnt], N, [(out2, off, co, cont2)])
+    m.grouped(xyz, feat, new_xyz, idx, out=out2, col_off=off, cnt=cnt, ws=ws2, cont=cont2)
+    torch.cuda.synchronize()
+    assert torch.equal(out, out2) and torch.equal(cont, cont2)
+    o = out.view(torch.int16).cpu().numpy().reshape(B * M, ld)
+    assert (out.float().cpu().numpy().reshape(B * M, ld)[:, :off] == -3).all() and (out.float().cpu().numpy().reshape(B * M, ld)[:, off + co:] == -3).all()
+    main = o[:, off:off + co].astype(np.int32)           # non-negative bf16: ordered like their bit patterns
+    ng = B * M
+    tab = ws2.view(torch.int32).cpu().numpy()
+    gs = tab[_gstart_off(ng, S):_gstart_off(ng, S) + ng + 1]
+    c = cnt_h.reshape(-1)
+    assert np.array_equal(np.diff(gs), c) and gs[0] == 0
+    ct = cont2.view(torch.int16).cpu().numpy().reshape(-1, co).astype(np.int32)
+    assert (ct[0] == 0).all()
+    full = main.copy()
+    t0, t1 = gs[:-1] >> 5, (gs[1:] - 1) >> 5
+    n_cont = t1 - t0
+    for k in (1, 2):
+        sel = n_cont >= k
+        full[sel] = np.maximum(full[sel], ct[t0[sel] + k])
+    assert n_cont.max() <= 2 and (n_cont > 0).any()
+    if fill >= 1.0 and S == 64:
+        assert (n_cont == 2).any()
+    assert np.array_equal(full.astype(np.int16), want), "split-pooled rows differ from the rounded f32-pooled rows"
+    # straddling groups really are split (the main row alone is not the answer)
+    assert not np.array_equal(main.astype(np.int16), want)
+
+
+@pytest.mark.parametrize("n_chain", [1, 3])
+def test_layer_reading_split_pooled_rows_equals_layer_on_f32_pooled_rows(sad, dev, n_chain):
+    """sa2-like stage: three branches into one [B,M,384] buffer, aggregation 384 -> 128, f32 pooling against split pooling; then the
+    same with full 64-row groups (second continuation rows) and a deep layer on the queued loop."""
+    import torch
+    from sad_amd import ops, synth
+    specs = [(32, [64, 64, 128], 0.3), (32, [64, 64, 128], 0.6), (64, [64, 96, 128], 1.0)][:n_chain]
+    B, N, M, C = 2, 2048, 640, 64
+    rng = np.random.default_rng(5 + n_chain)
+    cat_c = sum(s[1][-1] for s in specs)
+    agg = ops.PackedMLPBf16(synth.make_mlp_weights([cat_c, 128], rng), False, dev)
+    cat32 = torch.zeros((B, M, cat_c), device=dev)
+    cat16 = torch.full((B, M, cat_c), 9.0, device=dev, dtype=torch.bfloat16)
+    calls32, calls16, outs, idxs, cnts, conts, off = [], [], [], [], [], [], 0
+    for i, (S, mlp, fill) in enumerate(specs):
+        m, xyz, feat, new_xyz, idx, cnt, _ = _split_case(sad, dev, B, N, M, S, C, mlp, fill, seed=i)
+        cont = ops.cont_buffer(B, M, S, mlp[-1], dev)
+        cont.fill_(0x7F)
+        calls32.append((m, xyz, feat, new_xyz, idx, cat32, off, cnt))
+        calls16.append([m, xyz, feat, new_xyz, idx, cat16, off, cnt, None, cont])
+        outs.append((cat16, off, mlp[-1], cont))
+        idxs.append(idx); cnts.append(cnt); conts.append(cont)
+        off += mlp[-1]
+    for c in calls32:
+        c[0].grouped(*c[1:5], out=c[5], col_off=c[6], cnt=c[7])
+    wss = ops.rowscan_multi(idxs, cnts, N, outs)
+    for c, w in zip(calls16, wss):
+        c[8] = w
+    ops.grouped_multi([tuple(c) for c in calls16]) if n_chain > 1 else calls16[0][0].grouped(*calls16[0][1:5], out=cat16, col_off=0, cnt=cnts[0], ws=wss[0], cont=conts[0])
+    want = agg.rows(cat32, out_dtype=torch.bfloat16)
+    pool = [(w, k, s[0], s[1][-1]) for w, k, s in zip(wss, conts, specs)]
+    got = agg.rows(cat16, out_dtype=torch.bfloat16, pool=pool)
+    torch.cuda.synchronize()
+    assert torch.equal(got, want), f"max diff {(got.float() - want.float()).abs().max().item()}"
+    got32 = agg.rows(cat16, pool=pool)
+    assert torch.equal(got32, agg.rows(cat32))
+    # refused where it cannot run: a two-layer chain, f32 rows
+    two = ops.PackedMLPBf16(synth.make_mlp_weights([cat_c, 64, 32], rng), False, dev)
+    with pytest.raises(RuntimeError):
+        two.rows(cat16, pool=pool)
+
+
+@pytest.mark.parametrize("cfg_name", ["TINY", "KITTI"])
+def test_detector_bf16_split_pooling_changes_no_bit(sad, dev, cfg_name):
+    import torch
+    from sad_amd import config, ops, synth
+    from sad_amd.detector import SADDetector
+    cfg = getattr(config, cfg_name)
+    w = synth.make_weights(cfg, 0)
+    B = 3 if cfg_name == "TINY" else 4
+    pts = _t((synth.make_tiny_batch if cfg_name == "TINY" else synth.make_batch)(21, B, cfg.n_points), dev)
+    old = ops.SPLIT_POOL
+    try:
+        ops.SPLIT_POOL = False
+        ref_det = SADDetector(cfg, w, dev, dtype="bf16")
+        ref_det.use_plans = False
+        ref, ev = ref_det.submit(pts)
+        ev.synchronize()
+        ops.SPLIT_POOL = True
+        det = SADDetector(cfg, w, dev, dtype="bf16", streams=(ref_det._sides, ref_det._mains))
+        for i in range(det._plan_ring + 3):              # recorded and replayed steps
+            out, ev = det.submit(pts)
+        ev.synchronize()
+        assert det.plan_refused is None and det.plan_replays >= 3
+    finally:
+        ops.SPLIT_POOL = old
+    assert torch.equal(out, ref)
+    # the split path really ran: every stage with an aggregation layer and the cluster layer
+    n_in = [cfg.n_points] + [s.npoint for s in cfg.stages[:-1]]
+    assert all(m.can_split(B, n, m.stage.npoint, feat_dtype=torch.bfloat16 if i else torch.float32) for i, (m, n) in enumerate(zip(det.stages, n_in)))
