@@ -268,6 +268,20 @@ class SADDetector(nn.Module):
             out.append(cur)
         return out
 
+    def _cluster_tables(self, B: int) -> bool:
+        """Do both cluster branches run kernels that take a row-packing table (and prepare their pooling slice themselves)?"""
+        cfg = self.cfg
+        m3, cin = self.stages[-1].stage.npoint, self.stages[-1].out_channels
+        fdt = torch.bfloat16 if (self.dtype == "bf16" and self.stages[-1].agg is not None) else torch.float32
+        return all(mlp.wants_prescan(B, m3, cfg.n_cand, s_, self.cluster_cat, cin, feat_dtype=fdt)
+                   for mlp, s_ in zip(self.cluster_branches, cfg.cluster_nsamples))
+
+    def _cluster_can_split(self, B: int) -> bool:
+        """Split pooling for the cluster layer (sa_module.can_split has the rule for the SA stages)."""
+        return (self.dtype == "bf16" and ops.SPLIT_POOL and not ops.AUTOTUNE and self.agg_head is None and self._cluster_tables(B)
+                and all(mlp.preferred_geometry == 2 and mlp.out_channels % 16 == 0 for mlp in self.cluster_branches)
+                and self.cluster_agg.takes_pooled(B * self.cfg.n_cand, self.cluster_agg.out_channels))
+
     def forward(self, points: torch.Tensor, trace: Optional[dict] = None,
                 input_ready: bool = False, ready=None) -> torch.Tensor:
         """points [B,N,3+in_feat] f32 on the GPU -> boxes [B,K,9].
@@ -341,13 +355,8 @@ class SADDetector(nn.Module):
                     prev_agg = si > 0 and self.stages[si - 1].agg is not None
                     splits.append(split_ok and m.can_split(B, n_in[si], m.stage.npoint, feat=feat if si == 0 else None,
                                                            feat_dtype=torch.bfloat16 if prev_agg else torch.float32))
-                m3, cin = self.stages[-1].stage.npoint, self.stages[-1].out_channels
-                fdt = torch.bfloat16 if (self.dtype == "bf16" and self.stages[-1].agg is not None) else torch.float32
-                cluster_tables = all(mlp.wants_prescan(B, m3, cfg.n_cand, s_, self.cluster_cat, cin, feat_dtype=fdt)
-                                     for mlp, s_ in zip(self.cluster_branches, cfg.cluster_nsamples))
-                splits.append(split_ok and ops.SPLIT_POOL and cluster_tables and self.agg_head is None
-                              and all(mlp.preferred_geometry == 2 and mlp.out_channels % 16 == 0 for mlp in self.cluster_branches)
-                              and self.cluster_agg.takes_pooled(B * cfg.n_cand, self.cluster_agg.out_channels))
+                cluster_tables = self._cluster_tables(B)
+                splits.append(split_ok and self._cluster_can_split(B))
                 shapes = [(B, m.stage.npoint, m.cat_channels) for m in self.stages]
                 shapes.append((B, cfg.n_cand, self.cluster_cat))
                 if not prep:
@@ -441,11 +450,14 @@ class SADDetector(nn.Module):
         idxs, cnts = ops.ball_query_multi(cfg.cluster_scales, cfg.cluster_nsamples, cur_xyz, cand, rad,
                                           return_counts=True)
         cat = cats[-1]
+        ckont = conts[-1]
+        if cat is None and trace is None and not ops.AUTOTUNE and self._cluster_can_split(B):     # (the serial path: no buffers were prepared)
+            cat = ops._empty((B, K, self.cluster_cat), dtype=torch.bfloat16, device=points.device)
+            ckont = [ops.cont_buffer(B, K, s_, mlp.out_channels, points.device) for mlp, s_ in zip(self.cluster_branches, cfg.cluster_nsamples)]
         if cat is None:
             ops._unrecordable("zero-filled cluster pooling buffer")
             cat = torch.zeros((B, K, self.cluster_cat), dtype=torch.float32, device=points.device)
         calls, off = [], 0
-        ckont = conts[-1]
         if ckont is not None:
             # split pooling: the tables come from an explicit scan (the same two launches the dispatch would make itself), the aggregation
             # layer needs them beside the continuation rows
@@ -461,13 +473,15 @@ class SADDetector(nn.Module):
         # ---- head + decode (SPEC.md §9) -------------------------------------------------------
         if ckont is not None:
             pool = [(w_, k_, s_, mlp.out_channels) for w_, k_, s_, mlp in zip(cwss, ckont, cfg.cluster_nsamples, self.cluster_branches)]
-            cfeat = self.cluster_agg.rows(cat, pool=pool)
+            # (cluster features as bf16: the head rounds its input to bf16 on load, so storing them rounded changes no bit and halves their bytes)
+            cfeat = self.cluster_agg.rows(cat, out_dtype=torch.bfloat16, pool=pool)
             o = self.head.rows(cfeat)                                    # [B,K,10]
         elif self.agg_head is not None and trace is None:
             cfeat = None
             o = self.agg_head.rows(cat)                                  # [B,K,10]
         else:
-            cfeat = self.cluster_agg.rows(cat)
+            cfeat = (self.cluster_agg.rows(cat, out_dtype=torch.bfloat16) if (self.dtype == "bf16" and trace is None)     # (as above)
+                     else self.cluster_agg.rows(cat))
             o = self.head.rows(cfeat)                                    # [B,K,10]
         boxes = ops._empty((B, K, 9), dtype=torch.float32, device=points.device)
         check(lib().sad_decode_boxes_f32(cand.data_ptr(), o.data_ptr(), B, K, self._anchors,

@@ -582,15 +582,16 @@ def test_layer_reading_split_pooled_rows_equals_layer_on_f32_pooled_rows(sad, de
         two.rows(cat16, pool=pool)
 
 
-@pytest.mark.parametrize("cfg_name", ["TINY", "KITTI"])
+@pytest.mark.parametrize("cfg_name", ["TINY", "KITTI", "NUSCENES"])
 def test_detector_bf16_split_pooling_changes_no_bit(sad, dev, cfg_name):
     import torch
     from sad_amd import config, ops, synth
     from sad_amd.detector import SADDetector
     cfg = getattr(config, cfg_name)
     w = synth.make_weights(cfg, 0)
-    B = 3 if cfg_name == "TINY" else 4
-    pts = _t((synth.make_tiny_batch if cfg_name == "TINY" else synth.make_batch)(21, B, cfg.n_points), dev)
+    B = {"TINY": 3, "KITTI": 4, "NUSCENES": 2}[cfg_name]
+    make = {"TINY": synth.make_tiny_batch, "KITTI": synth.make_batch, "NUSCENES": synth.make_nuscenes_batch}[cfg_name]
+    pts = _t(make(21, B, cfg.n_points), dev)
     old = ops.SPLIT_POOL
     try:
         ops.SPLIT_POOL = False
