@@ -40,6 +40,7 @@ SAD_API int sad_set_option(const char *key, int value) {
     // test knobs of the cooperative chain kernel's item queues (csrc/mlp_coop.hip, include/sad_amd.h)
     if (!strcmp(key, "mlp_steal_after")) { sad::g_opt[sad::OPT_MLP_STEAL_AFTER].store(value, std::memory_order_relaxed); return SAD_OK; }
     if (!strcmp(key, "mlp_layer_queue")) { sad::g_opt[sad::OPT_MLP_LAYER_QUEUE].store(value, std::memory_order_relaxed); return SAD_OK; }
+    if (!strcmp(key, "mlp_rows_form")) { sad::g_opt[sad::OPT_MLP_ROWS_FORM].store(value, std::memory_order_relaxed); return SAD_OK; }
     if (!strcmp(key, "mlp_check_inuse")) { sad::g_opt[sad::OPT_MLP_CHECK_INUSE].store(value, std::memory_order_relaxed); return SAD_OK; }
     if (!strcmp(key, "group_variant")) { sad::g_opt[sad::OPT_GROUP_VARIANT].store(value, std::memory_order_relaxed); return SAD_OK; }   // 1 = L2-gather kernel only
     if (!strcmp(key, "bq_variant")) { sad::g_opt[sad::OPT_BQ_VARIANT].store(value, std::memory_order_relaxed); return SAD_OK; }

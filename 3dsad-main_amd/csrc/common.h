@@ -167,7 +167,7 @@ int bfreg_family(int shape);
 long long bfreg_stream_frags(int shape);           // 1-KB fragments of the stream image (whole stages)
 int bfreg_pack(int shape, const int *dims, int first_has_xyz, const float *const *W, void *dst, hipStream_t st);
 int launch_bfreg(const BfRegMulti &mp, hipStream_t st);
-enum { OPT_FPS_DPP = 0, OPT_MLP_RW = 1, OPT_MLP_BUDGET_KB = 2, OPT_BQ_VARIANT = 3, OPT_FPS_VARIANT = 4, OPT_MLP_FORCE = 5, OPT_MLP_DEDUP_F = 6, OPT_MLP_NODEDUP = 7, OPT_FPS_THREADS = 8, OPT_MLP_STATIC = 9, OPT_GROUP_VARIANT = 10, OPT_MLP_DYN_SLOTS = 11, OPT_MLP_NOXCD = 12, OPT_MLP_STEAL_AFTER = 13, OPT_MLP_CHECK_INUSE = 14, OPT_MLP_LAYER_QUEUE = 15, OPT_COUNT };
+enum { OPT_FPS_DPP = 0, OPT_MLP_RW = 1, OPT_MLP_BUDGET_KB = 2, OPT_BQ_VARIANT = 3, OPT_FPS_VARIANT = 4, OPT_MLP_FORCE = 5, OPT_MLP_DEDUP_F = 6, OPT_MLP_NODEDUP = 7, OPT_FPS_THREADS = 8, OPT_MLP_STATIC = 9, OPT_GROUP_VARIANT = 10, OPT_MLP_DYN_SLOTS = 11, OPT_MLP_NOXCD = 12, OPT_MLP_STEAL_AFTER = 13, OPT_MLP_CHECK_INUSE = 14, OPT_MLP_LAYER_QUEUE = 15, OPT_MLP_ROWS_FORM = 16, OPT_COUNT };
 
 inline int fail(int code, const char *fmt, ...) {
     char buf[480];

@@ -62,6 +62,9 @@ const char *sad_last_error(void);
  *                launching stream instead of a static round-robin.  Beside an FPS kernel of another stream the cluster
  *                dispatch of the benchmark is 15 % shorter (905 vs 1 080 us), alone 2 % longer, and the pipelined step
  *                (two main streams always busy) 1.5 % slower: off by default.  Same results either way.
+ *   mlp_rows_form 1 = the bf16 row-streaming layer (sad_mlp_chain_bf16, one plain layer) always in its first form (rows straight to
+ *                registers, register-staged weights) instead of the tiled GEMM fed by LDS-DMA that serves bf16 rows with
+ *                K % 64 == 0.  Same results either way (the same products in the same order).
  * Test knobs of the item queues of the cooperative chain kernel (geometry 4; tables of >= 257 groups):
  *   mlp_steal_after v > 0: a workgroup treats the queue of its own XCD as empty after v - 1 items and takes its items from
  *                the other queues, one at a time and with nothing prefetched, so the cross-queue / weight-ring refill

@@ -611,3 +611,43 @@ def test_detector_bf16_split_pooling_changes_no_bit(sad, dev, cfg_name):
     # the split path really ran: every stage with an aggregation layer and the cluster layer
     n_in = [cfg.n_points] + [s.npoint for s in cfg.stages[:-1]]
     assert all(m.can_split(B, n, m.stage.npoint, feat_dtype=torch.bfloat16 if i else torch.float32) for i, (m, n) in enumerate(zip(det.stages, n_in)))
+
+
+# ---- the row-streaming layer's second form (csrc/mlp_bf16_rows.hip: a tiled GEMM fed by LDS-DMA) --------------------------------------
+# Serves bf16 rows whose K is a multiple of 64; the same products in the same k order per accumulator as the first form, so the two must
+# agree BIT FOR BIT (sad_set_option("mlp_rows_form", 1) forces the first form).
+ROWS2 = [
+    (1000, [128, 64]),          # two chunks, two channel tiles (NTW = 1), ragged last row block
+    (8192, [1536, 512]),        # cluster.agg: 24 chunks, four channel blocks
+    (16384, [768, 256]),        # sa3.agg
+    (130, [384, 128]),          # two row blocks, the second nearly empty
+    (4099, [64, 96]),           # ONE chunk; three channel tiles: a ragged channel block
+    (257, [192, 40]),           # cout not a multiple of 32
+    (70000, [128, 64]),         # more row blocks than two rounds of the chip
+]
+
+
+@pytest.mark.parametrize("rows,dims", ROWS2)
+def test_rows_bf16_second_form_equals_first_form(orc, sad, dev, rows, dims):
+    import torch
+    from sad_amd import _lib, ops, synth
+    rng = np.random.default_rng(rows + sum(dims))
+    layers = synth.make_mlp_weights(dims, rng)
+    x = _t(rng.normal(size=(rows, dims[0])).astype(np.float32), dev).bfloat16()
+    mlp = ops.PackedMLPBf16(layers, False, dev)
+    try:
+        _lib.set_option("mlp_rows_form", 1)
+        want32 = mlp.rows(x)
+        want16 = mlp.rows(x, out_dtype=torch.bfloat16)
+        torch.cuda.synchronize()
+    finally:
+        _lib.set_option("mlp_rows_form", 0)
+    got32 = mlp.rows(x)
+    got16 = mlp.rows(x, out_dtype=torch.bfloat16)
+    buf = torch.full((rows, dims[-1] + 24), -7.0, device=dev, dtype=torch.bfloat16)
+    mlp.rows(x, out=buf, col_off=8)
+    torch.cuda.synchronize()
+    assert torch.equal(got32, want32), f"f32 out: max diff {(got32 - want32).abs().max().item()}"
+    assert torch.equal(got16, want16)
+    assert torch.equal(buf[:, 8:8 + dims[-1]], want16) and (buf[:, :8] == -7).all() and (buf[:, 8 + dims[-1]:] == -7).all()
+    _close(got32.cpu().numpy(), orc.mlp_rows_bf16(x.float().cpu().numpy(), layers), f"rows2 {dims} x {rows}")

@@ -1,0 +1,31 @@
+"""The row-streaming bf16 layer alone, first form against second (sad_set_option mlp_rows_form), plain bf16 rows, back to back launches:
+    python tools/probe/rows_forms_time.py            (the aggregation layers of 32 KITTI- and nuScenes-shaped scenes)"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import numpy as np, torch
+import sad_amd
+from sad_amd import _lib, ops, synth
+dev = torch.device("cuda:0")
+shapes = [("sa1.agg", 131072, 128, 64), ("sa2.agg", 32768, 384, 128), ("sa3.agg", 16384, 768, 256), ("cluster.agg", 8192, 1536, 512),
+          ("nus sa1.agg", 524288, 128, 64), ("nus sa2.agg", 131072, 384, 128), ("nus sa3.agg", 65536, 768, 256), ("nus cluster.agg", 32768, 1536, 512)]
+rng = np.random.default_rng(0)
+for name, R, K, CO in shapes:
+    mlp = ops.PackedMLPBf16(synth.make_mlp_weights([K, CO], rng), False, dev)
+    x = torch.randn((R, K), device=dev).bfloat16()
+    out = torch.empty((R, CO), device=dev, dtype=torch.bfloat16)
+    res = []
+    for form in (1, 0):
+        _lib.set_option("mlp_rows_form", form)
+        for _ in range(3): mlp.rows(x, out=out)
+        torch.cuda.synchronize()
+        best = 1e9
+        for _ in range(3):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10): mlp.rows(x, out=out)
+            e1.record(); torch.cuda.synchronize()
+            best = min(best, e0.elapsed_time(e1) * 100)
+        res.append(best)
+    _lib.set_option("mlp_rows_form", 0)
+    gb = (R * K * 2 + R * CO * 2) / 1e9
+    print(f"{name:16s} {R:7d} x {K:5d} -> {CO:4d}: first form {res[0]:6.1f} us, second {res[1]:6.1f} us ({gb / res[1] * 1e6 / 1e3:.2f} TB/s, {2 * R * K * CO / res[1] / 1e6:.0f} TFLOP/s)")
