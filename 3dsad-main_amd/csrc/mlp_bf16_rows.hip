@@ -442,6 +442,21 @@ __global__ __launch_bounds__(512) void bf16_rows2_kernel(const BfRowsJob jb) {
     }
     // split-pooled rows: byte offset of the first continuation row of this lane's two DMA rows in the buffer of chain i (0: the zero
     // row), and of the SECOND continuation row of the row this lane multiplies (rare; 0: none)
+    const int drow0 = 8 * wave + (lane >> 3), drow1 = drow0 + 64;              // the tile rows of this lane's two DMA pieces
+    auto issue_wx = [&](int c) __attribute__((always_inline)) {   // the DMA of chunk c into stage c % 3: weight fragments and row tile
+        const unsigned st = lds0 + (unsigned)(c % 3) * SB;
+#if !defined(SAD_ROWS2_WHATIF) || (SAD_ROWS2_WHATIF != 2 && SAD_ROWS2_WHATIF != 3)      // (measurement builds: 1 = no row tile, 2 = no weights, 3 = neither — wrong results, what the bytes cost)
+#pragma unroll
+        for (int i = 0; i < PW; ++i) glds16(wsrc[i] + (size_t)c * (KC * 1024), st + wdst[i]);
+#endif
+#if !defined(SAD_ROWS2_WHATIF) || (SAD_ROWS2_WHATIF != 1 && SAD_ROWS2_WHATIF != 3)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) glds16(xsrc[i] + (size_t)c * 128, st + xdst[i]);
+#endif
+    };
+    // the first two chunks' weights and rows are on their way before anything below waits for memory (the continuation tables, the bias)
+    issue_wx(0);
+    if (NC > 1) issue_wx(1);
     // split-pooled rows: per chain and tile row, the byte offset of the FIRST continuation row in the chain's buffer (0: the zero row) and of
     // the SECOND (0: none; rare), the chains' buffers and first columns — tables in LDS behind the ring, read by chain index per chunk
     // (as selects over per-lane registers the compiler built these tables itself, in scratch)
@@ -475,18 +490,9 @@ __global__ __launch_bounds__(512) void bf16_rows2_kernel(const BfRowsJob jb) {
         }
         __syncthreads();
     }
-    const int drow0 = 8 * wave + (lane >> 3), drow1 = drow0 + 64;              // the tile rows of this lane's two DMA pieces
-    auto issue = [&](int c) __attribute__((always_inline)) {      // the DMA of chunk c into stage c % 3
-        const unsigned st = lds0 + (unsigned)(c % 3) * SB;
-#if !defined(SAD_ROWS2_WHATIF) || (SAD_ROWS2_WHATIF != 2 && SAD_ROWS2_WHATIF != 3)      // (measurement builds: 1 = no row tile, 2 = no weights, 3 = neither — wrong results, what the bytes cost)
-#pragma unroll
-        for (int i = 0; i < PW; ++i) glds16(wsrc[i] + (size_t)c * (KC * 1024), st + wdst[i]);
-#endif
-#if !defined(SAD_ROWS2_WHATIF) || (SAD_ROWS2_WHATIF != 1 && SAD_ROWS2_WHATIF != 3)
-#pragma unroll
-        for (int i = 0; i < 2; ++i) glds16(xsrc[i] + (size_t)c * 128, st + xdst[i]);
-#endif
+    auto issue_c = [&](int c) __attribute__((always_inline)) {    // ... and the continuation tile (needs the tables)
         if constexpr (XCONT) {
+            const unsigned st = lds0 + (unsigned)(c % 3) * SB;
             // the chain behind this lane's eight columns (column ranges are multiples of 16: a 16-byte piece lies behind one chain)
             const int kl = 64 * c + 8 * ((lane & 7) ^ (lane >> 3));
             const int ci = (kl >= pk1) + (kl >= pk2) + (kl >= pk3);
@@ -515,8 +521,9 @@ __global__ __launch_bounds__(512) void bf16_rows2_kernel(const BfRowsJob jb) {
 #pragma unroll
     for (int j = 0; j < NTW; ++j) asm volatile("" : "+v"(acc[j]));
     // ---- the ring ------------------------------------------------------------------------------------------------------------------
-    issue(0);
-    if (NC > 1) { issue(1); wait_vm<PV>(); } else wait_vm<0>();
+    // (in issue order the wait below leaves only chunk 1's continuation pieces — or, without them, all of chunk 1 — in flight)
+    issue_c(0);
+    if (NC > 1) { issue_c(1); wait_vm<XCONT ? 2 : PV>(); } else wait_vm<0>();
     __syncthreads();                                   // (s_waitcnt lgkmcnt(0) + s_barrier: the compiler knows of no vector-memory operation in flight)
     const int xrow = rw * 32 + r;                       // this lane's row of the tile
     const unsigned xoff = WB + xrow * 128, xsw = (unsigned)(xrow & 7);
@@ -525,7 +532,7 @@ __global__ __launch_bounds__(512) void bf16_rows2_kernel(const BfRowsJob jb) {
         SAD_RSTAMP(ta);
         // (the two waves of a SIMD — w and w + 4 — taking turns, one issuing its DMA while the other multiplies, was measured: no faster, the
         // largest layers 7 - 12 % slower)
-        if (c + 2 < NC) issue(c + 2);
+        if (c + 2 < NC) { issue_wx(c + 2); issue_c(c + 2); }
         SAD_RSTAMP(tb);
         const unsigned char *st = smem2 + (c % 3) * SB;
         // the chunk's four B fragments first (row r of the tile, columns 2 s + h), then the weight fragments one k-step ahead of their MFMAs

@@ -14,7 +14,7 @@ for key, cs in agg.items():
     rows.append((key, {k: sum(v) / len(v) for k, v in cs.items()}, len(next(iter(cs.values())))))
 rows.sort(key=lambda t: -t[1].get("SQ_BUSY_CYCLES", t[1].get("FETCH_SIZE", 0)))
 for key, c, n in rows:
-    if not any(k in key[0] for k in ("mlp_chain", "mlp_multi", "mlp_reg", "mlp_coop", "mlp_layer", "mlp_bf16", "rowscan", "ball_query", "grid_query", "fps_", "group")):
+    if not any(k in key[0] for k in ("mlp_chain", "mlp_multi", "mlp_reg", "mlp_coop", "mlp_layer", "mlp_bf16", "bf16_rows", "rowscan", "ball_query", "grid_query", "fps_", "group")):
         continue
     print(f"{key[0]} grid={key[1]} lds={key[2]} dispatches={n}")
     for k in sorted(c):

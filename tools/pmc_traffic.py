@@ -4,7 +4,7 @@ Units and corrections as /opt/skills/guides/MI355X_MICROARCH.md prescribes: both
 import csv, glob, json, os, sys
 root, out = sys.argv[1], sys.argv[2]
 def is_mlp(n):      # every MLP kernel of either arithmetic + the row-packing scans (not the one-off weight packing)
-    return ("mlp_" in n or "bf16_rows_kernel" in n or "rowscan_" in n) and "pack_kernel" not in n
+    return ("mlp_" in n or "bf16_rows_kernel" in n or "bf16_rows2_kernel" in n or "rowscan_" in n) and "pack_kernel" not in n
 def total(passname, counter):
     tot, steps = 0.0, 0
     for f in glob.glob(os.path.join(root, passname, "*", "*_counter_collection.csv")) + glob.glob(os.path.join(root, "pmc_" + passname, "*", "*_counter_collection.csv")):

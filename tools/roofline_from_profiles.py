@@ -34,7 +34,7 @@ def main():
     allk = [(short(r["Kernel_Name"]), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3) for r in rows]
     ks = []
     for i, (n, d) in enumerate(allk):
-        if n.startswith("bf16_rows_kernel"):       # (the plain-row layer of the bf16 mode: an MLP kernel like the mlp_* ones)
+        if n.startswith(("bf16_rows_kernel", "bf16_rows2_kernel")):       # (the plain-row layer of the bf16 mode, both forms: an MLP kernel like the mlp_* ones)
             n = "mlp_" + n
         if n == "mlp_pack_kernel" or not n.startswith(("mlp_", "rowscan_")):
             continue
