@@ -40,8 +40,11 @@ using sad::GID_MASK;
 #ifndef SAD_BR_PFD
 #define SAD_BR_PFD 4
 #endif
+#ifndef SAD_BR_DMA
+#define SAD_BR_DMA 1     // the weight ring is filled by LDS-DMA (global_load_lds_dwordx4), three stages ahead; 0 = through registers, two ahead
+#endif
 constexpr int RS = SAD_BR_RS;        // fragments (1 KB each) per ring stage
-constexpr int RNS = 3;               // ring slots: being read / complete / being written
+constexpr int RNS = SAD_BR_DMA ? 4 : 3;      // ring slots: being read / complete / (DMA: in flight) / being written
 constexpr int RING_F4 = RNS * RS * 64;
 constexpr int PFD_DEFAULT = SAD_BR_PFD;   // ring reads run this many fragments ahead of the MFMA that consumes them
 #ifndef SAD_BR_F2
@@ -64,6 +67,15 @@ __host__ __device__ constexpr int pfd_of(int family) { return family == 2 ? SAD_
 // instruction rate.
 constexpr int STAGE_F = 1024;        // floats of pooled-output staging per wave
 __host__ __device__ constexpr int stage_cb(int no2) { return no2 * 32 < 128 ? no2 * 32 : 128; }
+
+// One wave-wide 16-byte LDS-DMA (1 KB lands at lds_dst + 16 * lane; cdna_hip_programming.md: M0 carries the LDS address and is the compiler's,
+// so it is saved and restored in the statement that uses it).  The compiler keeps no count of these loads: they are retired by wait_vm.
+__device__ __forceinline__ void glds16(const void *gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(__builtin_amdgcn_readfirstlane(lds_dst)));
+}
+template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N)); }
 
 __device__ __forceinline__ void atomic_max_pos(float *addr, float v) {
     atomicMax(reinterpret_cast<unsigned *>(addr), __builtin_bit_cast(unsigned, v));
@@ -204,6 +216,16 @@ __device__ __forceinline__ void br_tile(const BfRegChain &c, const int tile, con
     const unsigned ulane = (unsigned)lane;
     auto stage_begin = [&]() {
         if constexpr (STATICW) return;
+#if SAD_BR_DMA
+        // this wave's fragments of stage srel + 3 (the last three stages of an item: the first three of the next) straight into the slot
+        // that was read in the previous stage — every wave has passed that stage's barrier behind its reads
+        const int s3 = srel + 3;
+        const float4 *sp = s3 < NSTG ? sbase + (size_t)(s3 * RS + FPW * wave) * 64 : nbase + (size_t)((s3 - NSTG) * RS + FPW * wave) * 64;
+        const int ws = slot + 3 >= RNS ? slot + 3 - RNS : slot + 3;
+        const unsigned dst = (unsigned)(size_t)ring + (unsigned)(ws * RS + FPW * wave) * 1024u;
+#pragma unroll
+        for (int e = 0; e < FPW; ++e) glds16(sp + e * 64 + ulane, dst + e * 1024u);
+#else
         const int s2 = srel + 2;
         const float4 *sp = s2 < NSTG ? sbase + (size_t)(s2 * RS + FPW * wave) * 64 : nbase + (size_t)((s2 - NSTG) * RS + FPW * wave) * 64;
         T0 = sp[ulane];
@@ -212,9 +234,18 @@ __device__ __forceinline__ void br_tile(const BfRegChain &c, const int tile, con
             T2 = (sp + 128)[ulane];
             T3 = (sp + 192)[ulane];
         }
+#endif
     };
     auto stage_end = [&]() {
         if constexpr (STATICW) return;
+#if SAD_BR_DMA
+        // retire the DMA issued one stage ago (stage srel + 2: the next stage reads ahead into it), leave this stage's in flight; anything
+        // else this wave has in the queue behind it (gather loads, pooled-row stores) only makes the wait longer, never shorter
+        wait_vm<FPW>();
+        __syncthreads();                            // (lgkmcnt(0) + s_barrier: the compiler knows of no DMA)
+        slot = slot + 1 == RNS ? 0 : slot + 1;
+        ++srel;
+#else
         const int ws = slot + 2 >= RNS ? slot + 2 - RNS : slot + 2;
         float4 *wp = ring + (ws * RS + FPW * wave) * 64 + lane;
         wp[0] = T0;
@@ -226,6 +257,7 @@ __device__ __forceinline__ void br_tile(const BfRegChain &c, const int tile, con
         __syncthreads();
         slot = slot + 1 == RNS ? 0 : slot + 1;
         ++srel;
+#endif
     };
     // fragment at position pp of this tile's stream, read while position p0 is being consumed (pp >= p0)
     auto frag_at = [&](int pp, int p0) -> float4 {
@@ -536,12 +568,20 @@ __global__ __launch_bounds__(BR_NW * 64, FAMILY == 0 ? 4 : (FAMILY == 1 ? 3 : (F
             for (int i = tid; i < n4; i += NW * 64) ring[wo + i] = sp[i];
             wo += n4;
         }
-    } else if (item < nitems) {   // prologue: stages 0 and 1 of the first item
+    } else if (item < nitems) {   // prologue: stages 0 and 1 of the first item (DMA: 0, 1 and 2)
         const float4 *sp = stream_of(item) + (size_t)(FPW * wave) * 64;
+#if SAD_BR_DMA
+#pragma unroll
+        for (int s = 0; s < 3; ++s)
+#pragma unroll
+            for (int e = 0; e < FPW; ++e) glds16(sp + (size_t)(s * RS + e) * 64 + ulane, (unsigned)(size_t)ring + (unsigned)(s * RS + FPW * wave + e) * 1024u);
+        wait_vm<0>();
+#else
 #pragma unroll
         for (int s = 0; s < 2; ++s)
 #pragma unroll
             for (int e = 0; e < FPW; ++e) ring[(s * RS + FPW * wave + e) * 64 + lane] = (sp + (size_t)(s * RS + e) * 64)[ulane];
+#endif
     }
     __syncthreads();                                // (also: the biases are in place)
     Ring rs{ring, 0};
@@ -568,6 +608,9 @@ __global__ __launch_bounds__(BR_NW * 64, FAMILY == 0 ? 4 : (FAMILY == 1 ? 3 : (F
         run_br<FAMILY, NW, SPLIT>(mp.c[ci], mp.shape[ci], tile_of(item, ci), sbias + (ci == 0 ? 0 : (ci == 1 ? b1 : b2)), lane, wave, rs,
                            stream_of(item), stream_of(nit), stage, total_of(ci), rows, mp.c[nci], tile_of(nit, nci), total_of(nci));
     }
+#if SAD_BR_DMA
+    if constexpr (!STATICW) wait_vm<0>();             // (no DMA may land in this workgroup's LDS after it has gone)
+#endif
 #ifdef SAD_BR_STAMPS
     if (blockIdx.x < 256 && lane == 0) {
         g_brst[(blockIdx.x * 4 + wave) * 16 + 12] = __builtin_amdgcn_s_memtime() - tk0;
