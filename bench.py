@@ -565,6 +565,8 @@ def measure(w: Workload, steps: int, warmup: int, rank: int, world: int, dev, ar
                    "step_plans": {"enabled": bool(getattr(det, "use_plans", False)), "ring_slots": getattr(det, "_plan_ring", None),
                                   "priming_steps_before_warmup": primed, "replays": getattr(det, "plan_replays", None),
                                   "refused": getattr(det, "plan_refused", None)},
+                   # (bf16 mode: pooled rows as bf16 + continuation rows, which stages took it — DESIGN.md 3.4; f32: n/a)
+                   "split_pooling": split_pooling_state(det, B),
                    "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"), "gpu_max_hw_queues_at_process_start": HW_QUEUES_AT_START,
                    "mlp_geometry": tuned if tuned else "heuristic", "mlp_geometry_source": geometry_source,
                    "mlp_geometry_hash": geom_hash},
@@ -939,6 +941,21 @@ def pipeline_leg(args, dev, geometry, headline_value: float, rank: int, world: i
     return rec
 
 
+def split_pooling_state(det, B: int):
+    """Which stages of a bf16 detector pool split (None for f32 or a detector without the hooks): the SA stages, then the cluster layer."""
+    if getattr(det, "dtype", "f32") != "bf16" or not hasattr(det, "_cluster_can_split"):
+        return None
+    import torch
+    cfg = det.cfg
+    n_in = [cfg.n_points] + [st.npoint for st in cfg.stages[:-1]]
+    out = []
+    for si, m in enumerate(det.stages):
+        prev_agg = si > 0 and det.stages[si - 1].agg is not None
+        out.append(bool(m.can_split(B, n_in[si], m.stage.npoint, feat_dtype=torch.bfloat16 if prev_agg else torch.float32)))
+    out.append(bool(det._cluster_can_split(B)))
+    return out
+
+
 def leg_record(res: dict) -> dict:
     """The part of a measurement that a secondary leg reports inside the headline line."""
     out = {k: res[k] for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype") if k in res}
@@ -946,6 +963,7 @@ def leg_record(res: dict) -> dict:
     # (which kernels ran and whether the steps were replayed: a tiled pick for one chain turns the plans off and costs 7 - 8 %)
     out["mlp_geometry"] = res["config"].get("mlp_geometry")
     out["step_plans"] = res["config"].get("step_plans")
+    out["split_pooling"] = res["config"].get("split_pooling")
     out["fps_streams"] = res["config"]["fps_streams"]
     out["scenes_per_gpu"] = res["config"]["scenes_per_gpu"]
     if "step_ms" in res:
