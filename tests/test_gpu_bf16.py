@@ -540,14 +540,14 @@ def test_split_pooled_rows_are_the_f32_pooled_rows_rounded(sad, dev, B, N, M, S,
     assert not np.array_equal(main.astype(np.int16), want)
 
 
-@pytest.mark.parametrize("n_chain", [1, 3])
+@pytest.mark.parametrize("n_chain", [1, 3, 4])
 def test_layer_reading_split_pooled_rows_equals_layer_on_f32_pooled_rows(sad, dev, n_chain):
     """sa2-like stage: three branches into one [B,M,384] buffer, aggregation 384 -> 128, f32 pooling against split pooling; then the
     same with full 64-row groups (second continuation rows) and a deep layer on the queued loop."""
     import torch
     from sad_amd import ops, synth
-    specs = [(32, [64, 64, 128], 0.3), (32, [64, 64, 128], 0.6), (64, [64, 96, 128], 1.0)][:n_chain]
-    B, N, M, C = 2, 2048, 640, 64
+    specs = [(32, [64, 64, 128], 0.3), (32, [64, 64, 128], 0.6), (64, [64, 96, 128], 1.0), (16, [64, 64, 128], 0.5)][:n_chain]
+    B, N, M, C = 2, 2048, (641 if n_chain == 4 else 640), 64       # (four branches: two dispatches of the chain kernel, a ragged last row block)
     rng = np.random.default_rng(5 + n_chain)
     cat_c = sum(s[1][-1] for s in specs)
     agg = ops.PackedMLPBf16(synth.make_mlp_weights([cat_c, 128], rng), False, dev)
