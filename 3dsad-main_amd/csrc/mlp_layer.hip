@@ -219,6 +219,10 @@ __device__ __forceinline__ Prefetched gemm_item(const LayerMulti &lm, const Laye
     store_chunk(nxt, 0, lds);
     if (NC == 1) publish_next();
     __syncthreads();
+#if defined(SAD_LAYER_WHATIF) && SAD_LAYER_WHATIF == 4
+    float4 wnx[2], xnx[2];
+    wnx[0] = wnx[1] = xnx[0] = xnx[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+#endif
 #pragma unroll 1
     for (int c = 0; c < NC; ++c) {
         float4 *cur = lds + (c & 1) * STAGE_F4;
@@ -259,11 +263,20 @@ __device__ __forceinline__ Prefetched gemm_item(const LayerMulti &lm, const Laye
         }
         // one k-group = 2 weight + 2 activation fragments from LDS -> 16 MFMAs; reads run one k-group ahead
         float4 wa[2][2], xa[2][2];
+#if defined(SAD_LAYER_WHATIF) && SAD_LAYER_WHATIF == 4      // measurement build (racy, wrong results): the chunk's first fragments were read BEFORE the barrier (what a three-stage ring would allow)
+        if (c == 0) {
+#endif
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             wa[0][i] = cur[(0 * 8 + 2 * wx + i) * 64 + lane];
             xa[0][i] = cur[(0 * 8 + 4 + 2 * wy + i) * 64 + lane];
         }
+#if defined(SAD_LAYER_WHATIF) && SAD_LAYER_WHATIF == 4
+        } else {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) { wa[0][i] = wnx[i]; xa[0][i] = xnx[i]; }
+        }
+#endif
 #pragma unroll
         for (int u = 0; u < KC; ++u) {
             if (u + 1 < KC) {
@@ -284,6 +297,16 @@ __device__ __forceinline__ Prefetched gemm_item(const LayerMulti &lm, const Laye
         }
         if (c + 1 < NC) store_chunk(nxt, c + 1, lds + ((c + 1) & 1) * STAGE_F4);
         if (c + 2 == NC) publish_next();
+#if defined(SAD_LAYER_WHATIF) && SAD_LAYER_WHATIF == 4
+        {
+            const float4 *nx = lds + ((c + 1) & 1) * STAGE_F4;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                wnx[i] = nx[(0 * 8 + 2 * wx + i) * 64 + lane];
+                xnx[i] = nx[(0 * 8 + 4 + 2 * wy + i) * 64 + lane];
+            }
+        }
+#endif
         __syncthreads();
     }
     if (jb.relu) {
