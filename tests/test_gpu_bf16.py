@@ -651,3 +651,39 @@ def test_rows_bf16_second_form_equals_first_form(orc, sad, dev, rows, dims):
     assert torch.equal(got16, want16)
     assert torch.equal(buf[:, 8:8 + dims[-1]], want16) and (buf[:, :8] == -7).all() and (buf[:, 8 + dims[-1]:] == -7).all()
     _close(got32.cpu().numpy(), orc.mlp_rows_bf16(x.float().cpu().numpy(), layers), f"rows2 {dims} x {rows}")
+
+
+def test_bf16_pipelined_steps_soak(sad, dev):
+    """The LDS-DMA kernels (chain weight ring, row-streaming layer) and split pooling under the pipelined submit path: rotating KITTI-shaped
+    batches, several steps in flight, every result bit-equal to the eager single-step result of its batch (a DMA read too early would show
+    as a rare wrong tile).  SAD_STRESS=20: a longer soak of the same check."""
+    import os
+    import torch
+    from sad_amd import config, synth
+    from sad_amd.detector import SADDetector
+    stress = int(os.environ.get("SAD_STRESS", "1"))
+    cfg = config.KITTI
+    w = synth.make_weights(cfg, 0)
+    batches = [_t(synth.make_batch(100 + 8 * k, 8, cfg.n_points), dev) for k in range(4)]
+    ref_det = SADDetector(cfg, w, dev, dtype="bf16")
+    ref_det.use_plans = False
+    want = []
+    for b in batches:
+        out, ev = ref_det.submit(b)
+        ev.synchronize()
+        want.append(out.clone())
+    det = SADDetector(cfg, w, dev, dtype="bf16", streams=(ref_det._sides, ref_det._mains))
+    pending, bad = [], 0
+    for i in range(60 * stress):
+        k = (i * 3 + i // 7) % 4
+        out, ev = det.submit(batches[k])
+        pending.append((out, ev, k, i))
+        if len(pending) > 6:
+            o, e, kk, ii = pending.pop(0)
+            e.synchronize()
+            bad += int(not torch.equal(o, want[kk]))
+    for o, e, kk, ii in pending:
+        e.synchronize()
+        bad += int(not torch.equal(o, want[kk]))
+    assert bad == 0, f"{bad} of {60 * stress} pipelined steps differ from the eager result of their batch"
+    assert det.plan_refused is None
