@@ -576,6 +576,9 @@ static int prepare_bf16(const sad_mlp_bf16_args *a, sad_stream_t stream, BfPrepa
             cols += a->pool_cols[i];
         }
         SAD_REQUIRE(cols == a->C, "sad_mlp_chain_bf16: the pool_cols add up to %d, the layer reads C = %d channels", cols, a->C);
+        for (int i = 0; i < a->n_pool; ++i)     // (the layer addresses continuation rows with 32-bit byte offsets)
+            SAD_REQUIRE(sad_mlp_cont_bytes(a->B, a->M, a->pool_S[i], a->pool_cols[i]) < (1ull << 32),
+                        "sad_mlp_chain_bf16: continuation buffer %d of %zu bytes (limit 4 GB)", i, sad_mlp_cont_bytes(a->B, a->M, a->pool_S[i], a->pool_cols[i]));
     }
     if (!grouped && a->L == 1 && (a->geometry == 0 || a->geometry == 3)) {
         // ---- one plain layer: the row-streaming kernel (every input row read once per 128 output channels) ----
@@ -628,6 +631,8 @@ static int prepare_bf16(const sad_mlp_bf16_args *a, sad_stream_t stream, BfPrepa
             // this dispatch's own, or sad_mlp_rowscan_split)
             SAD_REQUIRE(a->dims[3] % 8 == 0 && a->ld_out % 8 == 0 && a->col_off % 8 == 0 && (uintptr_t)a->out % 16 == 0 && (uintptr_t)a->cont % 16 == 0,
                         "sad_mlp_chain_bf16: split pooling needs cout, ld_out and col_off multiples of 8 and 16-byte aligned out / cont");
+            SAD_REQUIRE(sad_mlp_cont_bytes(a->B, a->M, a->S, a->dims[3]) < (1ull << 32), "sad_mlp_chain_bf16: continuation buffer of %zu bytes (limit 4 GB)",
+                        sad_mlp_cont_bytes(a->B, a->M, a->S, a->dims[3]));
             prep.scan.split = 1;
             prep.scan.cont0 = a->cont;
             prep.scan.cont_cols = a->dims[3];

@@ -109,6 +109,50 @@ def test_layer_streamed_chain_refuses_rows_beyond_4gib(sad):
     assert b"4 GiB" in L.sad_last_error()
 
 
+def test_split_pooling_boundary_checks(sad):
+    """ABI 4 (split pooling): sizes and refusals that need no GPU.  A table grows by one int per group, a continuation buffer has one row per
+    32-row tile + the zero row, and the layer that reads split-pooled rows is ONE plain layer of bf16 rows on the row-streaming kernel."""
+    from sad_amd import _lib
+    L = _lib.lib()
+    assert L.sad_mlp_cont_bytes(2, 100, 32, 64) == ((2 * 100 * 32 + 31) // 32 + 1) * 64 * 2
+    assert L.sad_mlp_cont_bytes(0, 100, 32, 64) == 0
+    ng, S = 2 * 100, 32
+    before = 4 + (ng + 1) + (ng * S // 32 + 2) + (ng // 1024 + 2) + 2 * ng * S
+    assert L.sad_mlp_workspace_bytes(2, 100, S) == 4 * (((before + 3) & ~3) + ng + 1) + 64
+    assert L.sad_mlp_rowscan_split(1, None, None, None, 1, 8, 4, None, None, None, None) == -1
+    a = _lib.MlpBf16Args()
+    a.struct_size = ctypes.sizeof(_lib.MlpBf16Args)
+    a.feat, a.packed, a.out = 0x10000, 0x20000, 0x30000          # never dereferenced: every call below fails on the host
+    a.B, a.M, a.S, a.relu_mask = 1, 256, 1, 1
+    a.n_pool = 1
+    a.pool_ws[0], a.pool_cont[0], a.pool_S[0], a.pool_cols[0] = 0x40000, 0x50000, 32, 128
+    # two layers: refused (only a single plain layer reads split-pooled rows)
+    a.L, a.C, a.ld_feat, a.feat_bf16, a.ld_out = 2, 128, 128, 1, 32
+    a.dims[0], a.dims[1], a.dims[2] = 128, 64, 32
+    assert L.sad_mlp_chain_bf16(ctypes.byref(a), None) == -2 and b"split-pooled" in L.sad_last_error()
+    # f32 rows: refused
+    a.L, a.feat_bf16 = 1, 0
+    assert L.sad_mlp_chain_bf16(ctypes.byref(a), None) == -2
+    # column widths that do not add up to C / are not multiples of 16
+    a.feat_bf16 = 1
+    a.pool_cols[0] = 64
+    assert L.sad_mlp_chain_bf16(ctypes.byref(a), None) == -1 and b"add up" in L.sad_last_error()
+    a.pool_cols[0], a.C, a.ld_feat, a.dims[0] = 24, 24, 24, 24
+    assert L.sad_mlp_chain_bf16(ctypes.byref(a), None) == -1
+    # a grouped call with bf16 output but no continuation buffer / another kernel than the register-resident chain
+    g = _lib.MlpBf16Args()
+    g.struct_size = ctypes.sizeof(_lib.MlpBf16Args)
+    for f in ("xyz", "new_xyz", "idx", "feat", "packed", "out", "cnt", "workspace"):
+        setattr(g, f, 0x10000)
+    g.B, g.N, g.M, g.S, g.C, g.L, g.ld_feat, g.feat_bf16, g.relu_mask, g.ld_out = 1, 64, 16, 32, 64, 3, 64, 1, 7, 128
+    for i, d in enumerate((67, 64, 64, 128)):
+        g.dims[i] = d
+    g.out_bf16, g.geometry = 1, 2
+    assert L.sad_mlp_chain_bf16(ctypes.byref(g), None) == -1 and b"continuation" in L.sad_last_error()
+    g.cont, g.geometry = 0x60000, 128
+    assert L.sad_mlp_chain_bf16(ctypes.byref(g), None) == -1
+
+
 def test_ops_refuse_cpu_tensors(sad):
     import torch
     from sad_amd import ops
