@@ -480,7 +480,7 @@ def _split_case(sad, dev, B, N, M, S, C, mlp, fill, seed=0):
     from sad_amd import ops, synth
     rng = np.random.default_rng(N + M + S + C + seed)
     xyz = rng.random((B, N, 3), dtype=np.float32)
-    new_xyz = xyz[:, :M].copy()
+    new_xyz = xyz[:, :M].copy() if M <= N else rng.random((B, M, 3), dtype=np.float32)
     idx = rng.integers(0, N, size=(B, M, S)).astype(np.int32)
     cnt = np.clip(rng.poisson(fill * S, size=(B, M)), 1, S).astype(np.int32) if fill < 1.0 else np.full((B, M), S, np.int32)
     if fill >= 1.0:
@@ -540,14 +540,16 @@ def test_split_pooled_rows_are_the_f32_pooled_rows_rounded(sad, dev, B, N, M, S,
     assert not np.array_equal(main.astype(np.int16), want)
 
 
-@pytest.mark.parametrize("n_chain", [1, 3, 4])
+@pytest.mark.parametrize("n_chain", [1, 3, 4, 30])
 def test_layer_reading_split_pooled_rows_equals_layer_on_f32_pooled_rows(sad, dev, n_chain):
     """sa2-like stage: three branches into one [B,M,384] buffer, aggregation 384 -> 128, f32 pooling against split pooling; then the
     same with full 64-row groups (second continuation rows) and a deep layer on the queued loop."""
     import torch
     from sad_amd import ops, synth
+    big = n_chain == 30          # three branches on 40 002 groups: more row blocks than CUs -> the persistent form of the reading layer
+    n_chain = 3 if big else n_chain
     specs = [(32, [64, 64, 128], 0.3), (32, [64, 64, 128], 0.6), (64, [64, 96, 128], 1.0), (16, [64, 64, 128], 0.5)][:n_chain]
-    B, N, M, C = 2, 2048, (641 if n_chain == 4 else 640), 64       # (four branches: two dispatches of the chain kernel, a ragged last row block)
+    B, N, M, C = 2, 2048, (20001 if big else (641 if n_chain == 4 else 640)), 64       # (four branches: two dispatches of the chain kernel, a ragged last row block)
     rng = np.random.default_rng(5 + n_chain)
     cat_c = sum(s[1][-1] for s in specs)
     agg = ops.PackedMLPBf16(synth.make_mlp_weights([cat_c, 128], rng), False, dev)
@@ -623,7 +625,9 @@ ROWS2 = [
     (130, [384, 128]),          # two row blocks, the second nearly empty
     (4099, [64, 96]),           # ONE chunk; three channel tiles: a ragged channel block
     (257, [192, 40]),           # cout not a multiple of 32
-    (70000, [128, 64]),         # more row blocks than two rounds of the chip
+    (70000, [128, 64]),         # more row blocks than CUs: the persistent third form (two chunks per item, ragged last block)
+    (200001, [384, 128]),       # third form, six items per workgroup, four channel tiles
+    (40000, [1536, 512]),       # third form, four channel blocks (313 row blocks x 4 on 256 workgroups)
 ]
 
 
