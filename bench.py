@@ -213,32 +213,36 @@ def executed_flops(det, points, cfg, dense=False):
         return (2 if bf else 4) * sum(a * b for a, b in zip(d[:-1], d[1:]))
 
     feat_esz = 4                                   # the scene's own feature channels are float32 in both modes
+    pool_esz = 2 if bf else 4                      # pooled rows between the branches and the aggregation layer (bf16 mode: split pooling)
     for si, st in enumerate(cfg.stages):
         name = f"sa{si + 1}"
         for bi, idx in enumerate(tr[name]["ball_idx"]):
             r = rows_of(idx)
             d = dims[f"{name}.b{bi}"]
             per[f"{name}.b{bi}"] = r * chain(d)
-            per_bytes[f"{name}.b{bi}"] = r * (8 + 12 + (d[0] - 3) * feat_esz) + B * st.npoint * (12 + d[-1] * 4) + wbytes(d)
+            per_bytes[f"{name}.b{bi}"] = r * (8 + 12 + (d[0] - 3) * feat_esz) + B * st.npoint * (12 + d[-1] * pool_esz) + wbytes(d)
             exec_rows += r
             dense_rows += idx.numel()
         if st.agg:
             d = dims[f"{name}.agg"]
             per[f"{name}.agg"] = B * st.npoint * chain(d)
-            per_bytes[f"{name}.agg"] = B * st.npoint * (d[0] * 4 + d[-1] * (2 if bf else 4)) + wbytes(d)
+            per_bytes[f"{name}.agg"] = B * st.npoint * (d[0] * pool_esz + d[-1] * (2 if bf else 4)) + wbytes(d)
             feat_esz = 2 if bf else 4              # a bf16 aggregation layer hands bf16 rows to the next stage (SPEC 14)
     for bi, idx in enumerate(tr["cluster"]["ball_idx"]):
         r = rows_of(idx)
         d = dims[f"cluster.b{bi}"]
         per[f"cluster.b{bi}"] = r * chain(d)
-        per_bytes[f"cluster.b{bi}"] = r * (8 + 12 + (d[0] - 3) * feat_esz) + B * cfg.n_cand * (12 + d[-1] * 4) + wbytes(d)
+        per_bytes[f"cluster.b{bi}"] = r * (8 + 12 + (d[0] - 3) * feat_esz) + B * cfg.n_cand * (12 + d[-1] * pool_esz) + wbytes(d)
         exec_rows += r
         dense_rows += idx.numel()
     K = cfg.n_cand
     for n in ("cand", "cluster.agg", "head"):
         d = dims[n]
         per[n] = B * K * chain(d)
-        per_bytes[n] = B * K * (d[0] * (feat_esz if n == "cand" else 4) + d[-1] * 4) + wbytes(d)
+        # (bf16 mode: cluster.agg reads split-pooled rows and hands bf16 cluster features to the head)
+        in_esz = feat_esz if n == "cand" else pool_esz
+        out_esz = pool_esz if n == "cluster.agg" else 4
+        per_bytes[n] = B * K * (d[0] * in_esz + d[-1] * out_esz) + wbytes(d)
     executed_flops.last_bytes = per_bytes          # (kept beside the return value: the callers unpack three values)
     return sum(per.values()), exec_rows / max(1, dense_rows), per
 
