@@ -254,6 +254,7 @@ __global__ __launch_bounds__(512) void mlp_rows2_kernel(const RowsJob jb) {
     }
 }
 
+
 }  // namespace
 
 namespace sad {
