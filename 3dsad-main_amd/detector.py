@@ -66,7 +66,7 @@ class SADDetector(nn.Module):
         # no HBM round trip of the cluster features); used when no trace is requested
         n_fused = len(weights["cluster.agg"]) + len(weights["head"])
         self.agg_head = None
-        if n_fused <= 4 and (dtype == "f32" or os.environ.get("SAD_BF16_FUSE_HEAD")):
+        if n_fused <= 4 and ((dtype == "f32" and not os.environ.get("SAD_F32_NO_FUSE_HEAD")) or os.environ.get("SAD_BF16_FUSE_HEAD")):
             # (bf16: a measurement switch — the fused chain runs the round-1 tiled kernel)
             self.agg_head = mlp_cls(list(weights["cluster.agg"]) + list(weights["head"]), False, self.device,
                                     relu_mask=(1 << (n_fused - 1)) - 1, name="cluster.agg+head")
