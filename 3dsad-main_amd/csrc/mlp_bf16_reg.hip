@@ -48,13 +48,14 @@ constexpr int RNS = SAD_BR_DMA ? 4 : 3;      // ring slots: being read / complet
 constexpr int RING_F4 = RNS * RS * 64;
 constexpr int PFD_DEFAULT = SAD_BR_PFD;   // ring reads run this many fragments ahead of the MFMA that consumes them
 #ifndef SAD_BR_F2
-#define SAD_BR_F2 3
-#endif
+#define SAD_BR_F2 2      // (with the LDS-DMA ring: two workgroups of 256 registers, no spills — a spill reload is a vector-memory load whose wait, a
+#endif                   // vmcnt(0), drains the DMA issued for three stages ahead; 3 x 168 registers with 12 spilled: +0.3 % / +0.5 % on the KITTI / nuScenes-shaped step)
 #ifndef SAD_BR_PFD2
 #define SAD_BR_PFD2 2
 #endif
-// SA3 family: three workgroups per CU (168 registers) with reads two fragments ahead — 107 us against 121 with two workgroups of 207
-// registers and four ahead on the KITTI-shaped batch (three workgroups at four ahead: 113, 19 registers spilled instead of 10)
+// SA3 family, round 4 (weights through registers): three workgroups per CU (168 registers) with reads two fragments ahead — 107 us against 121
+// with two workgroups of 207 registers and four ahead on the KITTI-shaped batch (three workgroups at four ahead: 113, 19 registers spilled
+// instead of 10).  Round 5 (LDS-DMA ring): two workgroups again, see SAD_BR_F2
 __host__ __device__ constexpr int pfd_of(int family) { return family == 2 ? SAD_BR_PFD2 : PFD_DEFAULT; }
 // Staged pooled output.  A wave owns 4 KB of LDS: STAGE_F floats = slots x CB channels, slot = ordinal of a group inside
 // the tile, CB = 128 / 64 / 32 channels per block for tiles with <= 8 / 16 / 32 groups.  EVERY row of an output tile
