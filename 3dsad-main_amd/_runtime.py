@@ -13,7 +13,7 @@ import warnings
 
 HW_QUEUES_ENV = "GPU_MAX_HW_QUEUES"
 HW_QUEUES_DEFAULT = 4          # HIP's default when the variable is unset
-HW_QUEUES_WANTED = 16          # every stream of the largest pipeline (2 main + 8 sampling + gather) on its own queue
+HW_QUEUES_WANTED = 24          # every stream of the largest pipeline on its own queue, placeholders included (placed_streams below: 2 main + 8 sampling + 2 extra + 7 idle = 19)
 
 
 def _hip_initialised():
@@ -101,3 +101,57 @@ def check_stream_budget(n_streams: int, state: str, environ=None) -> bool:
                       f"queue serialise (use {HW_QUEUES_WANTED}, or fewer sampling streams).", RuntimeWarning, stacklevel=3)
         return False
     return True
+
+
+# ---- stream placement --------------------------------------------------------------------------------------------------
+# A HIP stream takes its hardware queue when it is first used, queues are numbered in that order, and queues whose numbers
+# differ by a multiple of four are served by the same dispatch pipe of the command processor (measured on MI355X, round 5:
+# DESIGN.md §9 "stream placement").  A main stream — ~40 launches per step, many of them a few microseconds long — that shares
+# its pipe with a sampling stream, with the gather stream (whose head packet is a barrier waiting for the step's end) or with
+# the other main stream loses 4 - 7 % of the pipelined step: its short kernels wait for the pipe.  So the streams of a
+# pipeline are created AND touched here in an order that leaves each main stream alone on its pipe: sampling and extra
+# streams take the even places, the (at most two) main streams the first two odd places, idle dummy streams the later odd
+# places.  Whatever took queues before (the null stream) is idle while the pipeline runs.
+_PLACEHOLDERS = []          # the dummy streams stay alive: a destroyed stream gives its queue back
+
+
+def placement_order(n_side: int, n_main: int, n_extra: int):
+    """The order of first use: a list of ("side", i) / ("main", i) / ("extra", i) / ("dummy", None).  With more than two
+    main streams there is no pipe to spare: plain order."""
+    if n_main > 2 or os.environ.get("SAD_NO_STREAM_PLACEMENT"):
+        return ([("side", i) for i in range(n_side)] + [("main", i) for i in range(n_main)] +
+                [("extra", i) for i in range(n_extra)])
+    even = [("side", i) for i in range(n_side)] + [("extra", i) for i in range(n_extra)]
+    odd = [("main", i) for i in range(n_main)]
+    order = []
+    while even or odd:
+        if even:
+            order.append(even.pop(0))
+        elif odd:
+            order.append(("dummy", None))
+        if odd:
+            order.append(odd.pop(0))
+        elif even:
+            order.append(("dummy", None))
+    while order and order[-1][0] == "dummy":
+        order.pop()
+    while order and order[0][0] == "dummy":
+        order.pop(0)
+    return order
+
+
+def placed_streams(device, n_side: int, n_main: int, n_extra: int = 0):
+    """(sampling streams, main streams, extra streams) of one pipeline on ``device``, each touched once (an event record and
+    a wait: the stream has its hardware queue afterwards) in ``placement_order``."""
+    import torch
+    out = {"side": [None] * n_side, "main": [None] * n_main, "extra": [None] * n_extra}
+    for kind, i in placement_order(n_side, n_main, n_extra):
+        s = torch.cuda.Stream(device=device)
+        if kind == "dummy":
+            _PLACEHOLDERS.append(s)
+        else:
+            out[kind][i] = s
+        e = torch.cuda.Event()
+        e.record(s)
+        s.synchronize()
+    return out["side"], out["main"], out["extra"]

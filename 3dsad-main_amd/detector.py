@@ -29,13 +29,17 @@ class SADDetector(nn.Module):
 
     def __init__(self, cfg: DetectorConfig, weights: dict, device, overlap_fps: bool = True,
                  n_fps_streams: int = 3, n_main_streams: int = 2, nested_fps_shortcut: bool = True,
-                 dtype: str = "f32", query_on_sampling_stream: bool = True, streams=None):
+                 dtype: str = "f32", query_on_sampling_stream: bool = True, streams=None, n_extra_streams: int = 2):
         """``dtype="bf16"``: every MLP runs on the bf16 matrix-core path (SPEC.md §14, BASELINE.json
         configs[4]); sampling, ball query and box decode are unchanged.
         ``streams`` = (sampling streams, main streams): reuse these instead of creating new ones — a process that builds
         several detectors should share one set, since every stream ever created keeps its place among the
         ``GPU_MAX_HW_QUEUES`` hardware queues and streams beyond that number share queues (a detector built after 16
-        streams exist ran its FPS chains at half speed: measured)."""
+        streams exist ran its FPS chains at half speed: measured).  A detector that makes its own streams makes them through
+        ``_runtime.placed_streams`` (each main stream alone on its dispatch pipe) together with ``n_extra_streams`` more for the
+        caller: ``det.extra_streams[0]`` is meant for the gather (``dist.AsyncBoxGather(dev, stream=...)``), ``[1]`` for the ingest
+        stream of ``pipeline.IngestPipeline`` — a stream the caller creates later lands wherever the next queue number falls,
+        possibly on a main stream's pipe (4 - 7 % of the pipelined step: DESIGN.md §9)."""
         super().__init__()
         if dtype not in ("f32", "bf16"):
             raise ValueError("dtype must be 'f32' or 'bf16'")
@@ -91,16 +95,17 @@ class SADDetector(nn.Module):
             if len(streams[0]) < n_side or len(streams[1]) < n_main:
                 raise ValueError(f"streams: need {n_side} sampling and {n_main} main streams")
         dkey = self.device.index if self.device.index is not None else torch.cuda.current_device()   # (hardware queues are per device)
-        made = SADDetector._streams_created.get(dkey, 0) + (0 if streams is not None else n_side + n_main)
+        made = SADDetector._streams_created.get(dkey, 0) + (0 if streams is not None else len(_runtime.placement_order(n_side, n_main, max(0, n_extra_streams))))
         SADDetector._streams_created[dkey] = made
         _runtime.check_stream_budget(max(n_side + n_main, made) + 1, HW_QUEUES_STATE)
-        self._sides = (list(streams[0][:n_side]) if streams is not None else
-                       [torch.cuda.Stream(device=self.device) for _ in range(n_side)])
+        # (own streams: created and touched in the order that leaves each main stream alone on its dispatch pipe, _runtime.py)
+        own = None if streams is not None else _runtime.placed_streams(self.device, n_side, n_main, max(0, n_extra_streams))
+        self.extra_streams = list(streams[2]) if (streams is not None and len(streams) > 2) else (own[2] if own is not None else [])
+        self._sides = list(streams[0][:n_side]) if streams is not None else own[0]
         self._calls = 0
         # submit(): consecutive batches alternate between main streams, so the tail of one batch's
         # kernels (few workgroups left, most CUs idle) overlaps the next batch's kernels.
-        self._mains = (list(streams[1][:n_main]) if streams is not None else
-                       [torch.cuda.Stream(device=self.device) for _ in range(n_main)])
+        self._mains = list(streams[1][:n_main]) if streams is not None else own[1]
         self._submits = 0
         # Step plans (plan.py): submit() records the launches of a step once per ring slot and replays them afterwards.  The
         # ring is a multiple of both stream counts, so a slot always meets the same (main, sampling) stream pair, and long

@@ -6,10 +6,20 @@ contiguous slice of the batch, and ONE ``all_gather`` of the fixed-shape ``boxes
 ROCm the ``nccl`` backend is RCCL over xGMI; the same code runs on ``gloo`` for CPU tests.
 The upstream reference (``/root/reference/README.md:1-2``) has no distributed code to mirror.
 """
+import os
 from typing import Callable, Tuple
 
 import torch
 import torch.distributed as dist
+
+
+def _collective_needed(group=None) -> bool:
+    """A one-rank group has nothing to exchange and skips the collective — unless ``SAD_DIST_FORCE_COLLECTIVE`` is set:
+    the rehearsal of the N > 1 path on a one-GPU box (a one-rank RCCL communicator runs the same ``all_gather_into_tensor``
+    on the communication stream, so the backend, the stream hand-off and the per-step cost of the call are exercised)."""
+    if not dist.is_available() or not dist.is_initialized():
+        return False
+    return dist.get_world_size(group) > 1 or bool(os.environ.get("SAD_DIST_FORCE_COLLECTIVE"))
 
 
 def shard_range(total: int, rank: int, world: int) -> Tuple[int, int]:
@@ -23,7 +33,7 @@ def shard_range(total: int, rank: int, world: int) -> Tuple[int, int]:
 
 def all_gather_boxes(local_boxes: torch.Tensor, group=None) -> torch.Tensor:
     """local [B_loc,K,9] on every rank -> [world*B_loc,K,9] in rank order (one collective)."""
-    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if not _collective_needed(group):
         return local_boxes
     world = dist.get_world_size(group)
     local_boxes = local_boxes.contiguous()
@@ -43,13 +53,15 @@ class AsyncBoxGather:
     tensor is allocated on the communication stream: a consumer on another stream waits for the
     event and calls ``out.record_stream(its_stream)``."""
 
-    def __init__(self, device, group=None):
-        self.stream = torch.cuda.Stream(device=device)
+    def __init__(self, device, group=None, stream=None):
+        # (``stream``: one made by ``_runtime.placed_streams`` together with the pipeline's other streams, so that it does not
+        # land on a main stream's dispatch pipe)
+        self.stream = stream if stream is not None else torch.cuda.Stream(device=device)
         self.group = group
         self.event = None       # completion of the most recent collective (None: nothing in flight)
 
     def __call__(self, local_boxes: torch.Tensor) -> torch.Tensor:
-        if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(self.group) == 1:
+        if not _collective_needed(self.group):
             self.event = None
             return local_boxes
         cur = torch.cuda.current_stream()

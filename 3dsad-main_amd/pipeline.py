@@ -26,7 +26,9 @@ class IngestPipeline:
         self.K = det.cfg.n_cand
         self.iou_thr, self.score_thr, self.seed = float(iou_thr), float(score_thr), int(seed)
         self.dev = det.device
-        self.ingest = ingest_stream if ingest_stream is not None else torch.cuda.Stream(device=self.dev)
+        # (default: the detector's second extra stream, made with its other streams so that it is not on a main stream's pipe)
+        extra = getattr(det, "extra_streams", [])
+        self.ingest = ingest_stream if ingest_stream is not None else (extra[1] if len(extra) > 1 else torch.cuda.Stream(device=self.dev))
         cap = self.B * int(max_points_per_scene)
         # pinned input: the scenes' file bytes back to back (as float32 rows) + the B + 1 row offsets
         self._in_pts = [torch.empty((cap, self.cols), dtype=torch.float32).pin_memory() for _ in range(in_slots)]

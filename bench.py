@@ -42,7 +42,7 @@ sys.path.insert(0, ROOT)
 # eight on 8 queues take twice as long - tools/fps_concurrency.py).  Must be set before the runtime initialises;
 # `import sad_amd` does the same for any other caller (3dsad-main_amd/_runtime.py).
 HW_QUEUES_AT_START = os.environ.get("GPU_MAX_HW_QUEUES")      # what the process was started with (None: unset; recorded in the line)
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
 
 PEAK_MFMA_F32_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: dense f32 MFMA
 PEAK_MFMA_BF16_TFLOPS = 2500.0 # same guide: dense bf16 MFMA (not the 2:1-sparsity headline)
@@ -312,10 +312,12 @@ def self_launch(cmd, env=None):
 
 
 def default_fps_streams(dtype: str) -> int:
-    """The serial FPS chain of a batch (2.9 ms KITTI, 15.6 ms nuScenes) must not bound the step.
-    f32, 16 hardware queues: 13.55 / 13.89 / 12.90 k scenes/s with 2 / 3 / 4 sampling streams (tools/probe/ab_fps_streams.sh);
-    bf16 nuScenes (tools/probe/nus_sweep.sh): 32 scenes per batch 3.7 / 4.6 / 5.1 / 5.2 k scenes/s with 3 / 4 / 5 / 6 streams."""
-    return 3 if dtype == "f32" else 6
+    """The serial FPS chain of a batch (2.0 ms KITTI, 11.9 ms nuScenes) must not bound the step, and at the start of a timed
+    region the chains of the first steps should all run at once.  With the streams placed (sad_amd._runtime.placed_streams: main
+    streams alone on their dispatch pipes) eight sampling streams are best everywhere (profiles/r05_stream_placement.txt):
+    f32 14.5 k at the driver's setting against 14.2 - 14.3 k with 2 - 4, bf16 47.7 k against 46.8 k with 6, nuScenes-shaped
+    7.05 k against 6.97 k; ten or more need more hardware queues than the device serves at full speed (37 k / 7 k)."""
+    return 8
 
 
 def batch_first_scene(k: int, rank: int, world: int, B: int) -> int:
@@ -381,16 +383,18 @@ _STREAMS = {}
 def shared_streams(dev, n_side: int, n_main: int):
     """ONE set of sampling / main streams (and one gather stream) for every detector this process builds: each stream
     ever created keeps a place among the GPU_MAX_HW_QUEUES hardware queues, and the three detectors of a default run
-    would otherwise create 24 (the last one then ran its FPS chains two to a queue: 3.1 k instead of 5.4 k scenes/s)."""
-    import torch
+    would otherwise create 24 (the last one then ran its FPS chains two to a queue: 3.1 k instead of 5.4 k scenes/s).
+    The whole set (eight sampling streams: what the bf16 legs use) is made at the first call, in the order that keeps the
+    main streams alone on their dispatch pipes (sad_amd._runtime.placed_streams)."""
+    from sad_amd import _runtime
     from sad_amd.dist import AsyncBoxGather
-    st = _STREAMS.setdefault(str(dev), {"side": [], "main": [], "gather": None})
-    while len(st["side"]) < n_side:
-        st["side"].append(torch.cuda.Stream(device=dev))
-    while len(st["main"]) < n_main:
-        st["main"].append(torch.cuda.Stream(device=dev))
-    if st["gather"] is None:
-        st["gather"] = AsyncBoxGather(dev)
+    st = _STREAMS.get(str(dev))
+    if st is None or len(st["side"]) < n_side or len(st["main"]) < n_main:
+        if st is not None:
+            raise SystemExit(f"shared_streams: {n_side} sampling / {n_main} main streams asked for after the set was made "
+                             f"with {len(st['side'])} / {len(st['main'])}")
+        side, main, extra = _runtime.placed_streams(dev, max(n_side, 8), max(n_main, 2), 2)
+        st = _STREAMS[str(dev)] = {"side": side, "main": main, "gather": AsyncBoxGather(dev, stream=extra[0]), "ingest": extra[1]}
     return (st["side"][:n_side], st["main"][:n_main]), st["gather"]
 
 
@@ -460,7 +464,7 @@ def measure(w: Workload, steps: int, warmup: int, rank: int, world: int, dev, ar
     for _ in range(warmup):
         step()
     torch.cuda.synchronize()
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         torch.cuda.synchronize()
     # The timed region carries no per-launch events (creating ~40 timing events per sampled step stalled the
@@ -478,7 +482,7 @@ def measure(w: Workload, steps: int, warmup: int, rank: int, world: int, dev, ar
             out, last = step()
             step_marks[i].record(det.last_stream)
         torch.cuda.synchronize()
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
             torch.cuda.synchronize()
         elapsed_local = time.perf_counter() - t0
@@ -521,7 +525,7 @@ def measure(w: Workload, steps: int, warmup: int, rank: int, world: int, dev, ar
     inflight.clear()
     elapsed = elapsed_local
     rank_info = None
-    if world > 1:
+    if dist.is_initialized():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -538,6 +542,7 @@ def measure(w: Workload, steps: int, warmup: int, rank: int, world: int, dev, ar
                      "device_index_per_rank": [int(p[1]) for p in per_rank],
                      "geometry_hash_per_rank": [f"{int(p[2]):06x}" for p in per_rank],
                      "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
+                     "one_rank_rehearsal": bool(os.environ.get("SAD_DIST_FORCE_COLLECTIVE")) and world == 1,
                      "note": "each rank autotunes its own geometry (same kernels, same bits; picks may differ "
                              "by a few per cent in speed); elapsed is the MAX over ranks between two barriers"}
     if rank != 0:
@@ -878,8 +883,7 @@ def pipeline_leg(args, dev, geometry, headline_value: float, rank: int, world: i
     weights = synth.make_weights(cfg, 0)
     w = Workload("kitti", "kitti", "f32", B, None, args.main_streams, None, args.batches)
     streams, _ = shared_streams(dev, w.fps_streams, w.main_streams)
-    ing = _STREAMS[str(dev)].setdefault("ingest", None) or torch.cuda.Stream(device=dev)
-    _STREAMS[str(dev)]["ingest"] = ing
+    ing = _STREAMS[str(dev)]["ingest"]              # (made with the other streams: not on a main stream's dispatch pipe)
     det = SADDetector(cfg, weights, dev, n_fps_streams=w.fps_streams, n_main_streams=w.main_streams, dtype="f32", streams=streams)
     if isinstance(geometry, dict):
         det.set_geometry(geometry)
@@ -1064,6 +1068,15 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    if world == 1 and os.environ.get("SAD_BENCH_FORCE_DIST"):
+        # rehearsal of the N > 1 path on a one-GPU box with the REAL backend: a one-rank RCCL communicator, the step's
+        # all_gather, the barriers and the max-over-ranks reduction all run (sad_amd.dist: SAD_DIST_FORCE_COLLECTIVE)
+        os.environ["SAD_DIST_FORCE_COLLECTIVE"] = "1"
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(free_port()))
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+        dist.init_process_group("nccl", device_id=dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = os.environ.get("SAD_BENCH_BACKEND", "nccl")       # "nccl" is RCCL on ROCm
@@ -1138,7 +1151,7 @@ def main():
                 rc = rc or 1
     if rank == 0:
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
     if rc:

@@ -248,7 +248,7 @@ def test_package_owns_hw_queue_precondition(monkeypatch):
     import warnings
     from sad_amd import _runtime
     env = {}
-    assert _runtime.ensure_hw_queues(env, initialised=False) == "set" and env["GPU_MAX_HW_QUEUES"] == "16"
+    assert _runtime.ensure_hw_queues(env, initialised=False) == "set" and env["GPU_MAX_HW_QUEUES"] == "24"
     assert _runtime.ensure_hw_queues(env, initialised=False) == "user"          # second import: already there
     env = {"GPU_MAX_HW_QUEUES": "8"}
     assert _runtime.ensure_hw_queues(env, initialised=False) == "user" and env["GPU_MAX_HW_QUEUES"] == "8"
@@ -256,7 +256,7 @@ def test_package_owns_hw_queue_precondition(monkeypatch):
     assert _runtime.ensure_hw_queues(env, initialised=True) == "late" and "GPU_MAX_HW_QUEUES" not in env
     # torch imported, its CUDA flag still False: is_available() / a profiler preload may have brought HIP up unseen
     env = {}
-    assert _runtime.ensure_hw_queues(env, initialised=None) == "unknown" and env["GPU_MAX_HW_QUEUES"] == "16"
+    assert _runtime.ensure_hw_queues(env, initialised=None) == "unknown" and env["GPU_MAX_HW_QUEUES"] == "24"
     assert _runtime.hw_queues({}) == 4 and _runtime.hw_queues({"GPU_MAX_HW_QUEUES": "16"}) == 16
     assert _runtime.hw_queues({"GPU_MAX_HW_QUEUES": "x"}) == 4
     with warnings.catch_warnings():
@@ -278,3 +278,26 @@ def test_package_owns_hw_queue_precondition(monkeypatch):
     assert sad_amd.HW_QUEUES_STATE in ("set", "user", "unknown")
     import os
     assert os.environ.get("GPU_MAX_HW_QUEUES")
+
+
+def test_stream_placement_order(monkeypatch):
+    """Order of first use of a pipeline's streams (``_runtime.placement_order``): hardware queues are numbered in that order and
+    numbers four apart share a dispatch pipe, so each of the (at most two) main streams must be the ONLY live stream of its
+    residue class — sampling / extra streams on the even places, idle dummies on the later odd places.  Pure logic."""
+    from sad_amd import _runtime
+    monkeypatch.delenv("SAD_NO_STREAM_PLACEMENT", raising=False)
+    for n_side, n_main, n_extra in ((3, 2, 1), (6, 2, 2), (3, 1, 0), (1, 1, 0), (0, 1, 0), (8, 2, 1), (2, 2, 0), (0, 2, 1)):
+        order = _runtime.placement_order(n_side, n_main, n_extra)
+        kinds = [k for k, _ in order]
+        assert sorted(i for k, i in order if k == "side") == list(range(n_side))
+        assert sorted(i for k, i in order if k == "main") == list(range(n_main))
+        assert sorted(i for k, i in order if k == "extra") == list(range(n_extra))
+        assert kinds[0] != "dummy" and kinds[-1] != "dummy"
+        for pos, (k, _) in enumerate(order):
+            if k == "main":
+                same_pipe = [kinds[q] for q in range(len(order)) if q != pos and q % 4 == pos % 4]
+                assert all(x == "dummy" for x in same_pipe), (n_side, n_main, n_extra, order)
+    # three main streams: no pipe to spare, plain order, no dummies; and the A/B switch
+    assert [k for k, _ in _runtime.placement_order(6, 3, 1)] == ["side"] * 6 + ["main"] * 3 + ["extra"]
+    monkeypatch.setenv("SAD_NO_STREAM_PLACEMENT", "1")
+    assert [k for k, _ in _runtime.placement_order(3, 2, 1)] == ["side"] * 3 + ["main"] * 2 + ["extra"]
