@@ -1,7 +1,7 @@
 """Runtime preconditions the package owns (no torch import here: this runs at ``import sad_amd``).
 
 HIP multiplexes a process's streams onto ``GPU_MAX_HW_QUEUES`` hardware queues (default 4).  The detector's
-pipeline uses two main streams, three to six sampling streams and a gather stream; when a 3 - 16 ms FPS kernel
+pipeline uses two main streams, three to eight sampling streams, a gather and an ingest stream (plus idle placeholders: below); when a 3 - 16 ms FPS kernel
 shares a hardware queue with MLP launches (or with another FPS chain) the queue serialises them — measured:
 9.5 - 13.2 k scenes/s instead of 14 k on the f32 benchmark.  The variable is read when the HIP
 runtime initialises, so it has to be in the environment before the first HIP call of the process.  There is no
@@ -35,7 +35,7 @@ _ASK = object()
 
 def ensure_hw_queues(environ=None, initialised=_ASK) -> str:
     """Called at ``import sad_amd``.  Leaves a value the user exported alone; otherwise exports
-    ``GPU_MAX_HW_QUEUES=16`` when the HIP runtime cannot have initialised yet.  Returns what happened:
+    ``GPU_MAX_HW_QUEUES=24`` when the HIP runtime cannot have initialised yet.  Returns what happened:
     "user" (already set), "set" (exported here: torch was not imported, no HIP call can have been made through it),
     "unknown" (exported here, but torch was imported already and ANY ``torch.cuda`` call — ``is_available()`` included —
     or a profiler preload may have initialised HIP with the default of 4 queues: the export may be read by nobody),
