@@ -142,6 +142,9 @@ class SADDetector(nn.Module):
                     plan.done.synchronize()
                 else:
                     plan.done = torch.cuda.Event()
+                if plan.post_done is not None:           # ... and the hook that read the slot's boxes on a stream of its own (the gather)
+                    plan.post_done.synchronize()
+                    plan.post_done = None
                 self._calls += 1
                 plan.last_input = points                 # (held until the slot's next use: a replay records no stream use for the allocator)
                 out = plan.replay(points.data_ptr(), ready)
@@ -150,6 +153,7 @@ class SADDetector(nn.Module):
                     with torch.cuda.stream(st):
                         out = post(out)
                     ev = getattr(post, "event", None)
+                    plan.post_done = ev
                 plan.done.record(st)
                 self.plan_replays += 1
                 return out, (ev if ev is not None else plan.done)
@@ -177,6 +181,7 @@ class SADDetector(nn.Module):
                 if plan.done is None:
                     plan.done = torch.cuda.Event()
                 plan.done.record(st)
+                plan.post_done = ev
                 if ev is None:
                     ev = plan.done
             if ev is None:

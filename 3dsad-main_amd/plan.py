@@ -119,11 +119,12 @@ class Recorder:
 
 class StepPlan:
     """The recorded launches of one step on one ring slot."""
-    __slots__ = ("ops", "keep", "patches", "out", "stream", "done", "n_calls", "last_input")
+    __slots__ = ("ops", "keep", "patches", "out", "stream", "done", "post_done", "n_calls", "last_input")
 
     def __init__(self, ops, keep, patches, out, stream):
         self.ops, self.keep, self.patches, self.out, self.stream = ops, keep, patches, out, stream
         self.done = None                          # completion of the slot's most recent step (event made and recorded by the detector)
+        self.post_done = None                     # completion of that step's post hook when it ran on a stream of its own (dist.AsyncBoxGather)
         self.n_calls = sum(1 for o in ops if o[0] == OP_CALL)
         self.last_input = None                    # the input tensor of the slot's most recent step (kept alive until the next one)
 

@@ -101,9 +101,9 @@ def test_bench_batch_rotation_and_workload_defaults():
             seen |= scenes
     assert len(seen) == world * 4 * B
     w = b.Workload("kitti", "kitti", "f32", 32)
-    assert (w.fps_streams, w.main_streams, w.queue_depth, w.n_batches) == (3, 2, 6, 4)
+    assert (w.fps_streams, w.main_streams, w.queue_depth, w.n_batches) == (8, 2, 10, 4)     # (eight sampling streams since the stream placement: DESIGN 5)
     w = b.Workload("nuscenes", "kitti", "bf16", 32, n_batches=2)
-    assert (w.fps_streams, w.queue_depth, w.n_batches) == (6, 8, 2) and w.peak() == b.PEAK_MFMA_BF16_TFLOPS
+    assert (w.fps_streams, w.queue_depth, w.n_batches) == (8, 10, 2) and w.peak() == b.PEAK_MFMA_BF16_TFLOPS
     assert "nuScenes" in w.describe() and "configs[4]" in w.describe()
     res = {"metric": "m", "value": 1.0, "unit": "scenes/s", "steps": 3, "warmup": 1, "ms_per_step": 2.0, "dtype": "bf16",
            "config": {"workload": "w", "fps_streams": 6, "scenes_per_gpu": 32},
