@@ -28,7 +28,7 @@ class SADDetector(nn.Module):
     _streams_created = {}         # device index -> streams made by every detector of this process there (never destroyed: torch pools them)
 
     def __init__(self, cfg: DetectorConfig, weights: dict, device, overlap_fps: bool = True,
-                 n_fps_streams: int = 3, n_main_streams: int = 2, nested_fps_shortcut: bool = True,
+                 n_fps_streams: int = 8, n_main_streams: int = 2, nested_fps_shortcut: bool = True,
                  dtype: str = "f32", query_on_sampling_stream: bool = True, streams=None, n_extra_streams: int = 2):
         """``dtype="bf16"``: every MLP runs on the bf16 matrix-core path (SPEC.md §14, BASELINE.json
         configs[4]); sampling, ball query and box decode are unchanged.
