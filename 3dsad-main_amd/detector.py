@@ -28,7 +28,7 @@ class SADDetector(nn.Module):
     _streams_created = {}         # device index -> streams made by every detector of this process there (never destroyed: torch pools them)
 
     def __init__(self, cfg: DetectorConfig, weights: dict, device, overlap_fps: bool = True,
-                 n_fps_streams: int = 8, n_main_streams: int = 2, nested_fps_shortcut: bool = True,
+                 n_fps_streams: Optional[int] = None, n_main_streams: int = 2, nested_fps_shortcut: bool = True,
                  dtype: str = "f32", query_on_sampling_stream: bool = True, streams=None, n_extra_streams: int = 2):
         """``dtype="bf16"``: every MLP runs on the bf16 matrix-core path (SPEC.md §14, BASELINE.json
         configs[4]); sampling, ball query and box decode are unchanged.
@@ -90,6 +90,8 @@ class SADDetector(nn.Module):
         # through the grouping / MLP kernels of earlier batches.
         # (main + sampling streams + the caller's gather stream must not outnumber the hardware queues: _runtime.py)
         from . import HW_QUEUES_STATE, _runtime
+        if n_fps_streams is None:                 # default: eight, or every sampling stream of a set that was handed in
+            n_fps_streams = 8 if streams is None else len(streams[0])
         n_side, n_main = (max(1, n_fps_streams) if overlap_fps else 0), max(1, n_main_streams)
         if streams is not None:
             if len(streams[0]) < n_side or len(streams[1]) < n_main:
