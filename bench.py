@@ -311,13 +311,21 @@ def self_launch(cmd, env=None):
     return rc
 
 
+# The device serves 24 mapped hardware queues at full speed (tools/probe/queue_budget.sh: the pipeline's 19 + the null stream + up to
+# 3 more; one more -10 %, four more -24 %).  A process group brings queues of its own (RCCL's internal streams, the backend's stream
+# for barriers and reductions: 3 in the one-rank rehearsal, unknown for 8 ranks), so a distributed run maps a smaller set:
+# six sampling streams, no ingest stream = 13 queues.  Set by main() once the process group exists.
+DISTRIBUTED = False
+
+
 def default_fps_streams(dtype: str) -> int:
     """The serial FPS chain of a batch (2.0 ms KITTI, 11.9 ms nuScenes) must not bound the step, and at the start of a timed
     region the chains of the first steps should all run at once.  With the streams placed (sad_amd._runtime.placed_streams: main
     streams alone on their dispatch pipes) eight sampling streams are best everywhere (profiles/r05_stream_placement.txt):
     f32 14.5 k at the driver's setting against 14.2 - 14.3 k with 2 - 4, bf16 47.7 k against 46.8 k with 6, nuScenes-shaped
-    7.05 k against 6.97 k; ten or more need more hardware queues than the device serves at full speed (37 k / 7 k)."""
-    return 8
+    7.05 k against 6.97 k; ten or more need more hardware queues than the device serves at full speed (37 k / 7 k).
+    Six under a process group (queue budget: above): f32 15.15 against 15.2 k."""
+    return 6 if DISTRIBUTED else 8
 
 
 def batch_first_scene(k: int, rank: int, world: int, B: int) -> int:
@@ -384,7 +392,7 @@ def shared_streams(dev, n_side: int, n_main: int):
     """ONE set of sampling / main streams (and one gather stream) for every detector this process builds: each stream
     ever created keeps a place among the GPU_MAX_HW_QUEUES hardware queues, and the three detectors of a default run
     would otherwise create 24 (the last one then ran its FPS chains two to a queue: 3.1 k instead of 5.4 k scenes/s).
-    The whole set (eight sampling streams: what the bf16 legs use) is made at the first call, in the order that keeps the
+    The whole set (eight sampling streams, six under a process group: `DISTRIBUTED`) is made at the first call, in the order that keeps the
     main streams alone on their dispatch pipes (sad_amd._runtime.placed_streams)."""
     from sad_amd import _runtime
     from sad_amd.dist import AsyncBoxGather
@@ -393,8 +401,9 @@ def shared_streams(dev, n_side: int, n_main: int):
         if st is not None:
             raise SystemExit(f"shared_streams: {n_side} sampling / {n_main} main streams asked for after the set was made "
                              f"with {len(st['side'])} / {len(st['main'])}")
-        side, main, extra = _runtime.placed_streams(dev, max(n_side, 8), max(n_main, 2), 2)
-        st = _STREAMS[str(dev)] = {"side": side, "main": main, "gather": AsyncBoxGather(dev, stream=extra[0]), "ingest": extra[1]}
+        side, main, extra = _runtime.placed_streams(dev, max(n_side, default_fps_streams("f32")), max(n_main, 2), 1 if DISTRIBUTED else 2)
+        st = _STREAMS[str(dev)] = {"side": side, "main": main, "gather": AsyncBoxGather(dev, stream=extra[0]),
+                                   "ingest": extra[1] if len(extra) > 1 else None}
     return (st["side"][:n_side], st["main"][:n_main]), st["gather"]
 
 
@@ -1084,6 +1093,9 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:                                                        # rehearsal on a one-GPU box
             dist.init_process_group(backend)
+
+    global DISTRIBUTED
+    DISTRIBUTED = dist.is_initialized()
 
     from sad_amd import _lib
     for kv in args.opt:

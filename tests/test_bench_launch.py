@@ -102,6 +102,10 @@ def test_bench_batch_rotation_and_workload_defaults():
     assert len(seen) == world * 4 * B
     w = b.Workload("kitti", "kitti", "f32", 32)
     assert (w.fps_streams, w.main_streams, w.queue_depth, w.n_batches) == (8, 2, 10, 4)     # (eight sampling streams since the stream placement: DESIGN 5)
+    b.DISTRIBUTED = True          # under a process group: a smaller stream set (the backend needs hardware queues of its own)
+    w = b.Workload("kitti", "kitti", "f32", 32)
+    assert (w.fps_streams, w.queue_depth) == (6, 8)
+    b.DISTRIBUTED = False
     w = b.Workload("nuscenes", "kitti", "bf16", 32, n_batches=2)
     assert (w.fps_streams, w.queue_depth, w.n_batches) == (8, 10, 2) and w.peak() == b.PEAK_MFMA_BF16_TFLOPS
     assert "nuScenes" in w.describe() and "configs[4]" in w.describe()
