@@ -116,11 +116,26 @@ _PLACEHOLDERS = []          # the dummy streams stay alive: a destroyed stream g
 
 
 def placement_order(n_side: int, n_main: int, n_extra: int):
-    """The order of first use: a list of ("side", i) / ("main", i) / ("extra", i) / ("dummy", None).  With more than two
+    """The order of first use: a list of ("side", i) / ("main", i) / ("extra", i) / ("dummy", None).  With more than three
     main streams there is no pipe to spare: plain order."""
-    if n_main > 2 or os.environ.get("SAD_NO_STREAM_PLACEMENT"):
+    if n_main > 3 or os.environ.get("SAD_NO_STREAM_PLACEMENT"):
         return ([("side", i) for i in range(n_side)] + [("main", i) for i in range(n_main)] +
                 [("extra", i) for i in range(n_extra)])
+    if n_main == 3:
+        # three main streams take three pipes (places 1, 2, 3); everything else shares the fourth (places 0, 4, 8, ...)
+        rest = [("side", i) for i in range(n_side)] + [("extra", i) for i in range(n_extra)]
+        order, mains, p = [], [("main", i) for i in range(3)], 0
+        while rest or mains:
+            if p % 4 == 0:
+                order.append(rest.pop(0) if rest else ("dummy", None))
+            elif p in (1, 2, 3):
+                order.append(mains.pop(0))
+            else:
+                order.append(("dummy", None))
+            p += 1
+        while order and order[-1][0] == "dummy":
+            order.pop()
+        return order
     even = [("side", i) for i in range(n_side)] + [("extra", i) for i in range(n_extra)]
     odd = [("main", i) for i in range(n_main)]
     order = []

@@ -401,7 +401,10 @@ def shared_streams(dev, n_side: int, n_main: int):
         if st is not None:
             raise SystemExit(f"shared_streams: {n_side} sampling / {n_main} main streams asked for after the set was made "
                              f"with {len(st['side'])} / {len(st['main'])}")
-        side, main, extra = _runtime.placed_streams(dev, max(n_side, default_fps_streams("f32")), max(n_main, 2), 1 if DISTRIBUTED else 2)
+        if n_main >= 3:       # (three main streams: every other stream shares ONE pipe, four queue numbers apiece: only what this run needs)
+            side, main, extra = _runtime.placed_streams(dev, n_side, n_main, 1)
+        else:
+            side, main, extra = _runtime.placed_streams(dev, max(n_side, default_fps_streams("f32")), max(n_main, 2), 1 if DISTRIBUTED else 2)
         st = _STREAMS[str(dev)] = {"side": side, "main": main, "gather": AsyncBoxGather(dev, stream=extra[0]),
                                    "ingest": extra[1] if len(extra) > 1 else None}
     return (st["side"][:n_side], st["main"][:n_main]), st["gather"]

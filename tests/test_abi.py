@@ -297,7 +297,12 @@ def test_stream_placement_order(monkeypatch):
             if k == "main":
                 same_pipe = [kinds[q] for q in range(len(order)) if q != pos and q % 4 == pos % 4]
                 assert all(x == "dummy" for x in same_pipe), (n_side, n_main, n_extra, order)
-    # three main streams: no pipe to spare, plain order, no dummies; and the A/B switch
-    assert [k for k, _ in _runtime.placement_order(6, 3, 1)] == ["side"] * 6 + ["main"] * 3 + ["extra"]
+    # three main streams: each on a pipe of its own, everything else on the fourth
+    order = _runtime.placement_order(4, 3, 1)
+    kinds = [k for k, _ in order]
+    assert kinds[:4] == ["side", "main", "main", "main"] and kinds.count("side") == 4 and kinds.count("extra") == 1
+    assert all(k == "dummy" for q, k in enumerate(kinds) if q > 3 and q % 4 != 0) and all(k != "dummy" for q, k in enumerate(kinds) if q % 4 == 0)
+    # four main streams: no pipe to spare, plain order, no dummies; and the A/B switch
+    assert [k for k, _ in _runtime.placement_order(6, 4, 1)] == ["side"] * 6 + ["main"] * 4 + ["extra"]
     monkeypatch.setenv("SAD_NO_STREAM_PLACEMENT", "1")
     assert [k for k, _ in _runtime.placement_order(3, 2, 1)] == ["side"] * 3 + ["main"] * 2 + ["extra"]
