@@ -129,7 +129,11 @@ class SADDetector(nn.Module):
         exposes its completion as ``post.event`` (``dist.AsyncBoxGather``), that event is returned,
         otherwise one recorded on the main stream behind the hook.  ``ready``: an event behind whatever produces ``points``
         on another stream (``pipeline.IngestPipeline``: H2D copy + subsample / pad) — the sampling stream and the main stream
-        wait for it instead of for each other."""
+        wait for it instead of for each other.
+        ``result`` belongs to the main stream that produced it (an eager step: a fresh tensor of that stream's allocator pool; a
+        replayed step: the slot's buffer).  A consumer on ANY other stream — the null stream included: torch's streams do not
+        synchronise with it — waits for ``done_event`` and then either finishes reading before the next submits reuse the memory
+        (``stream.synchronize()`` behind an asynchronous ``clone()``) or calls ``result.record_stream(its_stream)``."""
         st = self._mains[self._submits % len(self._mains)]
         slot = self._submits % self._plan_ring
         self._submits += 1

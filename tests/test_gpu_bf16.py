@@ -676,6 +676,7 @@ def test_bf16_pipelined_steps_soak(sad, dev):
         out, ev = ref_det.submit(b)
         ev.synchronize()
         want.append(out.clone())
+        torch.cuda.current_stream().synchronize()        # (the copy is on the null stream: done before the next step reuses `out`'s block)
     det = SADDetector(cfg, w, dev, dtype="bf16", streams=(ref_det._sides, ref_det._mains))
     pending, bad = [], 0
     for i in range(60 * stress):

@@ -48,7 +48,10 @@ def test_replayed_steps_equal_eager_steps_on_other_inputs(sad, dev, dtype):
     for b in batches:
         out, ev = eager.submit(b)
         ev.synchronize()
+        # (the copy runs on the null stream, which nothing orders against the main stream that owns `out`: it has to be DONE before
+        # the next eager step frees `out` and reuses its block — the consumer's side of the submit() contract)
         want.append(out.clone())
+        torch.cuda.current_stream().synchronize()
     det = SADDetector(cfg, w, dev, dtype=dtype, streams=(eager._sides, eager._mains))
     for i in range(40):
         out, ev = det.submit(batches[i % 5])
