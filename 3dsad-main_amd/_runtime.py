@@ -106,13 +106,14 @@ def check_stream_budget(n_streams: int, state: str, environ=None) -> bool:
 # ---- stream placement --------------------------------------------------------------------------------------------------
 # A HIP stream takes its hardware queue when it is first used, queues are numbered in that order, and queues whose numbers
 # differ by a multiple of four are served by the same dispatch pipe of the command processor (measured on MI355X, round 5:
-# DESIGN.md §9 "stream placement").  A main stream — ~40 launches per step, many of them a few microseconds long — that shares
+# DESIGN.md §5 "stream placement", profiles/r05_pipe_rule.txt).  A main stream — ~40 launches per step, many of them a few microseconds long — that shares
 # its pipe with a sampling stream, with the gather stream (whose head packet is a barrier waiting for the step's end) or with
 # the other main stream loses 4 - 7 % of the pipelined step: its short kernels wait for the pipe.  So the streams of a
 # pipeline are created AND touched here in an order that leaves each main stream alone on its pipe: sampling and extra
 # streams take the even places, the (at most two) main streams the first two odd places, idle dummy streams the later odd
 # places.  Whatever took queues before (the null stream) is idle while the pipeline runs.
-_PLACEHOLDERS = []          # the dummy streams stay alive: a destroyed stream gives its queue back
+_PLACEHOLDERS = []          # the idle streams (torch takes streams from a pool and never destroys them; kept for the record)
+_SETS = {}                  # (device, n_side, n_main, n_extra) -> the set made for it: see placed_streams
 
 
 def placement_order(n_side: int, n_main: int, n_extra: int):
@@ -157,8 +158,17 @@ def placement_order(n_side: int, n_main: int, n_extra: int):
 
 def placed_streams(device, n_side: int, n_main: int, n_extra: int = 0):
     """(sampling streams, main streams, extra streams) of one pipeline on ``device``, each touched once (an event record and
-    a wait: the stream has its hardware queue afterwards) in ``placement_order``."""
+    a wait: the stream has its hardware queue afterwards) in ``placement_order``.
+    ONE set per device and shape: a second call with the same counts returns the same streams.  Queue numbers only mean
+    something for the first streams a process maps (torch hands out 32 pool streams round-robin, the device serves 24 queues
+    at full speed), so a second set could be neither placed nor given queues of its own; detectors that share a set are
+    ordered against each other on it, which is what ``SADDetector(streams=...)`` asks a process with several detectors to do
+    anyway.  ``SAD_NEW_STREAMS_PER_DETECTOR=1``: a fresh set per call (the behaviour before; for experiments)."""
     import torch
+    key = (str(torch.device(device)), n_side, n_main, n_extra)
+    if key in _SETS and not os.environ.get("SAD_NEW_STREAMS_PER_DETECTOR"):
+        side, main, extra = _SETS[key]
+        return list(side), list(main), list(extra)
     out = {"side": [None] * n_side, "main": [None] * n_main, "extra": [None] * n_extra}
     for kind, i in placement_order(n_side, n_main, n_extra):
         s = torch.cuda.Stream(device=device)
@@ -169,4 +179,5 @@ def placed_streams(device, n_side: int, n_main: int, n_extra: int = 0):
         e = torch.cuda.Event()
         e.record(s)
         s.synchronize()
-    return out["side"], out["main"], out["extra"]
+    _SETS[key] = (out["side"], out["main"], out["extra"])
+    return list(out["side"]), list(out["main"]), list(out["extra"])

@@ -39,7 +39,8 @@ class SADDetector(nn.Module):
         ``_runtime.placed_streams`` (each main stream alone on its dispatch pipe) together with ``n_extra_streams`` more for the
         caller: ``det.extra_streams[0]`` is meant for the gather (``dist.AsyncBoxGather(dev, stream=...)``), ``[1]`` for the ingest
         stream of ``pipeline.IngestPipeline`` — a stream the caller creates later lands wherever the next queue number falls,
-        possibly on a main stream's pipe (4 - 7 % of the pipelined step: DESIGN.md §9)."""
+        possibly on a main stream's pipe (4 - 7 % of the pipelined step: DESIGN.md §5).  Detectors of one process that ask for
+        the same stream counts get the SAME set (``_runtime.placed_streams``)."""
         super().__init__()
         if dtype not in ("f32", "bf16"):
             raise ValueError("dtype must be 'f32' or 'bf16'")
@@ -97,7 +98,8 @@ class SADDetector(nn.Module):
             if len(streams[0]) < n_side or len(streams[1]) < n_main:
                 raise ValueError(f"streams: need {n_side} sampling and {n_main} main streams")
         dkey = self.device.index if self.device.index is not None else torch.cuda.current_device()   # (hardware queues are per device)
-        made = SADDetector._streams_created.get(dkey, 0) + (0 if streams is not None else len(_runtime.placement_order(n_side, n_main, max(0, n_extra_streams))))
+        new_set = streams is None and (str(self.device), n_side, n_main, max(0, n_extra_streams)) not in _runtime._SETS
+        made = SADDetector._streams_created.get(dkey, 0) + (len(_runtime.placement_order(n_side, n_main, max(0, n_extra_streams))) if new_set else 0)
         SADDetector._streams_created[dkey] = made
         _runtime.check_stream_budget(max(n_side + n_main, made) + 1, HW_QUEUES_STATE)
         # (own streams: created and touched in the order that leaves each main stream alone on its dispatch pipe, _runtime.py)
